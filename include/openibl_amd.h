@@ -1,0 +1,180 @@
+/*
+ * openibl_amd.h — C ABI of the MI355X (gfx950) descriptor + matching hot path.
+ *
+ * This is the drop-in boundary.  The reference (yxgeee/OpenIBL) has no
+ * FFI of its own: its hot path is the Python call surface ibl.models / ibl.pca /
+ * ibl.evaluators.  Every entry point below replaces the device work of one reference
+ * function (cited per function as path:line under the reference tree) and is what a
+ * ctypes binding added to the reference would bind.
+ *
+ * Conventions
+ *   - plain C: pointers and sizes only, no torch / C++ types.
+ *   - every pointer argument is a DEVICE pointer valid on the current HIP device unless
+ *     the name ends in _host.
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous and
+ *     stream-ordered; re-entrant across streams (no hidden global state besides the
+ *     thread-local error string).
+ *   - no hidden allocation: outputs and scratch are caller-provided; scratch size comes
+ *     from the matching *_workspace_bytes() query.  Workspace pointers must be 256-byte
+ *     aligned.
+ *   - return value: 0 = OK, negative = error (OIBL_E_*); message via oibl_last_error().
+ *   - `precision` selects the arithmetic of the contraction:
+ *       OIBL_BF16 : bf16 operands, fp32 accumulate on v_mfma_f32_32x32x16_bf16
+ *       OIBL_F32  : exact fp32 on v_mfma_f32_32x32x2_f32 (parity mode)
+ *     and with it the element type of activation / packed-weight buffers ("T" below:
+ *     uint16 bf16 bits or float).
+ */
+#ifndef OPENIBL_AMD_H
+#define OPENIBL_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OIBL_OK 0
+#define OIBL_E_INVALID (-1)   /* bad argument (shape, alignment, null pointer)      */
+#define OIBL_E_WORKSPACE (-2) /* workspace too small                                */
+#define OIBL_E_HIP (-3)       /* a HIP runtime call / kernel launch failed           */
+#define OIBL_E_UNSUPPORTED (-4)
+
+#define OIBL_BF16 0
+#define OIBL_F32 1
+
+#define OIBL_VGG16_NUM_CONV 13
+
+/* ---- library ---------------------------------------------------------------------- */
+
+/* ABI version of this header (bumped on any signature change). */
+int oibl_abi_version(void);
+/* Last error message of the calling thread (never NULL). */
+const char* oibl_last_error(void);
+/* Name of the gfx target the kernels were compiled for ("gfx950"). */
+const char* oibl_target_arch(void);
+/* sizeof(T) for a precision code, 0 if unknown. */
+size_t oibl_elem_size(int precision);
+
+/* ---- element conversion helpers --------------------------------------------------- */
+
+/* fp32 -> bf16 (round-to-nearest-even), n elements. */
+int oibl_cast_f32_to_bf16(const float* src, uint16_t* dst, size_t n, void* stream);
+/* bf16 -> fp32, n elements. */
+int oibl_cast_bf16_to_f32(const uint16_t* src, float* dst, size_t n, void* stream);
+
+/* ---- VGG16 conv1_1 .. conv5_3 backbone -------------------------------------------- *
+ * Replaces VGG.forward's `self.base(x)`  (ibl/models/vgg.py:61-62; layer list built at
+ * vgg.py:40-42 = torchvision vgg16.features[:-2]: 13 conv3x3(pad 1)+bias, ReLU after all
+ * but the last, 2x2/2 max-pool after conv1_2, conv2_2, conv3_3, conv4_3).                */
+
+/* Re-pack one conv weight from the state-dict layout [Cout][Cin][3][3] fp32 into the
+ * kernel layout [tap=ky*3+kx][Cout][Cin_pad] of T (Cin_pad = Cin rounded up to the K-step:
+ * 64 elements bf16 / 32 fp32; pad is zero).  packed must hold
+ * oibl_conv3x3_packed_bytes(cout, cin, precision) bytes. */
+size_t oibl_conv3x3_packed_bytes(int cout, int cin, int precision);
+int oibl_pack_conv3x3_weights(const float* w_oihw, int cout, int cin, int precision,
+                              void* packed, void* stream);
+
+/* One 3x3 / pad 1 / stride 1 convolution + bias (+ReLU) (+2x2/2 max-pool, floor) on NHWC
+ * activations: in [N][H][W][Cin] T -> out [N][Ho][Wo][Cout] T, (Ho,Wo) = (H,W) or
+ * (H/2,W/2) when pool != 0.  Cin % 64 == 0 (bf16) / % 32 (fp32); Cout % 64 == 0.
+ * (nn.Conv2d + nn.ReLU + nn.MaxPool2d modules of vgg.py:41-42.) */
+int oibl_conv3x3_nhwc(const void* in, int N, int H, int W, int cin, const void* packed_w,
+                      const float* bias, int cout, int relu, int pool, int precision,
+                      void* out, void* stream);
+
+/* First layer: reads the reference's input tensor directly — x [N][3][H][W] fp32 NCHW
+ * (already mean/std normalised, ibl/utils/data/__init__.py:40-41) — conv1_1 + bias + ReLU,
+ * writes NHWC T [N][H][W][64].  w is the plain state-dict tensor [64][3][3][3] fp32. */
+int oibl_conv1_1_nchw(const float* x_nchw, int N, int H, int W, const float* w_oihw,
+                      const float* bias, int precision, void* out, void* stream);
+
+/* Global max-pool over positions of an NHWC feature map -> pool_x [N][C] fp32
+ * (nn.AdaptiveMaxPool2d(1), vgg.py:43,67-68). */
+int oibl_global_maxpool_nhwc(const void* feat, int N, int P, int C, int precision,
+                             float* out, void* stream);
+
+/* NHWC T -> NCHW fp32 (the layout VGG.forward returns `x` in, vgg.py:70). */
+int oibl_nhwc_to_nchw_f32(const void* feat, int N, int P, int C, int precision, float* out,
+                          void* stream);
+/* NCHW fp32 -> NHWC T (to feed NetVLAD.forward from a reference-layout tensor). */
+int oibl_nchw_f32_to_nhwc(const float* x, int N, int C, int P, int precision, void* out,
+                          void* stream);
+
+/* Whole backbone: x [N][3][H][W] fp32 -> feat [N][P][512] T, P = (H/16)*(W/16) (floor at
+ * every pool).  packed_w_host / bias_host are HOST arrays of 13 DEVICE pointers: entry 0
+ * is the plain [64][3][3][3] fp32 conv1_1 weight, entries 1..12 are packed by
+ * oibl_pack_conv3x3_weights; bias entries are [Cout] fp32. */
+size_t oibl_vgg16_workspace_bytes(int N, int H, int W, int precision);
+int oibl_vgg16_conv5_forward(const float* x_nchw, int N, int H, int W,
+                             const void* const* packed_w_host,
+                             const float* const* bias_host, int precision, void* feat,
+                             void* ws, size_t ws_bytes, void* stream);
+
+/* ---- NetVLAD + intra-norm + L2 ---------------------------------------------------- *
+ * Replaces NetVLAD.forward (ibl/models/netvlad.py:44-61) and the normalisation that
+ * every Embed* module applies to it (netvlad.py:78-80 / 100-102 / 202-204):
+ *   xh = x / max(|x|_2, 1e-12)  per position; a = softmax_k(assign_w . xh);
+ *   vlad[k][c] = sum_p a[p][k] * (xh[p][c] - centroids[k][c]).
+ * feat [N][P][C] T (NHWC feature map), assign_w [K][C] fp32 (conv.weight[:, :, 0, 0]),
+ * centroids [K][C] fp32.  K = 64, C = 512 are what the kernels are built for.
+ *   vlad_raw  (optional, may be NULL): [N][K][C] fp32 un-normalised — NetVLAD.forward's
+ *             return value.
+ *   vlad_norm (optional, may be NULL): [N][K*C] fp32, intra-normalised per cluster then
+ *             L2-normalised over K*C, k-major (index k*C + c).
+ *   normalize_input: NetVLAD(normalize_input=...) (netvlad.py:46-47).                    */
+size_t oibl_netvlad_workspace_bytes(int N, int P, int K, int C);
+int oibl_netvlad_forward(const void* feat, int N, int P, int K, int C, int precision,
+                         const float* assign_w, const float* centroids, int normalize_input,
+                         float* vlad_raw, float* vlad_norm, void* ws, size_t ws_bytes,
+                         void* stream);
+
+/* ---- PCA-whitening projection + L2 ------------------------------------------------ *
+ * Replaces EmbedNetPCA.pca_layer + F.normalize (netvlad.py:105-108) and PCA.infer
+ * (ibl/pca.py:108-123):  y = normalize(W v + b).
+ * v [N][D] fp32; w [d][D] T (row-major, i.e. pca_layer.weight[:, :, 0, 0], cast with
+ * oibl_cast_f32_to_bf16 for OIBL_BF16); b [d] fp32; out [N][d] fp32.
+ * D % 64 == 0, d % 128 == 0.  l2norm != 0 applies the final F.normalize.               */
+size_t oibl_pca_workspace_bytes(int N, int D, int d, int precision);
+int oibl_pca_forward(const float* v, int N, int D, const void* w, const float* b, int d,
+                     int precision, int l2norm, float* out, void* ws, size_t ws_bytes,
+                     void* stream);
+
+/* Row-wise L2 normalisation x / max(|x|_2, 1e-12)  (F.normalize(dim=-1), e.g. the extra
+ * one in extract_cnn_feature, ibl/evaluators.py:29-33).  In place allowed. */
+int oibl_l2_normalize_rows(const float* x, int N, int D, float* out, void* stream);
+
+/* ---- query x gallery squared-L2 --------------------------------------------------- *
+ * Replaces the arithmetic of pairwise_distance (ibl/evaluators.py:122-129):
+ *   dist[i][j] = |x_i|^2 + |y_j|^2 - 2 x_i . y_j      (no clamp, no sqrt)
+ * x [m][d] fp32, y [n][d] fp32, dist [m][ldd] fp32 (ldd >= n).  d % 64 == 0.
+ * OIBL_BF16 rounds x,y to bf16 for the dot product only (norms stay fp32).              */
+size_t oibl_pairwise_workspace_bytes(int m, int n, int d, int precision);
+int oibl_pairwise_sqdist(const float* x, int m, const float* y, int n, int d,
+                         int precision, float* dist, size_t ldd, void* ws, size_t ws_bytes,
+                         void* stream);
+
+/* ---- top-k ------------------------------------------------------------------------ *
+ * Replaces np.argsort(distmat, axis=1) (ibl/evaluators.py:143), of which evaluate_all only
+ * consumes the first max(recall_topk) (or 12x that with nms) entries per row.
+ * Per row of vals [m][ld] keep the k smallest, ascending, ties broken by lowest index:
+ *   out_val [m][k] fp32, out_idx [m][k] int32.
+ * idx_in == NULL: element j of a row has index index_base + j (gallery shard offset);
+ * idx_in != NULL ([m][ld] int32): element j has index idx_in[row][j] (cross-shard merge).
+ * 1 <= k <= 1024; if n < k the tail is filled with (+inf, -1).                          */
+int oibl_row_topk(const float* vals, const int32_t* idx_in, int m, int n, size_t ld, int k,
+                  int index_base, float* out_val, int32_t* out_idx, void* stream);
+
+/* ---- diagnostics ------------------------------------------------------------------ */
+
+/* Plain C = A . B^T on the shared MFMA GEMM core (used by tests to validate the core and
+ * its fragment layout independently of the operators above):
+ * A [M][K] T, B [N][K] T, C [M][ldc] fp32; K % (128/sizeof(T)) == 0, N % 64 == 0. */
+int oibl_gemm_nt(const void* A, int M, const void* B, int N, int K, int precision, float* C,
+                 size_t ldc, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPENIBL_AMD_H */

@@ -1,0 +1,98 @@
+"""Build the gfx950 HIP extension in-tree:  openibl_amd/libopenibl_amd.so.
+
+Plain hipcc (no cmake, no torch cpp_extension): each csrc/*.hip is compiled for gfx950 and the
+objects are linked into one C-ABI shared library that `openibl_amd.lib` loads with ctypes.
+hipcc cross-compiles without a GPU, so this runs in the build container; the .so is git-ignored
+but travels to the GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+ROOT = PKG_DIR.parent
+CSRC = PKG_DIR / "csrc"
+INCLUDE = ROOT / "include"
+BUILD_DIR = ROOT / "build" / "obj"
+LIB_PATH = PKG_DIR / "libopenibl_amd.so"
+ARCH = "gfx950"
+
+CXXFLAGS = [
+    f"--offload-arch={ARCH}",
+    "-O3",
+    "-std=c++17",
+    "-fPIC",
+    "-fno-gpu-rdc",
+    "-Wall",
+    "-Wno-unused-function",
+    f"-I{INCLUDE}",
+    f"-I{CSRC}",
+]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(exe).exists():
+        raise RuntimeError("hipcc not found: the MI355X extension cannot be built on this machine")
+    return exe
+
+
+def sources() -> list[Path]:
+    return sorted(CSRC.glob("*.hip"))
+
+
+def _digest() -> str:
+    h = hashlib.sha256()
+    for p in sorted(list(CSRC.glob("*")) + [INCLUDE / "openibl_amd.h", Path(__file__)]):
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    h.update(" ".join(CXXFLAGS).encode())
+    return h.hexdigest()
+
+
+def is_current() -> bool:
+    stamp = BUILD_DIR / "stamp"
+    return LIB_PATH.exists() and stamp.exists() and stamp.read_text() == _digest()
+
+
+def build(force: bool = False, verbose: bool = True) -> Path:
+    """Compile every HIP source for gfx950 and link libopenibl_amd.so.  Returns its path."""
+    if not force and is_current():
+        return LIB_PATH
+    hipcc = _hipcc()
+    BUILD_DIR.mkdir(parents=True, exist_ok=True)
+    srcs = sources()
+    objs = [BUILD_DIR / (s.stem + ".o") for s in srcs]
+
+    def compile_one(pair):
+        src, obj = pair
+        cmd = [hipcc, *CXXFLAGS, "-c", str(src), "-o", str(obj)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src.name}:\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print(f"[openibl_amd.build] compiled {src.name}", file=sys.stderr)
+        return r.stderr
+
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        list(ex.map(compile_one, zip(srcs, objs)))
+
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fno-gpu-rdc",
+           *map(str, objs), "-o", str(LIB_PATH)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    (BUILD_DIR / "stamp").write_text(_digest())
+    if verbose:
+        print(f"[openibl_amd.build] linked {LIB_PATH}", file=sys.stderr)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,203 @@
+// Library-level entry points: error string, casts, row normalisation and the bare NT GEMM used
+// by the tests to validate the MFMA core.  See include/openibl_amd.h.
+#include <stdarg.h>
+#include <string.h>
+
+#include "gemm_core.h"
+
+namespace oibl {
+
+static thread_local char g_err[512] = "";
+int g_regstage = 0;
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+__device__ uint4 g_zero_line[8];  // 128 B, zero-initialised device memory
+
+const void* zero_line_device_ptr() {
+  void* p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_zero_line)) != hipSuccess) return nullptr;
+  return p;
+}
+
+// ---- casts ---------------------------------------------------------------------------
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst,
+                                     size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x * 8;
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
+    if (i + 8 <= n) {
+      const float4 a = *reinterpret_cast<const float4*>(src + i);
+      const float4 b = *reinterpret_cast<const float4*>(src + i + 4);
+      uint4 o;
+      o.x = f32_to_bf16_bits(a.x) | ((uint32_t)f32_to_bf16_bits(a.y) << 16);
+      o.y = f32_to_bf16_bits(a.z) | ((uint32_t)f32_to_bf16_bits(a.w) << 16);
+      o.z = f32_to_bf16_bits(b.x) | ((uint32_t)f32_to_bf16_bits(b.y) << 16);
+      o.w = f32_to_bf16_bits(b.z) | ((uint32_t)f32_to_bf16_bits(b.w) << 16);
+      *reinterpret_cast<uint4*>(dst + i) = o;
+    } else {
+      for (size_t k = i; k < n; ++k) dst[k] = f32_to_bf16_bits(src[k]);
+    }
+  }
+}
+
+__global__ void cast_bf16_f32_kernel(const uint16_t* __restrict__ src, float* __restrict__ dst,
+                                     size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    dst[i] = bf16_bits_to_f32(src[i]);
+}
+
+// ---- row L2 normalise -------------------------------------------------------------------
+// one wave per row; x / max(||x||, 1e-12) as F.normalize does.
+__global__ void l2_normalize_rows_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                         int N, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const float* xr = x + (size_t)row * D;
+  float s = 0.f;
+  for (int i = lane; i < D; i += 64) s += xr[i] * xr[i];
+  s = wave_sum(s);
+  const float inv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+  float* orow = out + (size_t)row * D;
+  for (int i = lane; i < D; i += 64) orow[i] = xr[i] * inv;
+}
+
+// ---- bare NT GEMM (diagnostic) ------------------------------------------------------------
+template <typename Cfg, bool GLDS>
+__global__ __launch_bounds__(Cfg::NTHREADS) void gemm_nt_kernel(const void* A, int M,
+                                                                const void* B, int N, int K,
+                                                                float* C, size_t ldc) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using T = typename Cfg::T;
+  const WaveCoord c = wave_coord<Cfg>();
+  const int tiles_n = N / Cfg::BN;
+  const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = tile % tiles_n, tm = tile / tiles_n;
+  const long m0 = (long)tm * Cfg::BM, n0 = (long)tn * Cfg::BN;
+
+  RowLoader<Cfg, Cfg::A_LOADS> la;
+  RowLoader<Cfg, Cfg::B_LOADS> lb;
+  la.init(c, A, m0, M, (long)K * sizeof(T));
+  lb.init(c, B, n0, N, (long)K * sizeof(T));
+
+  f32x16_t acc[Cfg::TM][Cfg::TN];
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  gemm_nt_mainloop<Cfg, GLDS>(acc, smem, c, la, lb, K / Cfg::BK);
+
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long m = m0 + (c.wm * Cfg::TM + i) * 32 + acc_row(r, c.lane);
+        const long n = n0 + (c.wn * Cfg::TN + j) * 32 + (c.lane & 31);
+        if (m < M) C[m * ldc + n] = acc[i][j][r];
+      }
+}
+
+template <typename T, bool GLDS>
+static int launch_gemm_nt(const void* A, int M, const void* B, int N, int K, float* C,
+                          size_t ldc, hipStream_t st) {
+  using Cfg = GemmCfg<T, 2, 2, 2, 2>;
+  using Cfg64 = GemmCfg<T, 2, 2, 2, 1>;
+  if (N % 128 == 0) {
+    const int grid = ((M + Cfg::BM - 1) / Cfg::BM) * (N / Cfg::BN);
+    hipLaunchKernelGGL((gemm_nt_kernel<Cfg, GLDS>), dim3(grid), dim3(Cfg::NTHREADS),
+                       Cfg::MAIN_LDS_BYTES, st, A, M, B, N, K, C, ldc);
+  } else {
+    const int grid = ((M + Cfg64::BM - 1) / Cfg64::BM) * (N / Cfg64::BN);
+    hipLaunchKernelGGL((gemm_nt_kernel<Cfg64, GLDS>), dim3(grid), dim3(Cfg64::NTHREADS),
+                       Cfg64::MAIN_LDS_BYTES, st, A, M, B, N, K, C, ldc);
+  }
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
+
+}  // namespace oibl
+
+using namespace oibl;
+
+extern "C" {
+
+// test hook (not in the public header): 1 = register-staged main loop, 0 = global_load_lds
+int oibl_debug_set_regstage(int on) {
+  g_regstage = on ? 1 : 0;
+  return OIBL_OK;
+}
+
+int oibl_abi_version(void) { return 1; }
+const char* oibl_last_error(void) { return g_err; }
+const char* oibl_target_arch(void) { return "gfx950"; }
+size_t oibl_elem_size(int precision) {
+  return precision == OIBL_BF16 ? 2 : precision == OIBL_F32 ? 4 : 0;
+}
+
+int oibl_cast_f32_to_bf16(const float* src, uint16_t* dst, size_t n, void* stream) {
+  OIBL_REQUIRE(src && dst, "cast_f32_to_bf16: null pointer");
+  if (n == 0) return OIBL_OK;
+  OIBL_REQUIRE(((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0),
+               "cast_f32_to_bf16: pointers must be 16-byte aligned");
+  size_t blocks = (n / 8 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, src, dst, n);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
+
+int oibl_cast_bf16_to_f32(const uint16_t* src, float* dst, size_t n, void* stream) {
+  OIBL_REQUIRE(src && dst, "cast_bf16_to_f32: null pointer");
+  if (n == 0) return OIBL_OK;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, src, dst, n);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
+
+int oibl_l2_normalize_rows(const float* x, int N, int D, float* out, void* stream) {
+  OIBL_REQUIRE(x && out, "l2_normalize_rows: null pointer");
+  OIBL_REQUIRE(N >= 0 && D > 0, "l2_normalize_rows: bad shape N=%d D=%d", N, D);
+  if (N == 0) return OIBL_OK;
+  hipLaunchKernelGGL(l2_normalize_rows_kernel, dim3((N + 3) / 4), dim3(256), 0,
+                     (hipStream_t)stream, x, out, N, D);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
+
+// precision bit 8 (0x100) selects the register-staged variant of the main loop (test hook).
+int oibl_gemm_nt(const void* A, int M, const void* B, int N, int K, int precision, float* C,
+                 size_t ldc, void* stream) {
+  const bool regstage = (precision & 0x100) != 0;
+  precision &= 0xff;
+  OIBL_REQUIRE(A && B && C, "gemm_nt: null pointer");
+  OIBL_REQUIRE(precision == OIBL_BF16 || precision == OIBL_F32, "gemm_nt: bad precision %d",
+               precision);
+  const int bk = precision == OIBL_BF16 ? 64 : 32;
+  OIBL_REQUIRE(M > 0 && N > 0 && K > 0 && K % bk == 0 && N % 64 == 0 && ldc >= (size_t)N,
+               "gemm_nt: unsupported shape M=%d N=%d K=%d", M, N, K);
+  OIBL_REQUIRE((uintptr_t)A % 16 == 0 && (uintptr_t)B % 16 == 0, "gemm_nt: unaligned operand");
+  hipStream_t st = (hipStream_t)stream;
+  if (precision == OIBL_BF16)
+    return regstage ? launch_gemm_nt<bf16_t, false>(A, M, B, N, K, C, ldc, st)
+                    : launch_gemm_nt<bf16_t, true>(A, M, B, N, K, C, ldc, st);
+  return regstage ? launch_gemm_nt<float, false>(A, M, B, N, K, C, ldc, st)
+                  : launch_gemm_nt<float, true>(A, M, B, N, K, C, ldc, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,126 @@
+// Shared host/device helpers for the gfx950 kernels.  Internal; the public surface is
+// include/openibl_amd.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "openibl_amd.h"
+
+namespace oibl {
+
+// ---- error plumbing (host) ---------------------------------------------------------
+void set_error(const char* fmt, ...);
+
+#define OIBL_REQUIRE(cond, ...)                 \
+  do {                                          \
+    if (!(cond)) {                              \
+      ::oibl::set_error(__VA_ARGS__);           \
+      return OIBL_E_INVALID;                    \
+    }                                           \
+  } while (0)
+
+#define OIBL_HIP_CHECK(expr)                                                          \
+  do {                                                                                \
+    hipError_t _e = (expr);                                                           \
+    if (_e != hipSuccess) {                                                           \
+      ::oibl::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                        __LINE__);                                                    \
+      return OIBL_E_HIP;                                                              \
+    }                                                                                 \
+  } while (0)
+
+#define OIBL_LAUNCH_CHECK()                                                          \
+  do {                                                                               \
+    hipError_t _e = hipGetLastError();                                               \
+    if (_e != hipSuccess) {                                                          \
+      ::oibl::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e),    \
+                        __FILE__, __LINE__);                                         \
+      return OIBL_E_HIP;                                                             \
+    }                                                                                \
+  } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- element types -------------------------------------------------------------------
+// bf16 is carried as raw 16-bit patterns; arithmetic always happens in fp32.
+struct bf16_t {
+  uint16_t bits;
+};
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+__host__ __device__ static inline uint16_t f32_to_bf16_bits(float f) {
+  // round-to-nearest-even; NaN kept quiet.
+  union {
+    float f;
+    uint32_t u;
+  } v;
+  v.f = f;
+  uint32_t u = v.u;
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+__host__ __device__ static inline float bf16_bits_to_f32(uint16_t b) {
+  union {
+    float f;
+    uint32_t u;
+  } v;
+  v.u = ((uint32_t)b) << 16;
+  return v.f;
+}
+
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+  __device__ static inline float load(const float* p) { return *p; }
+  __device__ static inline void store(float* p, float v) { *p = v; }
+  __device__ static inline float from_f32(float v) { return v; }
+  __device__ static inline float to_f32(float v) { return v; }
+};
+template <>
+struct Elem<bf16_t> {
+  __device__ static inline float load(const bf16_t* p) { return bf16_bits_to_f32(p->bits); }
+  __device__ static inline void store(bf16_t* p, float v) { p->bits = f32_to_bf16_bits(v); }
+  __device__ static inline bf16_t from_f32(float v) {
+    bf16_t r;
+    r.bits = f32_to_bf16_bits(v);
+    return r;
+  }
+  __device__ static inline float to_f32(bf16_t v) { return bf16_bits_to_f32(v.bits); }
+};
+
+// test hook: 1 = stage GEMM tiles through registers instead of global_load_lds
+extern int g_regstage;
+
+// 128 zero bytes: the source every out-of-image im2col tap points its load at.
+const void* zero_line_device_ptr();
+
+// wave-level reductions (wave = 64 lanes on gfx950)
+__device__ static inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ static inline float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Bijective XCD-aware remap of a 1-D block id: the hardware deals block b to XCD b % 8;
+// give every XCD a contiguous range of logical tiles so neighbouring tiles share an L2.
+__device__ static inline unsigned xcd_remap(unsigned bid, unsigned nblk) {
+  const unsigned xcd = bid & 7u, idx = bid >> 3;
+  const unsigned q = nblk >> 3, r = nblk & 7u;
+  const unsigned start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + idx;
+}
+
+}  // namespace oibl

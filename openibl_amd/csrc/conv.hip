@@ -1,0 +1,568 @@
+// VGG16 conv1_1..conv5_3 on gfx950: NHWC activations, 3x3 convolutions as implicit-GEMM on the
+// shared MFMA core (gemm_core.h), bias + ReLU + 2x2 max-pool fused into the epilogue.
+// Reference behaviour: ibl/models/vgg.py:40-42 (layer list), :61-70 (forward).
+#include "gemm_core.h"
+
+namespace oibl {
+
+// ---------------------------------------------------------------------------------------------
+// weight re-pack: [Cout][Cin][3][3] fp32 -> [tap][Cout][Cin] T
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__ packed, int cout,
+                                    int cin) {
+  const size_t total = (size_t)9 * cout * cin;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % cin);
+    const size_t t = i / cin;
+    const int co = (int)(t % cout);
+    const int tap = (int)(t / cout);
+    Elem<T>::store(packed + i, w[((size_t)co * cin + ci) * 9 + tap]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv1_1: x [N][3][H][W] fp32 -> out [N][H][W][64] T.   Cin = 3 gives K = 27: no MFMA shape fits
+// without an explicit im2col pass, and the layer is 0.56 % of the backbone FLOPs, so it runs on
+// the vector ALU in exact fp32:  lane = output channel (its 27 weights live in registers), a wave
+// walks a strip of 8 pixels; the strip's input window is wave-uniform (scalar/broadcast loads) and
+// every store is one full NHWC line (64 channels contiguous).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void conv1_1_kernel(const float* __restrict__ x,
+                                                      const float* __restrict__ w,
+                                                      const float* __restrict__ bias,
+                                                      T* __restrict__ out, int N, int H, int W) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int spr = (W + 7) >> 3;  // strips per row
+  const long nstrips = (long)N * H * spr;
+  const long strip = (long)blockIdx.x * 4 + wave;
+  if (strip >= nstrips) return;
+  const int n = (int)(strip / ((long)H * spr));
+  const int rem = (int)(strip - (long)n * H * spr);
+  const int y = rem / spr;
+  const int x0 = (rem - y * spr) * 8;
+
+  float wr[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) wr[k] = w[lane * 27 + k];
+  const float b = bias[lane];
+  float acc[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) acc[p] = b;
+
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int yy = y + ky - 1;
+      if (yy < 0 || yy >= H) continue;  // wave-uniform
+      const float* row = x + (((size_t)n * 3 + c) * H + yy) * W;
+      float v[10];
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        const int xx = x0 - 1 + i;
+        v[i] = (xx >= 0 && xx < W) ? row[xx] : 0.f;
+      }
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) acc[p] = fmaf(v[p + kx], wr[c * 9 + ky * 3 + kx], acc[p]);
+    }
+  }
+  T* o = out + (((size_t)n * H + y) * W + x0) * 64 + lane;
+#pragma unroll
+  for (int p = 0; p < 8; ++p)
+    if (x0 + p < W) Elem<T>::store(o + (size_t)p * 64, fmaxf(acc[p], 0.f));
+}
+
+// ---------------------------------------------------------------------------------------------
+// implicit-GEMM 3x3 convolution
+//   M = output pixels, N = Cout, K = 9 * Cin ordered (tap, cin).  A K-step is one tap x one
+//   128-byte run of input channels of each pixel, fetched straight from the NHWC tensor (or from a
+//   zero line when the tap falls outside the image).
+//   POOL: pixels are enumerated quad-major (m = 4*quad + 2*dy + dx over the floor(H/2) x floor(W/2)
+//   pooled grid), so that the four members of a 2x2 window are 4 consecutive GEMM rows = registers
+//   4g..4g+3 of one lane in the 32x32 accumulator layout: the pool is an in-register max and the
+//   kernel writes the pooled NHWC tensor directly.
+// ---------------------------------------------------------------------------------------------
+struct ConvParams {
+  const void* in;
+  const void* w;
+  const float* bias;
+  void* out;
+  const void* zero;
+  int N, H, W, cin, cout;
+  long m_total;   // GEMM rows (pixels enumerated, 4 per pooled output when POOL)
+  long out_rows;  // rows of the output tensor ( = m_total or m_total / 4)
+  int tiles_n;
+  int relu;
+};
+
+template <typename Cfg, bool POOL>
+struct ConvALoader {
+  const char* base[Cfg::A_LOADS];
+  unsigned mask[Cfg::A_LOADS];
+  const char* zero;
+  long tap_off;
+  int tap, cc, cchunks, W;
+  long pix_bytes;
+
+  __device__ inline void init(const WaveCoord& c, const ConvParams& p, long m0) {
+    using T = typename Cfg::T;
+    const int piece = load_piece_bytes<Cfg>(c);
+    pix_bytes = (long)p.cin * sizeof(T);
+    W = p.W;
+    cchunks = p.cin / Cfg::BK;
+    zero = reinterpret_cast<const char*>(p.zero) + (c.lane & 7) * 16;
+    const int Hq = POOL ? (p.H >> 1) : p.H, Wq = POOL ? (p.W >> 1) : p.W;
+#pragma unroll
+    for (int j = 0; j < Cfg::A_LOADS; ++j) {
+      const long m = m0 + load_row<Cfg>(c, j);
+      unsigned mk = 0;
+      long off = 0;
+      if (m < p.m_total) {
+        long q = POOL ? (m >> 2) : m;
+        const int sub = POOL ? (int)(m & 3) : 0;
+        const int n = (int)(q / ((long)Hq * Wq));
+        const int rem = (int)(q - (long)n * Hq * Wq);
+        int y = rem / Wq, x = rem - y * Wq;
+        if (POOL) {
+          y = 2 * y + (sub >> 1);
+          x = 2 * x + (sub & 1);
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+          if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) mk |= 1u << t;
+        }
+        off = (((long)n * p.H + y) * p.W + x) * pix_bytes;
+      }
+      mask[j] = mk;
+      base[j] = reinterpret_cast<const char*>(p.in) + off + piece;
+    }
+    tap = 0;
+    cc = 0;
+    tap_off = (long)(-W - 1) * pix_bytes;
+  }
+  __device__ inline const char* src(int j) const {
+    return ((mask[j] >> tap) & 1u) ? base[j] + tap_off + cc * 128 : zero;
+  }
+  __device__ inline void next() {
+    if (++cc == cchunks) {
+      cc = 0;
+      ++tap;
+      tap_off = (long)((tap / 3 - 1) * W + (tap % 3 - 1)) * pix_bytes;
+    }
+  }
+};
+
+template <typename Cfg>
+struct ConvBLoader {
+  const char* p[Cfg::B_LOADS];
+  long wrap_bytes;
+  int cc, cchunks;
+  __device__ inline void init(const WaveCoord& c, const ConvParams& prm, long n0) {
+    using T = typename Cfg::T;
+    const int piece = load_piece_bytes<Cfg>(c);
+    cchunks = prm.cin / Cfg::BK;
+    cc = 0;
+    wrap_bytes = (long)prm.cin * sizeof(T) * (prm.cout - 1);
+#pragma unroll
+    for (int j = 0; j < Cfg::B_LOADS; ++j) {
+      const long n = n0 + load_row<Cfg>(c, j);
+      p[j] = reinterpret_cast<const char*>(prm.w) + n * prm.cin * (long)sizeof(T) + piece;
+    }
+  }
+  __device__ inline const char* src(int j) const { return p[j]; }
+  __device__ inline void next() {
+    long d = 128;
+    if (++cc == cchunks) {
+      cc = 0;
+      d += wrap_bytes;
+    }
+#pragma unroll
+    for (int j = 0; j < Cfg::B_LOADS; ++j) p[j] += d;
+  }
+};
+
+template <typename Cfg, bool POOL>
+constexpr int conv_lds_bytes() {
+  constexpr int rows = POOL ? Cfg::BM / 4 : Cfg::BM;
+  constexpr int epi = rows * (Cfg::BN * (int)sizeof(typename Cfg::T) + 16);
+  return epi > Cfg::MAIN_LDS_BYTES ? epi : Cfg::MAIN_LDS_BYTES;
+}
+
+template <typename Cfg, bool POOL, bool GLDS>
+__global__ __launch_bounds__(Cfg::NTHREADS) void conv3x3_igemm_kernel(ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using T = typename Cfg::T;
+  constexpr int TM = Cfg::TM, TN = Cfg::TN;
+  const WaveCoord c = wave_coord<Cfg>();
+  const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+  const long m0 = (long)tm * Cfg::BM, n0 = (long)tn * Cfg::BN;
+
+  ConvALoader<Cfg, POOL> la;
+  ConvBLoader<Cfg> lb;
+  la.init(c, p, m0);
+  lb.init(c, p, n0);
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  gemm_nt_mainloop<Cfg, GLDS>(acc, smem, c, la, lb, 9 * (p.cin / Cfg::BK));
+  // (the main loop ends on a workgroup barrier: the staging LDS is free for the epilogue)
+
+  constexpr int PITCH = Cfg::BN * (int)sizeof(T) + 16;
+  constexpr int OUT_ROWS = POOL ? Cfg::BM / 4 : Cfg::BM;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = (c.wn * TN + j) * 32 + (c.lane & 31);
+    const float b = p.bias[n0 + col];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if constexpr (POOL) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float v = fmaxf(fmaxf(acc[i][j][4 * g], acc[i][j][4 * g + 1]),
+                          fmaxf(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3])) + b;
+          if (p.relu) v = fmaxf(v, 0.f);
+          const int row = (c.wm * TM + i) * 8 + 2 * g + (c.lane >> 5);
+          Elem<T>::store(reinterpret_cast<T*>(smem + row * PITCH) + col, v);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][j][r] + b;
+          if (p.relu) v = fmaxf(v, 0.f);
+          const int row = (c.wm * TM + i) * 32 + acc_row(r, c.lane);
+          Elem<T>::store(reinterpret_cast<T*>(smem + row * PITCH) + col, v);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // coalesced copy-out: every output row is BN * sizeof(T) contiguous bytes of the NHWC tensor
+  constexpr int CPR = Cfg::BN * (int)sizeof(T) / 16;  // 16-byte chunks per row
+  const long row0 = POOL ? (m0 >> 2) : m0;
+  char* obase = reinterpret_cast<char*>(p.out) + n0 * (long)sizeof(T);
+  const long orow_bytes = (long)p.cout * sizeof(T);
+  for (int idx = threadIdx.x; idx < OUT_ROWS * CPR; idx += Cfg::NTHREADS) {
+    const int row = idx / CPR, ch = idx - row * CPR;
+    const long grow = row0 + row;
+    if (grow < p.out_rows)
+      *reinterpret_cast<uint4*>(obase + grow * orow_bytes + ch * 16) =
+          *reinterpret_cast<const uint4*>(smem + row * PITCH + ch * 16);
+  }
+}
+
+template <typename Cfg, bool POOL>
+static int launch_conv_cfg(const ConvParams& p, hipStream_t st) {
+  ConvParams q = p;
+  q.tiles_n = p.cout / Cfg::BN;
+  const long tiles_m = (p.m_total + Cfg::BM - 1) / Cfg::BM;
+  const long grid = tiles_m * q.tiles_n;
+  if (grid <= 0 || grid > 0x7fffffffL) {
+    set_error("conv3x3: grid %ld out of range", grid);
+    return OIBL_E_INVALID;
+  }
+  constexpr int lds = conv_lds_bytes<Cfg, POOL>();
+  if (g_regstage)
+    hipLaunchKernelGGL((conv3x3_igemm_kernel<Cfg, POOL, false>), dim3((unsigned)grid),
+                       dim3(Cfg::NTHREADS), lds, st, q);
+  else
+    hipLaunchKernelGGL((conv3x3_igemm_kernel<Cfg, POOL, true>), dim3((unsigned)grid),
+                       dim3(Cfg::NTHREADS), lds, st, q);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
+
+template <typename T>
+static int launch_conv(const ConvParams& p, int pool, hipStream_t st) {
+  using Cfg128 = GemmCfg<T, 2, 2, 2, 2>;  // 128 x 128
+  using Cfg64 = GemmCfg<T, 2, 2, 2, 1>;   // 128 x 64
+  if (p.cout % 128 == 0)
+    return pool ? launch_conv_cfg<Cfg128, true>(p, st) : launch_conv_cfg<Cfg128, false>(p, st);
+  return pool ? launch_conv_cfg<Cfg64, true>(p, st) : launch_conv_cfg<Cfg64, false>(p, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// small layout / pooling helpers
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void global_maxpool_kernel(const T* __restrict__ feat, float* __restrict__ out, int P,
+                                      int C) {
+  __shared__ float red[4][64];
+  const int n = blockIdx.x, cg = blockIdx.y;
+  const int ch = cg * 64 + (threadIdx.x & 63), pg = threadIdx.x >> 6;
+  float m = -INFINITY;
+  if (ch < C)
+    for (int p = pg; p < P; p += 4) m = fmaxf(m, Elem<T>::load(feat + ((size_t)n * P + p) * C + ch));
+  red[pg][threadIdx.x & 63] = m;
+  __syncthreads();
+  if (pg == 0 && ch < C)
+    out[(size_t)n * C + ch] = fmaxf(fmaxf(red[0][threadIdx.x], red[1][threadIdx.x]),
+                                    fmaxf(red[2][threadIdx.x], red[3][threadIdx.x]));
+}
+
+// [N][P][C] T -> [N][C][P] fp32 through a 32x33 LDS tile
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict__ out, int P,
+                                    int C) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty 0..7
+  for (int r = ty; r < 32; r += 8) {
+    const int p = p0 + r, ch = c0 + tx;
+    tile[r][tx] = (p < P && ch < C) ? Elem<T>::load(in + ((size_t)n * P + p) * C + ch) : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int ch = c0 + r, p = p0 + tx;
+    if (p < P && ch < C) out[((size_t)n * C + ch) * P + p] = tile[tx][r];
+  }
+}
+
+// [N][C][P] fp32 -> [N][P][C] T
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict__ out, int C,
+                                    int P) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int ch = c0 + r, p = p0 + tx;
+    tile[r][tx] = (p < P && ch < C) ? in[((size_t)n * C + ch) * P + p] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int p = p0 + r, ch = c0 + tx;
+    if (p < P && ch < C) Elem<T>::store(out + ((size_t)n * P + p) * C + ch, tile[tx][r]);
+  }
+}
+
+struct VggLayer {
+  int cin, cout, relu, pool;
+};
+static const VggLayer kVgg[OIBL_VGG16_NUM_CONV] = {
+    {3, 64, 1, 0},    {64, 64, 1, 1},   {64, 128, 1, 0},  {128, 128, 1, 1}, {128, 256, 1, 0},
+    {256, 256, 1, 0}, {256, 256, 1, 1}, {256, 512, 1, 0}, {512, 512, 1, 0}, {512, 512, 1, 1},
+    {512, 512, 1, 0}, {512, 512, 1, 0}, {512, 512, 0, 0}};
+
+static int conv3x3_impl(const void* in, int N, int H, int W, int cin, const void* packed_w,
+                        const float* bias, int cout, int relu, int pool, int precision, void* out,
+                        hipStream_t st) {
+  OIBL_REQUIRE(in && packed_w && bias && out, "conv3x3: null pointer");
+  OIBL_REQUIRE(precision == OIBL_BF16 || precision == OIBL_F32, "conv3x3: bad precision %d",
+               precision);
+  const int bk = precision == OIBL_BF16 ? 64 : 32;
+  OIBL_REQUIRE(N > 0 && H > 0 && W > 0, "conv3x3: bad shape N=%d H=%d W=%d", N, H, W);
+  OIBL_REQUIRE(cin % bk == 0 && cout % 64 == 0, "conv3x3: unsupported channels cin=%d cout=%d", cin,
+               cout);
+  OIBL_REQUIRE(!pool || (H >= 2 && W >= 2), "conv3x3: pooling needs H,W >= 2");
+  OIBL_REQUIRE((uintptr_t)in % 16 == 0 && (uintptr_t)packed_w % 16 == 0 && (uintptr_t)out % 16 == 0,
+               "conv3x3: pointers must be 16-byte aligned");
+  ConvParams p;
+  p.in = in;
+  p.w = packed_w;
+  p.bias = bias;
+  p.out = out;
+  p.zero = zero_line_device_ptr();
+  OIBL_REQUIRE(p.zero != nullptr, "conv3x3: zero line symbol not found");
+  p.N = N;
+  p.H = H;
+  p.W = W;
+  p.cin = cin;
+  p.cout = cout;
+  p.relu = relu;
+  p.tiles_n = 0;
+  if (pool) {
+    p.out_rows = (long)N * (H / 2) * (W / 2);
+    p.m_total = p.out_rows * 4;
+  } else {
+    p.out_rows = (long)N * H * W;
+    p.m_total = p.out_rows;
+  }
+  return precision == OIBL_BF16 ? launch_conv<bf16_t>(p, pool, st) : launch_conv<float>(p, pool, st);
+}
+
+}  // namespace oibl
+
+using namespace oibl;
+
+extern "C" {
+
+size_t oibl_conv3x3_packed_bytes(int cout, int cin, int precision) {
+  return (size_t)9 * cout * cin * oibl_elem_size(precision);
+}
+
+int oibl_pack_conv3x3_weights(const float* w_oihw, int cout, int cin, int precision, void* packed,
+                              void* stream) {
+  OIBL_REQUIRE(w_oihw && packed, "pack_conv3x3_weights: null pointer");
+  OIBL_REQUIRE(cout > 0 && cin > 0, "pack_conv3x3_weights: bad shape");
+  OIBL_REQUIRE(precision == OIBL_BF16 || precision == OIBL_F32,
+               "pack_conv3x3_weights: bad precision %d", precision);
+  const size_t total = (size_t)9 * cout * cin;
+  unsigned blocks = (unsigned)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  if (precision == OIBL_BF16)
+    hipLaunchKernelGGL(pack_conv3x3_kernel<bf16_t>, dim3(blocks), dim3(256), 0,
+                       (hipStream_t)stream, w_oihw, (bf16_t*)packed, cout, cin);
+  else
+    hipLaunchKernelGGL(pack_conv3x3_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       w_oihw, (float*)packed, cout, cin);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
+
+int oibl_conv3x3_nhwc(const void* in, int N, int H, int W, int cin, const void* packed_w,
+                      const float* bias, int cout, int relu, int pool, int precision, void* out,
+                      void* stream) {
+  return conv3x3_impl(in, N, H, W, cin, packed_w, bias, cout, relu, pool, precision, out,
+                      (hipStream_t)stream);
+}
+
+int oibl_conv1_1_nchw(const float* x_nchw, int N, int H, int W, const float* w_oihw,
+                      const float* bias, int precision, void* out, void* stream) {
+  OIBL_REQUIRE(x_nchw && w_oihw && bias && out, "conv1_1: null pointer");
+  OIBL_REQUIRE(N > 0 && H > 0 && W > 0, "conv1_1: bad shape N=%d H=%d W=%d", N, H, W);
+  OIBL_REQUIRE(precision == OIBL_BF16 || precision == OIBL_F32, "conv1_1: bad precision %d",
+               precision);
+  const long nstrips = (long)N * H * ((W + 7) / 8);
+  const long grid = (nstrips + 3) / 4;
+  OIBL_REQUIRE(grid <= 0x7fffffffL, "conv1_1: grid too large");
+  if (precision == OIBL_BF16)
+    hipLaunchKernelGGL(conv1_1_kernel<bf16_t>, dim3((unsigned)grid), dim3(256), 0,
+                       (hipStream_t)stream, x_nchw, w_oihw, bias, (bf16_t*)out, N, H, W);
+  else
+    hipLaunchKernelGGL(conv1_1_kernel<float>, dim3((unsigned)grid), dim3(256), 0,
+                       (hipStream_t)stream, x_nchw, w_oihw, bias, (float*)out, N, H, W);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
+
+int oibl_global_maxpool_nhwc(const void* feat, int N, int P, int C, int precision, float* out,
+                             void* stream) {
+  OIBL_REQUIRE(feat && out, "global_maxpool: null pointer");
+  OIBL_REQUIRE(N > 0 && P > 0 && C > 0, "global_maxpool: bad shape");
+  dim3 grid(N, (C + 63) / 64);
+  if (precision == OIBL_BF16)
+    hipLaunchKernelGGL(global_maxpool_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)feat, out, P, C);
+  else if (precision == OIBL_F32)
+    hipLaunchKernelGGL(global_maxpool_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream,
+                       (const float*)feat, out, P, C);
+  else
+    OIBL_REQUIRE(false, "global_maxpool: bad precision %d", precision);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
+
+int oibl_nhwc_to_nchw_f32(const void* feat, int N, int P, int C, int precision, float* out,
+                          void* stream) {
+  OIBL_REQUIRE(feat && out, "nhwc_to_nchw: null pointer");
+  OIBL_REQUIRE(N > 0 && P > 0 && C > 0 && N < 65536, "nhwc_to_nchw: bad shape");
+  dim3 grid((P + 31) / 32, (C + 31) / 32, N);
+  if (precision == OIBL_BF16)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)feat, out, P, C);
+  else if (precision == OIBL_F32)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream,
+                       (const float*)feat, out, P, C);
+  else
+    OIBL_REQUIRE(false, "nhwc_to_nchw: bad precision %d", precision);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
+
+int oibl_nchw_f32_to_nhwc(const float* x, int N, int C, int P, int precision, void* out,
+                          void* stream) {
+  OIBL_REQUIRE(x && out, "nchw_to_nhwc: null pointer");
+  OIBL_REQUIRE(N > 0 && P > 0 && C > 0 && N < 65536, "nchw_to_nhwc: bad shape");
+  dim3 grid((P + 31) / 32, (C + 31) / 32, N);
+  if (precision == OIBL_BF16)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, x,
+                       (bf16_t*)out, C, P);
+  else if (precision == OIBL_F32)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x,
+                       (float*)out, C, P);
+  else
+    OIBL_REQUIRE(false, "nchw_to_nhwc: bad precision %d", precision);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
+
+// ping-pong activation buffers: A holds outputs of even layers, B of odd layers
+static void vgg_buffer_elems(int N, int H, int W, size_t* a, size_t* b) {
+  size_t ea = 0, eb = 0;
+  int h = H, w = W;
+  for (int l = 0; l < OIBL_VGG16_NUM_CONV - 1; ++l) {  // the last layer writes `feat`
+    if (kVgg[l].pool) {
+      h /= 2;
+      w /= 2;
+    }
+    const size_t e = (size_t)N * h * w * kVgg[l].cout;
+    if (l % 2 == 0)
+      ea = e > ea ? e : ea;
+    else
+      eb = e > eb ? e : eb;
+  }
+  *a = ea;
+  *b = eb;
+}
+
+size_t oibl_vgg16_workspace_bytes(int N, int H, int W, int precision) {
+  if (N <= 0 || H < 16 || W < 16) return 0;
+  size_t ea, eb;
+  vgg_buffer_elems(N, H, W, &ea, &eb);
+  const size_t es = oibl_elem_size(precision);
+  return align_up(ea * es, 256) + align_up(eb * es, 256);
+}
+
+int oibl_vgg16_conv5_forward(const float* x_nchw, int N, int H, int W,
+                             const void* const* packed_w_host, const float* const* bias_host,
+                             int precision, void* feat, void* ws, size_t ws_bytes, void* stream) {
+  OIBL_REQUIRE(x_nchw && packed_w_host && bias_host && feat && ws, "vgg16: null pointer");
+  OIBL_REQUIRE(precision == OIBL_BF16 || precision == OIBL_F32, "vgg16: bad precision %d",
+               precision);
+  OIBL_REQUIRE(N > 0 && H >= 16 && W >= 16, "vgg16: bad shape N=%d H=%d W=%d", N, H, W);
+  OIBL_REQUIRE((uintptr_t)ws % 256 == 0, "vgg16: workspace must be 256-byte aligned");
+  const size_t need = oibl_vgg16_workspace_bytes(N, H, W, precision);
+  if (ws_bytes < need) {
+    set_error("vgg16: workspace %zu < required %zu bytes", ws_bytes, need);
+    return OIBL_E_WORKSPACE;
+  }
+  size_t ea, eb;
+  vgg_buffer_elems(N, H, W, &ea, &eb);
+  const size_t es = oibl_elem_size(precision);
+  char* bufA = (char*)ws;
+  char* bufB = bufA + align_up(ea * es, 256);
+
+  int rc = oibl_conv1_1_nchw(x_nchw, N, H, W, (const float*)packed_w_host[0], bias_host[0],
+                             precision, bufA, stream);
+  if (rc) return rc;
+  int h = H, w = W;
+  const void* cur = bufA;
+  for (int l = 1; l < OIBL_VGG16_NUM_CONV; ++l) {
+    void* dst = (l == OIBL_VGG16_NUM_CONV - 1) ? feat : (l % 2 == 0 ? (void*)bufA : (void*)bufB);
+    rc = conv3x3_impl(cur, N, h, w, kVgg[l].cin, packed_w_host[l], bias_host[l], kVgg[l].cout,
+                      kVgg[l].relu, kVgg[l].pool, precision, dst, (hipStream_t)stream);
+    if (rc) return rc;
+    if (kVgg[l].pool) {
+      h /= 2;
+      w /= 2;
+    }
+    cur = dst;
+  }
+  return OIBL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,108 @@
+"""ctypes binding of the C-ABI library (include/openibl_amd.h).
+
+There is no CPU fallback: if the library cannot be loaded the import of the product path fails
+with an explicit error, and every call that returns a non-zero status raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+from . import build as _build
+
+_LIB = None
+
+c_void_p, c_int, c_size_t, c_char_p = C.c_void_p, C.c_int, C.c_size_t, C.c_char_p
+
+# name -> (restype, argtypes); mirrors include/openibl_amd.h one to one.
+SIGNATURES = {
+    "oibl_abi_version": (c_int, []),
+    "oibl_last_error": (c_char_p, []),
+    "oibl_target_arch": (c_char_p, []),
+    "oibl_elem_size": (c_size_t, [c_int]),
+    "oibl_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "oibl_cast_bf16_to_f32": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "oibl_conv3x3_packed_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "oibl_pack_conv3x3_weights": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "oibl_conv3x3_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                  c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "oibl_conv1_1_nchw": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
+                                  c_void_p, c_void_p]),
+    "oibl_global_maxpool_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "oibl_nhwc_to_nchw_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "oibl_nchw_f32_to_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "oibl_vgg16_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "oibl_vgg16_conv5_forward": (c_int, [c_void_p, c_int, c_int, c_int, C.POINTER(c_void_p),
+                                         C.POINTER(c_void_p), c_int, c_void_p, c_void_p,
+                                         c_size_t, c_void_p]),
+    "oibl_netvlad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "oibl_netvlad_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                     c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
+                                     c_void_p]),
+    "oibl_pca_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "oibl_pca_forward": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                 c_void_p, c_void_p, c_size_t, c_void_p]),
+    "oibl_l2_normalize_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "oibl_pairwise_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "oibl_pairwise_sqdist": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
+                                     c_size_t, c_void_p, c_size_t, c_void_p]),
+    "oibl_row_topk": (c_int, [c_void_p, c_void_p, c_int, c_int, c_size_t, c_int, c_int, c_void_p,
+                              c_void_p, c_void_p]),
+    "oibl_gemm_nt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t,
+                             c_void_p]),
+}
+# test hooks exported by the library but deliberately absent from the public header
+_HOOKS = {"oibl_debug_set_regstage": (c_int, [c_int])}
+
+ABI_VERSION = 1
+
+
+class OpenIBLAmdError(RuntimeError):
+    pass
+
+
+def lib_path() -> Path:
+    return _build.LIB_PATH
+
+
+def load():
+    """Load (building first if the in-tree .so is missing or stale and hipcc is available)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if os.environ.get("OPENIBL_AMD_NO_BUILD", "0") != "1":
+        try:
+            if not _build.is_current():
+                _build.build(verbose=False)
+        except Exception as e:  # stale-but-present library is still usable
+            if not path.exists():
+                raise OpenIBLAmdError(
+                    f"openibl_amd: the HIP extension is not built and cannot be built here: {e}")
+    if not path.exists():
+        raise OpenIBLAmdError(
+            f"openibl_amd: {path} is missing; run `python -m openibl_amd.build` (needs hipcc). "
+            "There is no CPU fallback for this path.")
+    try:
+        lib = C.CDLL(str(path))
+    except OSError as e:
+        raise OpenIBLAmdError(f"openibl_amd: cannot load {path}: {e}")
+    for name, (res, args) in {**SIGNATURES, **_HOOKS}.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise OpenIBLAmdError(f"openibl_amd: {path} does not export {name}")
+        fn.restype = res
+        fn.argtypes = args
+    if lib.oibl_abi_version() != ABI_VERSION:
+        raise OpenIBLAmdError(
+            f"openibl_amd: ABI version {lib.oibl_abi_version()} != expected {ABI_VERSION}")
+    _LIB = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().oibl_last_error().decode(errors="replace")
+        raise OpenIBLAmdError(f"openibl_amd {what} failed (status {rc}): {msg}")

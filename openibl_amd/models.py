@@ -1,0 +1,277 @@
+"""nn.Module mirror of the reference's model zoo (ibl/models/{vgg,netvlad,__init__}.py).
+
+Same class names, constructor arguments, return conventions and — because `base` is a real
+nn.Sequential of the same 29 modules and NetVLAD / pca_layer hold the same parameters —
+bit-for-bit the same `state_dict()` keys and shapes, so the released `vgg16_netvlad.pth` and
+DDP-saved (`module.`-prefixed) checkpoints load unchanged.  The modules only *own* the parameters;
+`forward` never calls them.  It hands raw device pointers to the HIP kernels via openibl_amd.ops:
+
+    VGG.forward          -> oibl_vgg16_conv5_forward      (vgg.py:61-70)
+    NetVLAD.forward      -> oibl_netvlad_forward           (netvlad.py:44-61)
+    EmbedNet.forward     -> backbone + NetVLAD + norms      (netvlad.py:73-82)
+    EmbedNetPCA.forward  -> ... + oibl_pca_forward           (netvlad.py:95-110)
+
+Inference only (the reference's training paths are out of scope).  Inputs must be
+CUDA(HIP) tensors; there is no CPU path.
+"""
+from __future__ import annotations
+
+import os
+import warnings
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import ops
+
+__all__ = ["VGG", "vgg16", "NetVLAD", "EmbedNet", "EmbedNetPCA", "EmbedRegionNet", "names",
+           "create", "default_precision"]
+
+_CFG_D = (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M")
+
+
+def default_precision() -> str:
+    """'fp32' (exact fp32 MFMA, reference-grade numerics) unless OPENIBL_AMD_PRECISION=bf16."""
+    return os.environ.get("OPENIBL_AMD_PRECISION", "fp32").lower()
+
+
+class _PrecisionMixin:
+    """`module.set_precision('bf16' | 'fp32')` switches the arithmetic of the contractions."""
+
+    def set_precision(self, precision: str):
+        ops.precision_code(precision)
+        for m in self.modules():
+            if isinstance(m, _PrecisionMixin):
+                m._precision = precision.lower()
+                m._cache = {}
+        return self
+
+    @property
+    def precision(self) -> str:
+        return getattr(self, "_precision", None) or default_precision()
+
+
+def _fingerprint(params: List[torch.Tensor]) -> Tuple:
+    return tuple((p.data_ptr(), p._version, str(p.device)) for p in params)
+
+
+class VGG(_PrecisionMixin, nn.Module):
+    """VGG16 cfg-D up to conv5_3 without the last ReLU / pool (ibl/models/vgg.py:15-70)."""
+
+    _fix_layers = {"conv5": 24, "conv4": 17, "conv3": 10, "conv2": 5, "full": 0}
+
+    def __init__(self, depth, pretrained=True, cut_at_pooling=False, train_layers="conv5",
+                 matconvnet=None):
+        super().__init__()
+        if depth != 16:
+            raise KeyError("Unsupported depth:", depth)
+        self.pretrained = pretrained
+        self.depth = depth
+        self.cut_at_pooling = cut_at_pooling
+        self.train_layers = train_layers
+        self.feature_dim = 512
+        self.matconvnet = matconvnet
+        layers, cin = [], 3
+        for v in _CFG_D:
+            if v == "M":
+                layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+            else:
+                layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+                cin = v
+        self.base = nn.Sequential(*layers[:-2])   # drop the last ReLU and max-pool (vgg.py:41-42)
+        self.gap = nn.AdaptiveMaxPool2d(1)
+        self._cache: Dict = {}
+        self._init_params()
+        if not pretrained:
+            self.reset_params()
+        else:
+            if matconvnet is None:
+                warnings.warn("openibl_amd: ImageNet weights for vgg16 cannot be downloaded here; "
+                              "the backbone is randomly initialised until a checkpoint is loaded")
+                self.reset_params()
+            for l in list(self.base.children())[: VGG._fix_layers[train_layers]]:
+                for p in l.parameters():
+                    p.requires_grad = False
+
+    def _init_params(self):
+        if self.matconvnet is not None:
+            self.base.load_state_dict(torch.load(self.matconvnet))
+            self.pretrained = True
+
+    def reset_params(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out")
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    # ---- HIP path ---------------------------------------------------------------------------
+    def _convs(self) -> List[nn.Conv2d]:
+        return [m for m in self.base if isinstance(m, nn.Conv2d)]
+
+    def _packed(self, device: torch.device):
+        convs = self._convs()
+        params = [c.weight for c in convs] + [c.bias for c in convs]
+        if params[0].device != device:
+            raise RuntimeError(f"VGG: parameters are on {params[0].device}, input on {device}")
+        key = (self.precision, _fingerprint(params))
+        hit = self._cache.get("packed")
+        if hit is None or hit[0] != key:
+            ws = [convs[0].weight.detach().float().contiguous()]
+            ws += [ops.pack_conv3x3(c.weight.detach().float().contiguous(), self.precision)
+                   for c in convs[1:]]
+            bs = [c.bias.detach().float().contiguous() for c in convs]
+            self._cache["packed"] = (key, ws, bs)
+            hit = self._cache["packed"]
+        return hit[1], hit[2]
+
+    def features_nhwc(self, x: torch.Tensor) -> torch.Tensor:
+        """[N][3][H][W] fp32 -> conv5_3 map [N][h][w][512] in the precision's element type."""
+        if x.dtype != torch.float32:
+            x = x.float()
+        x = x.contiguous()
+        ws, bs = self._packed(x.device)
+        return ops.vgg16_conv5(x, ws, bs, self.precision)
+
+    @torch.no_grad()
+    def forward(self, x):
+        feat = self.features_nhwc(x)
+        x_nchw = ops.nhwc_to_nchw_f32(feat)
+        if self.cut_at_pooling:
+            return x_nchw
+        return ops.global_maxpool_nhwc(feat), x_nchw
+
+
+def vgg16(**kwargs):
+    return VGG(16, **kwargs)
+
+
+class NetVLAD(_PrecisionMixin, nn.Module):
+    """NetVLAD layer (ibl/models/netvlad.py:8-61); forward returns the UN-normalised [N][K][C]."""
+
+    def __init__(self, num_clusters=64, dim=512, alpha=100.0, normalize_input=True):
+        super().__init__()
+        self.num_clusters = num_clusters
+        self.dim = dim
+        self.alpha = alpha
+        self.normalize_input = normalize_input
+        self.conv = nn.Conv2d(dim, num_clusters, kernel_size=(1, 1), bias=False)
+        self.centroids = nn.Parameter(torch.rand(num_clusters, dim), requires_grad=True)
+        self.clsts = None
+        self.traindescs = None
+        self._cache: Dict = {}
+
+    def _init_params(self):
+        raise NotImplementedError("NetVLAD._init_params (k-means initialisation for training) is "
+                                  "outside the inference path this package implements")
+
+    def _params(self):
+        w = self.conv.weight.detach().float().reshape(self.num_clusters, self.dim).contiguous()
+        return w, self.centroids.detach().float().contiguous()
+
+    def aggregate_nhwc(self, feat: torch.Tensor, want_raw: bool, want_norm: bool):
+        w, c = self._params()
+        return ops.netvlad(feat, w, c, self.normalize_input, want_raw=want_raw, want_norm=want_norm)
+
+    @torch.no_grad()
+    def forward(self, x):
+        """x: the backbone's [N][C][h][w] fp32 map (reference layout)."""
+        feat = ops.nchw_f32_to_nhwc(x.float().contiguous(), self.precision)
+        raw, _ = self.aggregate_nhwc(feat, want_raw=True, want_norm=False)
+        return raw
+
+
+class EmbedNet(_PrecisionMixin, nn.Module):
+    """ibl/models/netvlad.py:63-82: returns (pool_x [N][512], vlad [N][K*C] intra+L2 normalised)."""
+
+    def __init__(self, base_model, net_vlad):
+        super().__init__()
+        self.base_model = base_model
+        self.net_vlad = net_vlad
+
+    def _init_params(self):
+        self.base_model._init_params()
+        self.net_vlad._init_params()
+
+    @torch.no_grad()
+    def forward(self, x):
+        feat = self.base_model.features_nhwc(x)
+        _, vlad = self.net_vlad.aggregate_nhwc(feat, want_raw=False, want_norm=True)
+        return ops.global_maxpool_nhwc(feat), vlad
+
+
+class EmbedNetPCA(_PrecisionMixin, nn.Module):
+    """ibl/models/netvlad.py:84-110: image batch -> [N][dim] unit-norm descriptors."""
+
+    def __init__(self, base_model, net_vlad, dim=4096):
+        super().__init__()
+        self.base_model = base_model
+        self.net_vlad = net_vlad
+        self.pca_layer = nn.Conv2d(net_vlad.num_clusters * net_vlad.dim, dim, 1, stride=1, padding=0)
+        self._cache: Dict = {}
+
+    def _init_params(self):
+        self.base_model._init_params()
+        self.net_vlad._init_params()
+
+    def _pca_params(self):
+        w, b = self.pca_layer.weight, self.pca_layer.bias
+        key = (self.precision, _fingerprint([w, b]))
+        hit = self._cache.get("pca")
+        if hit is None or hit[0] != key:
+            w2 = w.detach().float().reshape(w.shape[0], -1).contiguous()
+            self._cache["pca"] = (key, ops.cast(w2, self.precision), b.detach().float().contiguous())
+            hit = self._cache["pca"]
+        return hit[1], hit[2]
+
+    @torch.no_grad()
+    def forward(self, x):
+        feat = self.base_model.features_nhwc(x)
+        _, vlad = self.net_vlad.aggregate_nhwc(feat, want_raw=False, want_norm=True)
+        w, b = self._pca_params()
+        return ops.pca(vlad, w, b, l2norm=True)
+
+
+class EmbedRegionNet(_PrecisionMixin, nn.Module):
+    """ibl/models/netvlad.py:112-207.  Only the evaluation branch (:199-205, identical to
+    EmbedNet.forward) is implemented; the SFRS region-similarity training branch is out of scope."""
+
+    def __init__(self, base_model, net_vlad, tuple_size=1):
+        super().__init__()
+        self.base_model = base_model
+        self.net_vlad = net_vlad
+        self.tuple_size = tuple_size
+
+    def _init_params(self):
+        self.base_model._init_params()
+        self.net_vlad._init_params()
+
+    @torch.no_grad()
+    def forward(self, x):
+        if self.training:
+            raise NotImplementedError("EmbedRegionNet: the SFRS training branch is not part of the "
+                                      "MI355X inference path; call .eval() first")
+        feat = self.base_model.features_nhwc(x)
+        _, vlad = self.net_vlad.aggregate_nhwc(feat, want_raw=False, want_norm=True)
+        return ops.global_maxpool_nhwc(feat), vlad
+
+
+_factory = {
+    "vgg16": vgg16,
+    "netvlad": NetVLAD,
+    "embednet": EmbedNet,
+    "embednetpca": EmbedNetPCA,
+    "embedregionnet": EmbedRegionNet,
+}
+
+
+def names():
+    return sorted(_factory.keys())
+
+
+def create(name, *args, **kwargs):
+    """Same factory contract as ibl/models/__init__.py:20-53."""
+    if name not in _factory:
+        raise KeyError("Unknown model:", name)
+    return _factory[name](*args, **kwargs)

@@ -1,0 +1,345 @@
+"""Torch-facing wrappers over the C ABI: tensors in, tensors out, device pointers across.
+
+PyTorch is used only for device memory, streams and dtype bookkeeping; every computation below is
+a call into libopenibl_amd.so.  All tensors must live on a CUDA(HIP) device and be contiguous.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import lib as _lib
+
+BF16 = 0
+F32 = 1
+_DTYPES = {BF16: torch.bfloat16, F32: torch.float32}
+_NAMES = {"bf16": BF16, "bfloat16": BF16, "fp32": F32, "f32": F32, "float32": F32}
+
+
+def precision_code(p) -> int:
+    if isinstance(p, str):
+        try:
+            return _NAMES[p.lower()]
+        except KeyError:
+            raise ValueError(f"unknown precision {p!r} (use 'bf16' or 'fp32')")
+    if p in (BF16, F32):
+        return int(p)
+    raise ValueError(f"unknown precision {p!r}")
+
+
+def elem_dtype(p) -> torch.dtype:
+    return _DTYPES[precision_code(p)]
+
+
+def _need_cuda(*tensors: torch.Tensor) -> torch.device:
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.OpenIBLAmdError(
+                "openibl_amd: tensor is on %s; this path runs only on an AMD GPU through the HIP "
+                "extension (there is no CPU fallback)" % t.device)
+        if not t.is_contiguous():
+            raise ValueError("openibl_amd: tensors must be contiguous")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise ValueError("openibl_amd: tensors on different devices")
+    return dev
+
+
+def _stream(dev: torch.device) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+_WS = {}
+
+
+def workspace(nbytes: int, dev: torch.device, slot: str = "default") -> torch.Tensor:
+    """Grow-only per-(device, stream, slot) scratch buffer (torch allocations are 512-B aligned)."""
+    key = (dev.index, _stream(dev), slot)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+        _WS[key] = buf
+    return buf
+
+
+def release_workspaces() -> None:
+    _WS.clear()
+
+
+# ---------------------------------------------------------------------------------------------
+def cast(x: torch.Tensor, precision) -> torch.Tensor:
+    """fp32 tensor -> tensor of the precision's element type (bf16 round-to-nearest-even)."""
+    p = precision_code(precision)
+    dev = _need_cuda(x)
+    if x.dtype != torch.float32:
+        raise ValueError("cast expects float32 input")
+    if p == F32:
+        return x
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=dev)
+    _lib.check(_lib.load().oibl_cast_f32_to_bf16(_ptr(x), _ptr(out), x.numel(), _stream(dev)),
+               "cast_f32_to_bf16")
+    return out
+
+
+def to_f32(x: torch.Tensor) -> torch.Tensor:
+    dev = _need_cuda(x)
+    if x.dtype == torch.float32:
+        return x
+    if x.dtype != torch.bfloat16:
+        raise ValueError("to_f32 expects bf16 or fp32")
+    out = torch.empty(x.shape, dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().oibl_cast_bf16_to_f32(_ptr(x), _ptr(out), x.numel(), _stream(dev)),
+               "cast_bf16_to_f32")
+    return out
+
+
+def set_regstage(on: bool) -> None:
+    """Test hook: run the GEMM main loops register-staged instead of through global_load_lds."""
+    _lib.load().oibl_debug_set_regstage(1 if on else 0)
+
+
+# ---- backbone -------------------------------------------------------------------------------
+VGG16_CONV_IDX = (0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28)  # vgg.py:40-42 conv positions
+VGG16_CFG = ((3, 64, 1, 0), (64, 64, 1, 1), (64, 128, 1, 0), (128, 128, 1, 1), (128, 256, 1, 0),
+             (256, 256, 1, 0), (256, 256, 1, 1), (256, 512, 1, 0), (512, 512, 1, 0),
+             (512, 512, 1, 1), (512, 512, 1, 0), (512, 512, 1, 0), (512, 512, 0, 0))
+
+
+def pack_conv3x3(w: torch.Tensor, precision) -> torch.Tensor:
+    """[Cout][Cin][3][3] fp32 -> packed [9][Cout][Cin] in the precision's element type."""
+    p = precision_code(precision)
+    dev = _need_cuda(w)
+    if w.dtype != torch.float32 or w.dim() != 4 or w.shape[2:] != (3, 3):
+        raise ValueError("pack_conv3x3 expects a float32 [Cout][Cin][3][3] tensor")
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    out = torch.empty((9, cout, cin), dtype=_DTYPES[p], device=dev)
+    _lib.check(_lib.load().oibl_pack_conv3x3_weights(_ptr(w), cout, cin, p, _ptr(out),
+                                                     _stream(dev)), "pack_conv3x3_weights")
+    return out
+
+
+def conv3x3_nhwc(x: torch.Tensor, packed_w: torch.Tensor, bias: torch.Tensor, relu: bool,
+                 pool: bool, precision) -> torch.Tensor:
+    """x [N][H][W][Cin] T -> [N][Ho][Wo][Cout] T (conv3x3 pad 1 + bias (+ReLU) (+2x2 max-pool))."""
+    p = precision_code(precision)
+    dev = _need_cuda(x, packed_w, bias)
+    if x.dtype != _DTYPES[p] or packed_w.dtype != _DTYPES[p] or bias.dtype != torch.float32:
+        raise ValueError("conv3x3_nhwc: dtype mismatch with precision")
+    N, H, W, cin = map(int, x.shape)
+    cout = int(packed_w.shape[1])
+    if int(packed_w.shape[2]) != cin:
+        raise ValueError("conv3x3_nhwc: packed weight Cin mismatch")
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    out = torch.empty((N, Ho, Wo, cout), dtype=_DTYPES[p], device=dev)
+    _lib.check(_lib.load().oibl_conv3x3_nhwc(_ptr(x), N, H, W, cin, _ptr(packed_w), _ptr(bias),
+                                             cout, int(relu), int(pool), p, _ptr(out),
+                                             _stream(dev)), "conv3x3_nhwc")
+    return out
+
+
+def conv1_1_nchw(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, precision) -> torch.Tensor:
+    """x [N][3][H][W] fp32 -> [N][H][W][64] T (conv1_1 + bias + ReLU)."""
+    p = precision_code(precision)
+    dev = _need_cuda(x, w, bias)
+    if x.dtype != torch.float32 or w.dtype != torch.float32 or tuple(w.shape) != (64, 3, 3, 3):
+        raise ValueError("conv1_1_nchw: expects fp32 x and a [64][3][3][3] fp32 weight")
+    N, _, H, W = map(int, x.shape)
+    out = torch.empty((N, H, W, 64), dtype=_DTYPES[p], device=dev)
+    _lib.check(_lib.load().oibl_conv1_1_nchw(_ptr(x), N, H, W, _ptr(w), _ptr(bias), p, _ptr(out),
+                                             _stream(dev)), "conv1_1_nchw")
+    return out
+
+
+def vgg16_feature_hw(H: int, W: int) -> Tuple[int, int]:
+    for _ in range(4):
+        H, W = H // 2, W // 2
+    return H, W
+
+
+def vgg16_conv5(x: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor],
+                precision) -> torch.Tensor:
+    """x [N][3][H][W] fp32 -> conv5_3 feature map [N][h][w][512] T (NHWC), h = H//16, w = W//16.
+
+    weights[0] is the plain conv1_1 tensor, weights[1:] come from pack_conv3x3."""
+    p = precision_code(precision)
+    dev = _need_cuda(x, *weights, *biases)
+    if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3:
+        raise ValueError("vgg16_conv5 expects a float32 [N][3][H][W] tensor")
+    if len(weights) != 13 or len(biases) != 13:
+        raise ValueError("vgg16_conv5 needs 13 weights and 13 biases")
+    N, _, H, W = map(int, x.shape)
+    h, w = vgg16_feature_hw(H, W)
+    lib = _lib.load()
+    ws_bytes = lib.oibl_vgg16_workspace_bytes(N, H, W, p)
+    if ws_bytes == 0:
+        raise ValueError(f"vgg16_conv5: unsupported input shape {tuple(x.shape)}")
+    ws = workspace(ws_bytes, dev, "vgg")
+    feat = torch.empty((N, h, w, 512), dtype=_DTYPES[p], device=dev)
+    wp = (C.c_void_p * 13)(*[t.data_ptr() for t in weights])
+    bp = (C.c_void_p * 13)(*[t.data_ptr() for t in biases])
+    _lib.check(lib.oibl_vgg16_conv5_forward(_ptr(x), N, H, W, wp, bp, p, _ptr(feat), _ptr(ws),
+                                            ws.numel(), _stream(dev)), "vgg16_conv5_forward")
+    return feat
+
+
+def global_maxpool_nhwc(feat: torch.Tensor) -> torch.Tensor:
+    """[N][h][w][C] T -> [N][C] fp32 (AdaptiveMaxPool2d(1))."""
+    dev = _need_cuda(feat)
+    p = BF16 if feat.dtype == torch.bfloat16 else F32
+    N, C_ = int(feat.shape[0]), int(feat.shape[-1])
+    P = feat.numel() // (N * C_)
+    out = torch.empty((N, C_), dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().oibl_global_maxpool_nhwc(_ptr(feat), N, P, C_, p, _ptr(out),
+                                                    _stream(dev)), "global_maxpool_nhwc")
+    return out
+
+
+def nhwc_to_nchw_f32(feat: torch.Tensor) -> torch.Tensor:
+    """[N][h][w][C] T -> [N][C][h][w] fp32."""
+    dev = _need_cuda(feat)
+    p = BF16 if feat.dtype == torch.bfloat16 else F32
+    N, h, w, C_ = map(int, feat.shape)
+    out = torch.empty((N, C_, h, w), dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().oibl_nhwc_to_nchw_f32(_ptr(feat), N, h * w, C_, p, _ptr(out),
+                                                 _stream(dev)), "nhwc_to_nchw_f32")
+    return out
+
+
+def nchw_f32_to_nhwc(x: torch.Tensor, precision) -> torch.Tensor:
+    """[N][C][h][w] fp32 -> [N][h][w][C] T."""
+    p = precision_code(precision)
+    dev = _need_cuda(x)
+    if x.dtype != torch.float32 or x.dim() != 4:
+        raise ValueError("nchw_f32_to_nhwc expects a float32 [N][C][h][w] tensor")
+    N, C_, h, w = map(int, x.shape)
+    out = torch.empty((N, h, w, C_), dtype=_DTYPES[p], device=dev)
+    _lib.check(_lib.load().oibl_nchw_f32_to_nhwc(_ptr(x), N, C_, h * w, p, _ptr(out),
+                                                 _stream(dev)), "nchw_f32_to_nhwc")
+    return out
+
+
+# ---- NetVLAD ----------------------------------------------------------------------------------
+def netvlad(feat: torch.Tensor, assign_w: torch.Tensor, centroids: torch.Tensor,
+            normalize_input: bool = True, want_raw: bool = False, want_norm: bool = True):
+    """feat [N][h][w][C] (or [N][P][C]) T -> (vlad_raw [N][K][C] | None, vlad_norm [N][K*C] | None)."""
+    dev = _need_cuda(feat, assign_w, centroids)
+    p = BF16 if feat.dtype == torch.bfloat16 else F32
+    if feat.dtype not in (torch.bfloat16, torch.float32):
+        raise ValueError("netvlad: feature map must be bf16 or fp32")
+    N, C_ = int(feat.shape[0]), int(feat.shape[-1])
+    P = feat.numel() // (N * C_)
+    K = int(centroids.shape[0])
+    aw = assign_w.reshape(K, C_)
+    if aw.dtype != torch.float32 or centroids.dtype != torch.float32 or not aw.is_contiguous():
+        raise ValueError("netvlad: assign_w / centroids must be contiguous float32")
+    lib = _lib.load()
+    ws_bytes = lib.oibl_netvlad_workspace_bytes(N, P, K, C_)
+    ws = workspace(ws_bytes, dev, "netvlad")
+    raw = torch.empty((N, K, C_), dtype=torch.float32, device=dev) if want_raw else None
+    nrm = torch.empty((N, K * C_), dtype=torch.float32, device=dev) if want_norm else None
+    _lib.check(lib.oibl_netvlad_forward(_ptr(feat), N, P, K, C_, p, _ptr(aw), _ptr(centroids),
+                                        int(normalize_input), _ptr(raw), _ptr(nrm), _ptr(ws),
+                                        ws.numel(), _stream(dev)), "netvlad_forward")
+    return raw, nrm
+
+
+# ---- PCA --------------------------------------------------------------------------------------
+def pca(v: torch.Tensor, w: torch.Tensor, b: torch.Tensor, l2norm: bool = True) -> torch.Tensor:
+    """normalize(W v + b): v [N][D] fp32, w [d][D] bf16|fp32 (selects the precision), b [d] fp32."""
+    dev = _need_cuda(v, w, b)
+    if w.dtype not in (torch.bfloat16, torch.float32):
+        raise ValueError("pca: weight must be bf16 or fp32")
+    p = BF16 if w.dtype == torch.bfloat16 else F32
+    if v.dtype != torch.float32 or b.dtype != torch.float32:
+        raise ValueError("pca: v and b must be float32")
+    N, D = map(int, v.shape)
+    d = int(w.shape[0])
+    if w.numel() != d * D:
+        raise ValueError("pca: weight shape mismatch")
+    lib = _lib.load()
+    ws_bytes = lib.oibl_pca_workspace_bytes(N, D, d, p)
+    ws = workspace(ws_bytes, dev, "pca")
+    out = torch.empty((N, d), dtype=torch.float32, device=dev)
+    _lib.check(lib.oibl_pca_forward(_ptr(v), N, D, _ptr(w), _ptr(b), d, p, int(l2norm), _ptr(out),
+                                    _ptr(ws), ws.numel(), _stream(dev)), "pca_forward")
+    return out
+
+
+def l2_normalize(x: torch.Tensor) -> torch.Tensor:
+    """Row-wise x / max(||x||, 1e-12) for a float32 [N][D] tensor."""
+    dev = _need_cuda(x)
+    if x.dtype != torch.float32 or x.dim() != 2:
+        raise ValueError("l2_normalize expects a float32 [N][D] tensor")
+    out = torch.empty_like(x)
+    if x.shape[0] == 0:
+        return out
+    _lib.check(_lib.load().oibl_l2_normalize_rows(_ptr(x), int(x.shape[0]), int(x.shape[1]),
+                                                  _ptr(out), _stream(dev)), "l2_normalize_rows")
+    return out
+
+
+# ---- matching ---------------------------------------------------------------------------------
+def pairwise_sqdist(x: torch.Tensor, y: torch.Tensor, precision=F32,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dist[i][j] = |x_i|^2 + |y_j|^2 - 2 x_i.y_j for float32 x [m][d], y [n][d]."""
+    p = precision_code(precision)
+    dev = _need_cuda(x, y, out)
+    if x.dtype != torch.float32 or y.dtype != torch.float32 or x.dim() != 2 or y.dim() != 2:
+        raise ValueError("pairwise_sqdist expects float32 [m][d] and [n][d]")
+    m, d = map(int, x.shape)
+    n = int(y.shape[0])
+    if int(y.shape[1]) != d:
+        raise ValueError("pairwise_sqdist: dimension mismatch")
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=dev)
+    if m == 0 or n == 0:
+        return out
+    lib = _lib.load()
+    ws_bytes = lib.oibl_pairwise_workspace_bytes(m, n, d, p)
+    ws = workspace(ws_bytes, dev, "pairwise")
+    _lib.check(lib.oibl_pairwise_sqdist(_ptr(x), m, _ptr(y), n, d, p, _ptr(out), int(out.stride(0)),
+                                        _ptr(ws), ws.numel(), _stream(dev)), "pairwise_sqdist")
+    return out
+
+
+def row_topk(vals: torch.Tensor, k: int, index_base: int = 0,
+             idx_in: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """k smallest per row, ascending, lowest index first on ties -> (values [m][k], idx [m][k] int32)."""
+    dev = _need_cuda(vals, idx_in)
+    if vals.dtype != torch.float32 or vals.dim() != 2:
+        raise ValueError("row_topk expects a float32 [m][n] tensor")
+    if idx_in is not None and (idx_in.dtype != torch.int32 or idx_in.shape != vals.shape):
+        raise ValueError("row_topk: idx_in must be int32 with the shape of vals")
+    m, n = map(int, vals.shape)
+    ov = torch.empty((m, k), dtype=torch.float32, device=dev)
+    oi = torch.empty((m, k), dtype=torch.int32, device=dev)
+    if m == 0:
+        return ov, oi
+    _lib.check(_lib.load().oibl_row_topk(_ptr(vals), _ptr(idx_in), m, n, int(vals.stride(0)), k,
+                                         int(index_base), _ptr(ov), _ptr(oi), _stream(dev)),
+               "row_topk")
+    return ov, oi
+
+
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, regstage: bool = False) -> torch.Tensor:
+    """Diagnostic: C = A . B^T on the MFMA core; A [M][K], B [N][K] both bf16 or both fp32."""
+    dev = _need_cuda(a, b)
+    if a.dtype != b.dtype or a.dtype not in (torch.bfloat16, torch.float32):
+        raise ValueError("gemm_nt: operands must both be bf16 or both fp32")
+    p = BF16 if a.dtype == torch.bfloat16 else F32
+    M, K = map(int, a.shape)
+    N = int(b.shape[0])
+    c = torch.empty((M, N), dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().oibl_gemm_nt(_ptr(a), M, _ptr(b), N, K, p | (0x100 if regstage else 0),
+                                        _ptr(c), N, _stream(dev)), "gemm_nt")
+    return c

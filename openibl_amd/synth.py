@@ -1,0 +1,158 @@
+"""Deterministic synthetic weights and inputs for the descriptor + matching path.
+
+Neither the released checkpoint (hubconf.py:10, a GitHub release URL) nor the Pittsburgh / Tokyo
+images are reachable here, so tests, goldens and the benchmark all run on these seeded stand-ins.
+Everything is drawn from numpy's PCG64 stream (stable across numpy versions and machines), never
+from torch's RNG, so that the build container and the GPU box generate bit-identical tensors.
+
+State-dict keys and shapes are exactly those of the reference's
+`vgg16_netvlad()` / `EmbedNetPCA`.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+# torchvision vgg16 `features` indices of the 13 convolutions kept by ibl/models/vgg.py:40-42
+CONV_IDX = (0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28)
+CONV_CH = ((3, 64), (64, 64), (64, 128), (128, 128), (128, 256), (256, 256), (256, 256),
+           (256, 512), (512, 512), (512, 512), (512, 512), (512, 512), (512, 512))
+NUM_CLUSTERS = 64
+DIM = 512
+PCA_DIM = 4096
+
+# input normalisation of the reference test transform (ibl/utils/data/__init__.py:40-41):
+# Normalize(mean, std = 1/255) on ToTensor output  ==  pixel_0..255 - 255 * mean
+MEAN = (0.48501960784313836, 0.4579568627450961, 0.4076039215686255)
+STD = 0.00392156862745098
+
+
+def _normal(rng: np.random.Generator, shape, std: float) -> torch.Tensor:
+    return torch.from_numpy(rng.standard_normal(shape, dtype=np.float32) * np.float32(std))
+
+
+def backbone_state(seed: int = 0, prefix: str = "base_model.base.") -> "OrderedDict[str, torch.Tensor]":
+    """conv weights ~ N(0, sqrt(2 / fan_out)) like VGG.reset_params (vgg.py:72-77); biases are
+    small non-zero values (the reference zero-fills them, which would leave the bias path of the
+    kernels untested)."""
+    rng = np.random.default_rng([seed, 1])
+    sd = OrderedDict()
+    for idx, (cin, cout) in zip(CONV_IDX, CONV_CH):
+        std = math.sqrt(2.0 / (cout * 9))
+        sd[f"{prefix}{idx}.weight"] = _normal(rng, (cout, cin, 3, 3), std)
+        sd[f"{prefix}{idx}.bias"] = _normal(rng, (cout,), 0.05)
+    return sd
+
+
+def netvlad_state(seed: int = 0, prefix: str = "net_vlad.", alpha: float = 30.0
+                  ) -> "OrderedDict[str, torch.Tensor]":
+    """A trained-looking NetVLAD layer: centroids of norm ~0.08, conv.weight = alpha * unit
+    centroid (+ a perturbation, since the two are independent parameters after training) so that
+    the soft-assignment is neither uniform nor one-hot."""
+    rng = np.random.default_rng([seed, 2])
+    cent = _normal(rng, (NUM_CLUSTERS, DIM), 0.08 / math.sqrt(DIM))
+    unit = cent / cent.norm(dim=1, keepdim=True)
+    conv = alpha * unit + _normal(rng, (NUM_CLUSTERS, DIM), 0.02 * alpha / math.sqrt(DIM))
+    sd = OrderedDict()
+    sd[f"{prefix}centroids"] = cent.contiguous()
+    sd[f"{prefix}conv.weight"] = conv.reshape(NUM_CLUSTERS, DIM, 1, 1).contiguous()
+    return sd
+
+
+def pca_state(seed: int = 0, prefix: str = "pca_layer.", dim: int = PCA_DIM
+              ) -> "OrderedDict[str, torch.Tensor]":
+    rng = np.random.default_rng([seed, 3])
+    sd = OrderedDict()
+    sd[f"{prefix}weight"] = _normal(rng, (dim, NUM_CLUSTERS * DIM, 1, 1), 0.01)
+    sd[f"{prefix}bias"] = _normal(rng, (dim,), 0.01)
+    return sd
+
+
+def embednetpca_state(seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    """Full state dict of the reference's EmbedNetPCA (30 tensors, 149 002 048 parameters)."""
+    sd = backbone_state(seed)
+    sd.update(netvlad_state(seed))
+    sd.update(pca_state(seed))
+    return sd
+
+
+def embednet_state(seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    sd = backbone_state(seed)
+    sd.update(netvlad_state(seed))
+    return sd
+
+
+def images(n: int, height: int = 480, width: int = 640, seed: int = 1) -> torch.Tensor:
+    """[n][3][height][width] float32, normalised exactly like the reference's test transform.
+
+    uint8 pixels = a per-image mixture of low-frequency sinusoids, soft blobs and noise (white
+    noise alone makes every image collapse to nearly the same descriptor), then
+    (pixel / 255 - mean) / std  ->  values in about [-124, 151]."""
+    rng = np.random.default_rng([seed, 4])
+    yy = np.linspace(0.0, 1.0, height, dtype=np.float32)[:, None]
+    xx = np.linspace(0.0, 1.0, width, dtype=np.float32)[None, :]
+    out = np.empty((n, 3, height, width), dtype=np.float32)
+    for i in range(n):
+        img = np.zeros((3, height, width), dtype=np.float32)
+        for c in range(3):
+            acc = np.zeros((height, width), dtype=np.float32)
+            for _ in range(6):
+                fy, fx = rng.uniform(0.5, 14.0, size=2).astype(np.float32)
+                ph = np.float32(rng.uniform(0, 2 * math.pi))
+                amp = np.float32(rng.uniform(0.3, 1.0))
+                acc += amp * np.sin(2 * math.pi * (fy * yy + fx * xx) + ph)
+            for _ in range(4):
+                cy, cx = rng.uniform(0, 1, size=2).astype(np.float32)
+                s = np.float32(rng.uniform(0.03, 0.2))
+                amp = np.float32(rng.uniform(-2.0, 2.0))
+                acc += amp * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * s * s))
+            img[c] = acc
+        img = (img - img.min()) / max(float(img.max() - img.min()), 1e-6) * 255.0
+        img += rng.normal(0.0, 6.0, size=img.shape).astype(np.float32)
+        u8 = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+        x = u8.astype(np.float32) / np.float32(255.0)
+        for c in range(3):
+            out[i, c] = (x[c] - np.float32(MEAN[c])) / np.float32(STD)
+    return torch.from_numpy(out)
+
+
+def descriptors(n: int, dim: int = PCA_DIM, seed: int = 2) -> torch.Tensor:
+    """n unit-norm float32 descriptors."""
+    rng = np.random.default_rng([seed, 5])
+    x = rng.standard_normal((n, dim), dtype=np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return torch.from_numpy(x)
+
+
+def retrieval_problem(num_query: int, num_gallery: int, dim: int = PCA_DIM, seed: int = 3,
+                      positives_per_query: int = 2, noise: float = 0.6,
+                      hard_fraction: float = 0.3, views_per_place: int = 1,
+                      hard_noise_mult: float = 25.0):
+    """Synthetic matching set with planted positives.
+
+    Returns (q [Q][dim], g [G][dim], gt: list[list[int]], gallery_pids: list[int]).
+    For each query a few gallery rows are replaced by normalize(query + sigma * noise); a fraction
+    of the queries get a much larger sigma (cosine to the query ~4 sigma of the random-pair
+    distribution) so that Recall@1 < Recall@5 < Recall@10 < 1 and the numbers
+    are not trivially 0 or 1.  `views_per_place` > 1 gives consecutive gallery rows the same pid
+    (Tokyo 24/7 style, exercises spatial_nms)."""
+    rng = np.random.default_rng([seed, 6])
+    q = rng.standard_normal((num_query, dim), dtype=np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    g = rng.standard_normal((num_gallery, dim), dtype=np.float32)
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    gt = []
+    slots = rng.permutation(num_gallery)[: num_query * positives_per_query]
+    slots = slots.reshape(num_query, positives_per_query)
+    hard = rng.uniform(size=num_query) < hard_fraction
+    for i in range(num_query):
+        amp = noise * (hard_noise_mult if hard[i] else 1.0) / math.sqrt(dim)
+        for j in slots[i]:
+            v = q[i] + np.float32(amp) * rng.standard_normal(dim, dtype=np.float32)
+            g[j] = v / np.linalg.norm(v)
+        gt.append(sorted(int(j) for j in slots[i]))
+    pids = [int(j // views_per_place) for j in range(num_gallery)]
+    return torch.from_numpy(q), torch.from_numpy(g), gt, pids

@@ -1,0 +1,182 @@
+"""Generate tests/golden/*.npz by running THE REFERENCE ITSELF (imported from /root/reference).
+
+Run in the build container only (`python oracle/make_golden.py`); the GPU box has no
+/root/reference.  The inputs are regenerated from seeds by `openibl_amd.synth` on both sides, so
+the fixtures hold only the reference's outputs (plus the seeds / shapes that produced them).
+
+What is exercised, all through the reference's own code objects:
+  hubconf.vgg16_netvlad() -> EmbedNetPCA.forward                     (hubconf.py:5-11, netvlad.py:95-110)
+  VGG.forward, NetVLAD.forward, EmbedNet.forward                     (vgg.py:61-70, netvlad.py:44-82)
+  ibl.evaluators.extract_cnn_feature                                 (evaluators.py:22-34)
+  ibl.pca.PCA.load / PCA.infer                                       (pca.py:86-123)
+  ibl.evaluators.pairwise_distance / evaluate_all / spatial_nms      (evaluators.py:105-167)
+Two things have to be faked for the reference to run on a CPU-only box without h5py: `Tensor.cuda`
+is patched to the identity, and `h5py.File` is served from an in-memory dict.
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+import os
+import sys
+from collections import OrderedDict
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+from oracle import refshim  # noqa: E402
+
+refshim.install()  # puts /root/reference FIRST on sys.path: `import ibl` below is the reference
+
+from openibl_amd import synth  # noqa: E402
+
+OUT = ROOT / "tests" / "golden"
+WEIGHT_SEED = 0
+
+
+@contextlib.contextmanager
+def cpu_cuda():
+    orig = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        yield
+    finally:
+        torch.Tensor.cuda = orig
+
+
+class _FakeH5Group(dict):
+    def __getitem__(self, k):
+        if k == ".":
+            return self
+        return dict.__getitem__(self, k)
+
+
+def fake_h5py(datasets):
+    import h5py
+
+    class File:
+        def __init__(self, path, mode="r"):
+            self.g = _FakeH5Group({k: np.asarray(v) for k, v in datasets.items()})
+
+        def __getitem__(self, k):
+            return self.g[k]
+
+        def close(self):
+            pass
+
+    h5py.File = File
+
+
+def main():
+    import ibl  # the reference
+    assert ibl.__file__.startswith(refshim.REFERENCE_ROOT), ibl.__file__
+    from ibl import models
+    from ibl.evaluators import extract_cnn_feature, pairwise_distance, evaluate_all, spatial_nms
+    from ibl.pca import PCA
+
+    refshim.init_process_group()
+    OUT.mkdir(parents=True, exist_ok=True)
+    torch.set_num_threads(8)
+
+    sd = synth.embednetpca_state(WEIGHT_SEED)
+    model = refshim.reference_model(sd)            # hubconf.vgg16_netvlad + load_state_dict
+    embednet = models.create("embednet", model.base_model, model.net_vlad).eval()
+
+    def run_descriptor(name, n, h, w, seed, keep_feat_stride=1):
+        x = synth.images(n, h, w, seed=seed)
+        with torch.no_grad():
+            desc = model(x)
+            pool_x, feat = model.base_model(x)
+            vlad_raw = model.net_vlad(feat)
+            pool_e, vlad_norm = embednet(x)
+            with cpu_cuda():
+                ecf_pca = extract_cnn_feature(model, x)
+                ecf_vlad = extract_cnn_feature(embednet, x, vlad=True)
+                ecf_pool = extract_cnn_feature(embednet, x, vlad=False)
+        assert torch.equal(pool_x, pool_e)
+        np.savez_compressed(
+            OUT / f"{name}.npz",
+            weight_seed=WEIGHT_SEED, image_seed=seed, shape=np.array([n, 3, h, w]),
+            feat_stride=keep_feat_stride,
+            feat=feat[:, ::keep_feat_stride].numpy(), pool_x=pool_x.numpy(),
+            vlad_raw=vlad_raw.numpy(), vlad_norm=vlad_norm.numpy(), desc=desc.numpy(),
+            ecf_pca=ecf_pca.numpy(), ecf_vlad=ecf_vlad.numpy(), ecf_pool=ecf_pool.numpy())
+        print(name, "desc", tuple(desc.shape), "feat", tuple(feat.shape),
+              "row norms", desc.norm(dim=1).tolist()[:2],
+              "d2(img0,img1)" if n > 1 else "", float((desc[0] - desc[-1]).pow(2).sum()) if n > 1 else "")
+
+    run_descriptor("desc_small", 2, 64, 96, seed=11)
+    run_descriptor("desc_odd", 2, 70, 90, seed=13)          # not multiples of 16: pools floor
+    run_descriptor("desc_480x640", 1, 480, 640, seed=12, keep_feat_stride=8)   # BASELINE config[0]
+
+    # ---- PCA.load / PCA.infer -------------------------------------------------------------
+    rng = np.random.default_rng([7, 7])
+    D, d, npts = 256, 128, 300                       # small stand-in for 32768 -> 4096
+    U = np.linalg.qr(rng.standard_normal((D, D)))[0][:, :160].astype(np.float32)
+    lams = np.sort(rng.uniform(0.05, 3.0, size=160).astype(np.float32))[::-1].copy()
+    mu = rng.standard_normal((D, 1)).astype(np.float32) * 0.1
+    Utmu = (U.T @ mu).astype(np.float32)
+    fake_h5py({"U": U, "lams": lams, "mu": mu, "Utmu": Utmu})
+    data = torch.from_numpy(rng.standard_normal((npts, D)).astype(np.float32))
+    res = {}
+    for whiten in (True, False):
+        pca = PCA(pca_n_components=d, pca_whitening=whiten, pca_parameters_path="unused.h5")
+        with cpu_cuda(), contextlib.redirect_stdout(io.StringIO()):
+            pca.load(gpu=None)
+            out = pca.infer(data)
+        tag = "whiten" if whiten else "nowhiten"
+        res[f"weight_{tag}"] = pca.weight.view(d, D).numpy()
+        res[f"bias_{tag}"] = pca.bias.numpy()
+        res[f"out_{tag}"] = out.numpy()
+    np.savez_compressed(OUT / "pca.npz", U=U, lams=lams, mu=mu, Utmu=Utmu, data=data.numpy(),
+                        n_components=d, **res)
+    print("pca", res["out_whiten"].shape)
+
+    # ---- matching ---------------------------------------------------------------------------
+    def run_matching(name, Q, G, seed, views_per_place, dim=4096):
+        q, g, gt, pids = synth.retrieval_problem(Q, G, dim=dim, seed=seed,
+                                                 views_per_place=views_per_place,
+                                                 hard_fraction=0.5, hard_noise_mult=35.0)
+        features = OrderedDict()
+        query = [(f"q{i:05d}.jpg", 100000 + i, 0.0, 0.0) for i in range(Q)]
+        gallery = [(f"g{j:05d}.jpg", pids[j], 0.0, 0.0) for j in range(G)]
+        for (f, _, _, _), v in zip(query, q):
+            features[f] = v
+        for (f, _, _, _), v in zip(gallery, g):
+            features[f] = v
+        with contextlib.redirect_stdout(io.StringIO()):
+            distmat, xq, yg = pairwise_distance(features, query, gallery)
+            rec = evaluate_all(distmat.numpy().copy(), gt, gallery)
+            rec_nms = evaluate_all(distmat.numpy().copy(), gt, gallery, nms=True)
+            sub = OrderedDict((k, features[k]) for k in list(features)[:40])
+            dist_all, _, _ = pairwise_distance(sub)
+        order = np.argsort(distmat.numpy(), axis=1)
+        nms_rows = [spatial_nms(order[i].tolist(), [gl[1] for gl in gallery], 120)
+                    for i in range(min(Q, 8))]
+        nms_len = max(len(r) for r in nms_rows)
+        nms_arr = np.full((len(nms_rows), nms_len), -1, dtype=np.int64)
+        for i, r in enumerate(nms_rows):
+            nms_arr[i, : len(r)] = r
+        assert np.array_equal(xq, q.numpy()) and np.array_equal(yg, g.numpy())
+        np.savez_compressed(OUT / f"{name}.npz", Q=Q, G=G, dim=dim, seed=seed,
+                            views_per_place=views_per_place, hard_fraction=0.5,
+                            hard_noise_mult=35.0, distmat=distmat.numpy(),
+                            recalls=rec, recalls_nms=rec_nms, dist_all40=dist_all.numpy(),
+                            nms_rows=nms_arr, top20=order[:, :20])
+        print(name, "recalls", rec, "nms", rec_nms)
+
+    run_matching("match_small", 48, 300, seed=21, views_per_place=1)
+    run_matching("match_nms", 40, 360, seed=22, views_per_place=12)
+    # tiny-dimension case with many exact ties is deliberately absent: np.argsort's tie order is
+    # unspecified in the reference (evaluators.py:143).
+
+    for p in sorted(OUT.glob("*.npz")):
+        print(f"{p.name}: {p.stat().st_size / 1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    main()

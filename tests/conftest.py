@@ -1,0 +1,68 @@
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+GOLDEN = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real AMD GPU (run on the MI355X box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def load_golden(name):
+    return dict(np.load(GOLDEN / f"{name}.npz", allow_pickle=False))
+
+
+@pytest.fixture(scope="session")
+def state_dict():
+    """Synthetic EmbedNetPCA weights (seed 0) — the ones the goldens were generated with."""
+    from openibl_amd import synth
+    return synth.embednetpca_state(0)
+
+
+@pytest.fixture(scope="session")
+def dev():
+    return torch.device("cuda", 0)
+
+
+def rel_l2(got, want):
+    got = torch.as_tensor(got).double().flatten()
+    want = torch.as_tensor(want).double().flatten()
+    return float((got - want).norm() / want.norm().clamp_min(1e-30))
+
+
+def report(name, got, want):
+    got = torch.as_tensor(got).double().cpu()
+    want = torch.as_tensor(want).double().cpu()
+    diff = (got - want).abs()
+    i = int(diff.flatten().argmax())
+    msg = (f"{name}: rel_l2={rel_l2(got, want):.3e} max_abs={float(diff.max()):.3e} "
+           f"at flat index {i} (got {float(got.flatten()[i]):.6g}, want {float(want.flatten()[i]):.6g}) "
+           f"|want|max={float(want.abs().max()):.3e} shape={tuple(want.shape)}")
+    print(msg)
+    return msg
+
+
+def assert_rel_l2(name, got, want, tol):
+    assert tuple(torch.as_tensor(got).shape) == tuple(torch.as_tensor(want).shape), \
+        f"{name}: shape {tuple(got.shape)} != {tuple(want.shape)}"
+    msg = report(name, got, want)
+    assert torch.isfinite(torch.as_tensor(got).float()).all(), f"{name}: non-finite values; {msg}"
+    assert rel_l2(got, want) <= tol, f"{msg} > tol {tol:g}"
