@@ -1,0 +1,74 @@
+"""3x3 convolution kernels against F.conv2d on the host (GPU)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import assert_rel_l2
+from openibl_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(N, H, W, cin, cout, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((N, cin, H, W), generator=g)
+    w = torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn((cout,), generator=g) * 0.1
+    return x, w, b
+
+
+def _host_conv(x, w, b, relu, pool, precision):
+    """What the kernel computes: operands rounded to the storage type, exact accumulation."""
+    if precision == "bf16":
+        x, w = x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float()
+    y = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if relu:
+        y = F.relu(y)
+    if pool:
+        y = F.max_pool2d(y, 2, 2)
+    return y
+
+
+@pytest.mark.parametrize("regstage", [False, True])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("N,H,W,cin,cout,relu,pool", [
+    (2, 12, 20, 64, 64, True, False),
+    (2, 12, 20, 64, 64, True, True),
+    (1, 9, 7, 64, 128, True, False),      # odd sizes, partial tiles
+    (1, 9, 7, 128, 128, True, True),      # odd sizes + pooling floors
+    (3, 8, 8, 256, 256, False, False),
+    (1, 30, 40, 512, 512, False, False),  # conv5_3 shape
+    (2, 6, 10, 256, 512, True, True),
+])
+def test_conv3x3(dev, N, H, W, cin, cout, relu, pool, precision, regstage):
+    x, w, b = _case(N, H, W, cin, cout, seed=H * 1000 + cin)
+    ops.set_regstage(regstage)
+    try:
+        xd = ops.nchw_f32_to_nhwc(x.to(dev), precision)
+        wp = ops.pack_conv3x3(w.to(dev), precision)
+        y = ops.conv3x3_nhwc(xd, wp, b.to(dev), relu, pool, precision)
+    finally:
+        ops.set_regstage(False)
+    got = ops.nhwc_to_nchw_f32(y).cpu()
+    want = _host_conv(x, w, b, relu, pool, precision)
+    tol = 2e-6 if precision == "fp32" else 4e-3   # bf16: output rounding (2^-9 relative)
+    assert_rel_l2(f"conv3x3 {precision} {N}x{H}x{W} {cin}->{cout} relu={relu} pool={pool}",
+                  got, want, tol)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("N,H,W", [(2, 16, 24), (1, 7, 13), (1, 33, 9)])
+def test_conv1_1(dev, N, H, W, precision):
+    x, w, b = _case(N, H, W, 3, 64, seed=77 + H)
+    x = x * 60.0
+    y = ops.conv1_1_nchw(x.to(dev), w.to(dev), b.to(dev), precision)
+    got = ops.nhwc_to_nchw_f32(y).cpu()
+    want = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1))
+    assert_rel_l2(f"conv1_1 {precision}", got, want, 2e-6 if precision == "fp32" else 4e-3)
+
+
+def test_pack_layout(dev):
+    w = torch.arange(2 * 64 * 64 * 9, dtype=torch.float32).reshape(128, 64, 3, 3) / 1000.0
+    p = ops.pack_conv3x3(w.to(dev), "fp32").cpu()
+    assert tuple(p.shape) == (9, 128, 64)
+    assert torch.equal(p, w.permute(2, 3, 0, 1).reshape(9, 128, 64))

@@ -1,0 +1,115 @@
+"""Image -> 4096-d descriptor through the reference's API surface on the HIP path, against the
+vectors the reference itself produced (tests/golden) and against the oracle (GPU)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_rel_l2, load_golden, rel_l2
+from openibl_amd import ops, synth
+from oracle import descriptor as od
+
+pytestmark = pytest.mark.gpu
+
+# north_star: descriptors within 1e-4 relative of the reference CPU path (fp32 mode)
+TOL_FP32 = 1e-4
+
+
+@pytest.fixture(scope="module")
+def model(state_dict, dev):
+    import hubconf
+    m = hubconf.vgg16_netvlad(pretrained=False)
+    m.load_state_dict(state_dict)
+    return m.to(dev).eval()
+
+
+@pytest.mark.parametrize("name", ["desc_small", "desc_odd", "desc_480x640"])
+def test_embednetpca_fp32_matches_reference(name, model, dev):
+    g = load_golden(name)
+    n, _, h, w = [int(v) for v in g["shape"]]
+    x = synth.images(n, h, w, seed=int(g["image_seed"])).to(dev)
+    model.set_precision("fp32")
+    desc = model(x)
+    assert tuple(desc.shape) == (n, 4096) and desc.dtype == torch.float32
+    assert_rel_l2(f"{name} desc", desc.cpu(), g["desc"], TOL_FP32)
+    # stage by stage
+    pool_x, feat = model.base_model(x)
+    s = int(g["feat_stride"])
+    assert_rel_l2(f"{name} feat", feat.cpu()[:, ::s], g["feat"], TOL_FP32)
+    assert_rel_l2(f"{name} pool_x", pool_x.cpu(), g["pool_x"], TOL_FP32)
+    vlad_raw = model.net_vlad(feat)
+    assert tuple(vlad_raw.shape) == (n, 64, 512)
+    assert_rel_l2(f"{name} vlad_raw", vlad_raw.cpu(), g["vlad_raw"], TOL_FP32)
+    from ibl import models
+    emb = models.create("embednet", model.base_model, model.net_vlad).eval()
+    pool_e, vlad = emb(x)
+    assert_rel_l2(f"{name} vlad_norm", vlad.cpu(), g["vlad_norm"], TOL_FP32)
+    assert_rel_l2(f"{name} pool_e", pool_e.cpu(), g["pool_x"], TOL_FP32)
+    from ibl.evaluators import extract_cnn_feature
+    assert_rel_l2(f"{name} ecf pca", extract_cnn_feature(model, x.cpu()).cpu(), g["ecf_pca"], TOL_FP32)
+    assert_rel_l2(f"{name} ecf vlad", extract_cnn_feature(emb, x.cpu(), vlad=True).cpu(),
+                  g["ecf_vlad"], TOL_FP32)
+    assert_rel_l2(f"{name} ecf pool", extract_cnn_feature(emb, x.cpu(), vlad=False).cpu(),
+                  g["ecf_pool"], TOL_FP32)
+
+
+@pytest.mark.parametrize("name", ["desc_small", "desc_480x640"])
+def test_embednetpca_bf16_reported_honestly(name, model, dev):
+    """bf16 operands cannot meet 1e-4 (~5e-3 expected); the test pins the error band
+    and the cosine instead, and the regstage / glds variants must agree bit for bit."""
+    g = load_golden(name)
+    n, _, h, w = [int(v) for v in g["shape"]]
+    x = synth.images(n, h, w, seed=int(g["image_seed"])).to(dev)
+    model.set_precision("bf16")
+    try:
+        desc = model(x).cpu()
+        ops.set_regstage(True)
+        desc_rs = model(x).cpu()
+    finally:
+        ops.set_regstage(False)
+        model.set_precision("fp32")
+    want = torch.from_numpy(g["desc"])
+    err = rel_l2(desc, want)
+    cos = torch.nn.functional.cosine_similarity(desc.double(), want.double(), dim=1).min().item()
+    print(f"{name}: bf16 rel_l2={err:.3e} min cosine={cos:.6f}")
+    assert err < 3e-2 and cos > 0.9995
+    assert torch.equal(desc, desc_rs)
+
+
+def test_batch_rows_are_independent(model, dev):
+    """A batch gives the same descriptors as its images one at a time (and different images give
+    different descriptors)."""
+    x = synth.images(3, 64, 96, seed=31).to(dev)
+    model.set_precision("fp32")
+    full = model(x).cpu()
+    for i in range(3):
+        one = model(x[i:i + 1].contiguous()).cpu()
+        assert_rel_l2(f"row {i}", one[0], full[i], 1e-6)
+    assert (full[0] - full[1]).norm() > 1e-3
+
+
+def test_state_dict_contract(model, state_dict):
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(state_dict.keys())
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(state_dict[k].shape), k
+    # DDP-style prefixed checkpoints load through copy_state_dict
+    from ibl.utils.serialization import copy_state_dict
+    import hubconf
+    m2 = hubconf.vgg16_netvlad()
+    copy_state_dict({"module." + k: v for k, v in state_dict.items()}, m2, strip="module.")
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v, state_dict[k]), k
+
+
+def test_weight_update_invalidates_packed_cache(model, dev, state_dict):
+    x = synth.images(1, 64, 96, seed=11).to(dev)
+    model.set_precision("fp32")
+    a = model(x).cpu()
+    key = "base_model.base.28.bias"
+    with torch.no_grad():
+        model.state_dict()[key].add_(0.5)
+    b = model(x).cpu()
+    model.load_state_dict(state_dict)
+    c = model(x).cpu()
+    assert (a - b).norm() > 1e-4
+    assert torch.equal(a, c)

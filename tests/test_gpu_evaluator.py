@@ -1,0 +1,69 @@
+"""End-to-end Evaluator flows on one GPU with a synthetic loader (GPU)."""
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+
+from openibl_amd import synth
+from oracle import descriptor as od
+from oracle import matching as om
+
+pytestmark = pytest.mark.gpu
+
+
+class _Records(torch.utils.data.Dataset):
+    def __init__(self, images, records):
+        self.images, self.records = images, records
+
+    def __len__(self):
+        return len(self.records)
+
+    def __getitem__(self, i):
+        f, pid, x, y = self.records[i]
+        return self.images[i], f, pid, x, y
+
+
+@pytest.fixture(scope="module")
+def group():
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1)
+    yield
+    dist.destroy_process_group()
+
+
+def test_evaluator_flows_agree_with_oracle(group, state_dict, dev):
+    import hubconf
+    from ibl.evaluators import Evaluator
+    from ibl.utils.data.sampler import DistributedSliceSampler
+    model = hubconf.vgg16_netvlad()
+    model.load_state_dict(state_dict)
+    model = model.to(dev).eval()
+    nq, ng = 5, 13
+    imgs = synth.images(nq + ng, 64, 96, seed=41)
+    # queries are noisy copies of some gallery images
+    for i in range(nq):
+        imgs[i] = imgs[nq + 2 * i] + 2.0 * torch.randn_like(imgs[i])
+    query = [(f"q{i}.png", 1000 + i, 0.0, 0.0) for i in range(nq)]
+    gallery = [(f"g{j}.png", j // 2, 0.0, 0.0) for j in range(ng)]
+    gt = [[2 * i] for i in range(nq)]
+    qset, gset = _Records(imgs[:nq], query), _Records(imgs[nq:], gallery)
+
+    def loader(ds):
+        return torch.utils.data.DataLoader(ds, batch_size=4, num_workers=0, shuffle=False,
+                                           sampler=DistributedSliceSampler(ds))
+
+    ev = Evaluator(model)
+    r_dev = ev.evaluate(loader(qset), query + gallery, query, gallery, gt, gallery_loader=loader(gset))
+    r_host = ev.evaluate(loader(qset), query + gallery, query, gallery, gt,
+                         gallery_loader=loader(gset), device_resident=False)
+    r_nms = ev.evaluate(loader(qset), query + gallery, query, gallery, gt,
+                        gallery_loader=loader(gset), nms=True)
+    with torch.no_grad():
+        desc = od.extract_cnn_feature(imgs, state_dict)
+    d = om.pairwise_distance(desc[:nq], desc[nq:]).numpy()
+    want = om.evaluate_all(d, gt, [g[1] for g in gallery])
+    want_nms = om.evaluate_all(d, gt, [g[1] for g in gallery], nms=True)
+    print("recalls", r_dev, r_host, want, "nms", r_nms, want_nms)
+    assert np.array_equal(r_dev, want) and np.array_equal(r_host, want)
+    assert np.array_equal(r_nms, want_nms)
+    assert want[0] == 1.0     # the planted copies are found
