@@ -1,0 +1,208 @@
+#!/usr/bin/env python
+"""Benchmark of the descriptor + matching hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: BASELINE.json configs[1], i.e. a batch of 32
+synthetic 480x640 images (already resident in HBM, fp32 NCHW as the reference's loader hands them
+over) through VGG16-conv5 -> NetVLAD -> PCA-4096 in bf16, producing 32 descriptors, through the
+reference's own API (`hubconf.vgg16_netvlad()` -> `model(x)`).  Every rank runs its own batch
+(weak scaling, no data-path collective); `value` is images/s over all ranks.
+
+Rank 0 prints ONE JSON line.  Besides the contract keys it carries
+  roofline      the implicit-GEMM convolution kernel (12 launches per step, 99.4 % of the FLOPs):
+                algorithmic FLOPs of the 12 launches / their measured span, bracketed with HIP
+                events recorded inside the C ABI on the launching stream, against the dense bf16
+                MFMA peak (2.5 PFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md).
+  cpu_baseline  the CPU oracle (a port of the reference's path onto plain torch-CPU ops) timed on
+                this box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+  matching      secondary metric of BASELINE.json: query x gallery squared-L2 pairs/s on a
+                synthetic 8192 x 81920 x 4096-d problem, gallery sharded over the ranks, per-shard
+                top-k + all_gather merge (strong scaling: the gallery size is fixed).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense; MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+F32_MFMA_PEAK_TFLOPS = 157.3
+HEIGHT, WIDTH = 480, 640
+# VGG16 conv stack (cin, cout, spatial divisor); layer 0 (conv1_1) runs on the vector ALU
+_LAYERS = [(3, 64, 1), (64, 64, 1), (64, 128, 2), (128, 128, 2), (128, 256, 4), (256, 256, 4),
+           (256, 256, 4), (256, 512, 8), (512, 512, 8), (512, 512, 8), (512, 512, 16),
+           (512, 512, 16), (512, 512, 16)]
+
+
+def igemm_flops_per_image(h=HEIGHT, w=WIDTH) -> float:
+    return float(sum(2 * (h // d) * (w // d) * cout * 9 * cin for cin, cout, d in _LAYERS[1:]))
+
+
+def total_flops_per_image(h=HEIGHT, w=WIDTH) -> float:
+    p = (h // 16) * (w // 16)
+    return (igemm_flops_per_image(h, w) + 2 * h * w * 64 * 27      # conv1_1
+            + 2 * 2 * p * 64 * 512 + 2 * 4096 * 32768)            # NetVLAD (2 GEMMs) + PCA
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--skip-matching", action="store_true")
+    ap.add_argument("--skip-cpu-baseline", action="store_true")
+    ap.add_argument("--queries", type=int, default=8192)
+    ap.add_argument("--gallery", type=int, default=81920)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an AMD GPU: the hot path has no CPU implementation")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    if world != args.gpus and rank == 0:
+        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+
+    import hubconf
+    from openibl_amd import ops, sharded, synth
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # ---- model + inputs (synthetic, seeded) -------------------------------------------------
+    model = hubconf.vgg16_netvlad(pretrained=False)
+    model.load_state_dict(synth.embednetpca_state(0))
+    model = model.to(dev).eval().set_precision(args.precision)
+    base = synth.images(4, HEIGHT, WIDTH, seed=100 + rank)
+    x = base.repeat((args.batch + 3) // 4, 1, 1, 1)[: args.batch].contiguous().to(dev)
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+    for a, b in ev:           # create the underlying hipEvents
+        a.record()
+        b.record()
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 0)):
+            model(x)
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            model.base_model.profile_events = ev[k]
+            out = model(x)
+        barrier()
+        t1 = time.perf_counter()
+    model.base_model.profile_events = None
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    assert tuple(out.shape) == (args.batch, 4096) and bool(torch.isfinite(out).all())
+
+    images = args.batch * args.steps * world
+    value = images / elapsed
+    span_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)          # 12 igemm launches
+    fl_igemm = igemm_flops_per_image() * args.batch
+    achieved = fl_igemm / (span_ms * 1e-3) / 1e12
+    peak = BF16_MFMA_PEAK_TFLOPS if args.precision == "bf16" else F32_MFMA_PEAK_TFLOPS
+    roofline = {
+        "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+        "frac": round(achieved / peak, 4), "traffic": None,
+        "kernel": "oibl::conv3x3_igemm_kernel (conv1_2..conv5_3, 12 launches/step)",
+        "launches_per_step": 12, "avg_launch_ms": round(span_ms / 12, 5),
+        "flops_per_launch_avg": fl_igemm / 12,
+        "end_to_end_tflops": round(total_flops_per_image() * value / 1e12, 2),
+        "end_to_end_frac": round(total_flops_per_image() * value / 1e12 / (peak * world), 4),
+    }
+
+    # ---- secondary metric: query x gallery matching, gallery sharded ---------------------------
+    matching = None
+    if not args.skip_matching:
+        Q, G = args.queries, args.gallery
+        start, per, n_valid = sharded.slice_bounds(G, rank, world)
+        gq = torch.Generator(device=dev).manual_seed(7)
+        q = torch.nn.functional.normalize(torch.randn((Q, 4096), generator=gq, device=dev), dim=1)
+        gg = torch.Generator(device=dev).manual_seed(11 + rank)
+        g = torch.nn.functional.normalize(torch.randn((n_valid, 4096), generator=gg, device=dev), dim=1)
+        msteps = 5
+        for _ in range(2):
+            sharded.sharded_topk(q, g, 10, start, args.precision)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(msteps):
+            vals, idx = sharded.sharded_topk(q, g, 10, start, args.precision)
+        barrier()
+        t1 = time.perf_counter()
+        mt = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(mt, op=dist.ReduceOp.MAX)
+        pairs = float(Q) * G * msteps / float(mt.item())
+        matching = {"metric": "query_gallery_pairs_per_sec", "value": pairs, "unit": "pairs/s",
+                    "ms_per_step": float(mt.item()) / msteps * 1e3, "scaling": "strong",
+                    "tflops": round(pairs * 8192 / 1e12, 2),
+                    "config": {"workload": f"{Q} queries x {G} gallery x 4096-d squared-L2 + top-10, "
+                                           f"gallery sharded {world}-way, top-k all_gather merge",
+                               "precision": args.precision}}
+        del q, g
+
+    # ---- CPU baseline: the oracle on this box's host cores (rank 0, single-GPU run only) -----------
+    cpu = None
+    if rank == 0 and world == 1 and not args.skip_cpu_baseline:
+        from oracle import descriptor as od
+        sd = synth.embednetpca_state(0)
+        xb = synth.images(4, HEIGHT, WIDTH, seed=100).repeat(2, 1, 1, 1)      # batch 8
+        with torch.no_grad():
+            od.embednetpca(xb[:2], sd)                                       # warm-up
+            reps, t0 = 0, time.perf_counter()
+            while reps < 3 or (time.perf_counter() - t0 < 10.0 and reps < 6):
+                od.embednetpca(xb, sd)
+                reps += 1
+            dt = time.perf_counter() - t0
+        cpu = {"value": round(8 * reps / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(),
+               "kind": "port",
+               "sample": f"{reps} x batch 8 of 480x640 through oracle.descriptor.embednetpca "
+                         f"(torch {torch.__version__} CPU fp32, {os.cpu_count()} logical cores)"}
+
+    if rank == 0:
+        line = {
+            "metric": "descriptors_per_sec", "value": round(value, 2), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "batch=32 VGG16-conv5 + NetVLAD(64x512) + PCA-4096 descriptor "
+                                   "extraction, synthetic 480x640 inputs resident in HBM "
+                                   "(BASELINE.json configs[1])",
+                       "global_batch": args.batch * world, "image": f"3x{HEIGHT}x{WIDTH}",
+                       "parallelism": f"dp{world}",
+                       "weights": "seeded random init (openibl_amd.synth, seed 0)"},
+            "roofline": roofline, "cpu_baseline": cpu, "matching": matching,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -111,6 +111,14 @@ int oibl_vgg16_conv5_forward(const float* x_nchw, int N, int H, int W,
                              const void* const* packed_w_host,
                              const float* const* bias_host, int precision, void* feat,
                              void* ws, size_t ws_bytes, void* stream);
+/* Same, with two optional hipEvent_t handles (may be NULL) recorded on `stream` right before the
+ * first and right after the last implicit-GEMM convolution (conv1_2 .. conv5_3, 12 launches of
+ * the dominant kernel): bench.py brackets the kernel it reports a roofline for with these. */
+int oibl_vgg16_conv5_forward_ev(const float* x_nchw, int N, int H, int W,
+                                const void* const* packed_w_host,
+                                const float* const* bias_host, int precision, void* feat,
+                                void* ws, size_t ws_bytes, void* stream, void* ev_igemm_begin,
+                                void* ev_igemm_end);
 
 /* ---- NetVLAD + intra-norm + L2 ---------------------------------------------------- *
  * Replaces NetVLAD.forward (ibl/models/netvlad.py:44-61) and the normalisation that

@@ -530,6 +530,14 @@ size_t oibl_vgg16_workspace_bytes(int N, int H, int W, int precision) {
 int oibl_vgg16_conv5_forward(const float* x_nchw, int N, int H, int W,
                              const void* const* packed_w_host, const float* const* bias_host,
                              int precision, void* feat, void* ws, size_t ws_bytes, void* stream) {
+  return oibl_vgg16_conv5_forward_ev(x_nchw, N, H, W, packed_w_host, bias_host, precision, feat, ws,
+                                     ws_bytes, stream, nullptr, nullptr);
+}
+
+int oibl_vgg16_conv5_forward_ev(const float* x_nchw, int N, int H, int W,
+                                const void* const* packed_w_host, const float* const* bias_host,
+                                int precision, void* feat, void* ws, size_t ws_bytes, void* stream,
+                                void* ev_igemm_begin, void* ev_igemm_end) {
   OIBL_REQUIRE(x_nchw && packed_w_host && bias_host && feat && ws, "vgg16: null pointer");
   OIBL_REQUIRE(precision == OIBL_BF16 || precision == OIBL_F32, "vgg16: bad precision %d",
                precision);
@@ -549,6 +557,7 @@ int oibl_vgg16_conv5_forward(const float* x_nchw, int N, int H, int W,
   int rc = oibl_conv1_1_nchw(x_nchw, N, H, W, (const float*)packed_w_host[0], bias_host[0],
                              precision, bufA, stream);
   if (rc) return rc;
+  if (ev_igemm_begin) OIBL_HIP_CHECK(hipEventRecord((hipEvent_t)ev_igemm_begin, (hipStream_t)stream));
   int h = H, w = W;
   const void* cur = bufA;
   for (int l = 1; l < OIBL_VGG16_NUM_CONV; ++l) {
@@ -562,6 +571,7 @@ int oibl_vgg16_conv5_forward(const float* x_nchw, int N, int H, int W,
     }
     cur = dst;
   }
+  if (ev_igemm_end) OIBL_HIP_CHECK(hipEventRecord((hipEvent_t)ev_igemm_end, (hipStream_t)stream));
   return OIBL_OK;
 }
 

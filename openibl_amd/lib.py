@@ -36,6 +36,9 @@ SIGNATURES = {
     "oibl_vgg16_conv5_forward": (c_int, [c_void_p, c_int, c_int, c_int, C.POINTER(c_void_p),
                                          C.POINTER(c_void_p), c_int, c_void_p, c_void_p,
                                          c_size_t, c_void_p]),
+    "oibl_vgg16_conv5_forward_ev": (c_int, [c_void_p, c_int, c_int, c_int, C.POINTER(c_void_p),
+                                            C.POINTER(c_void_p), c_int, c_void_p, c_void_p,
+                                            c_size_t, c_void_p, c_void_p, c_void_p]),
     "oibl_netvlad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "oibl_netvlad_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                      c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t,

@@ -132,7 +132,7 @@ class VGG(_PrecisionMixin, nn.Module):
             x = x.float()
         x = x.contiguous()
         ws, bs = self._packed(x.device)
-        return ops.vgg16_conv5(x, ws, bs, self.precision)
+        return ops.vgg16_conv5(x, ws, bs, self.precision, events=getattr(self, "profile_events", None))
 
     @torch.no_grad()
     def forward(self, x):

@@ -167,10 +167,12 @@ def vgg16_feature_hw(H: int, W: int) -> Tuple[int, int]:
 
 
 def vgg16_conv5(x: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor],
-                precision) -> torch.Tensor:
+                precision, events=None) -> torch.Tensor:
     """x [N][3][H][W] fp32 -> conv5_3 feature map [N][h][w][512] T (NHWC), h = H//16, w = W//16.
 
-    weights[0] is the plain conv1_1 tensor, weights[1:] come from pack_conv3x3."""
+    weights[0] is the plain conv1_1 tensor, weights[1:] come from pack_conv3x3.
+    `events`: optional pair of already-recorded torch.cuda.Event(enable_timing=True); they are
+    re-recorded right before / after the 12 implicit-GEMM convolutions (bench.py's roofline)."""
     p = precision_code(precision)
     dev = _need_cuda(x, *weights, *biases)
     if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3:
@@ -187,8 +189,12 @@ def vgg16_conv5(x: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequen
     feat = torch.empty((N, h, w, 512), dtype=_DTYPES[p], device=dev)
     wp = (C.c_void_p * 13)(*[t.data_ptr() for t in weights])
     bp = (C.c_void_p * 13)(*[t.data_ptr() for t in biases])
-    _lib.check(lib.oibl_vgg16_conv5_forward(_ptr(x), N, H, W, wp, bp, p, _ptr(feat), _ptr(ws),
-                                            ws.numel(), _stream(dev)), "vgg16_conv5_forward")
+    ev0 = ev1 = None
+    if events is not None:
+        ev0, ev1 = int(events[0].cuda_event), int(events[1].cuda_event)
+    _lib.check(lib.oibl_vgg16_conv5_forward_ev(_ptr(x), N, H, W, wp, bp, p, _ptr(feat), _ptr(ws),
+                                               ws.numel(), _stream(dev), ev0, ev1),
+               "vgg16_conv5_forward")
     return feat
 
 
@@ -293,7 +299,10 @@ def pairwise_sqdist(x: torch.Tensor, y: torch.Tensor, precision=F32,
                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dist[i][j] = |x_i|^2 + |y_j|^2 - 2 x_i.y_j for float32 x [m][d], y [n][d]."""
     p = precision_code(precision)
-    dev = _need_cuda(x, y, out)
+    dev = _need_cuda(x, y)
+    if out is not None and (not out.is_cuda or out.dtype != torch.float32 or out.dim() != 2
+                            or out.stride(1) != 1 or out.device != dev):
+        raise ValueError("pairwise_sqdist: `out` must be a float32 CUDA matrix with unit column stride")
     if x.dtype != torch.float32 or y.dtype != torch.float32 or x.dim() != 2 or y.dim() != 2:
         raise ValueError("pairwise_sqdist expects float32 [m][d] and [n][d]")
     m, d = map(int, x.shape)

@@ -116,12 +116,13 @@ def test_full_size_properties(dev):
     """Pitts30k-sized matrix (6816 x 10000 x 4096): size-independent checks instead of a host
     recomputation — planted duplicates are their own nearest neighbour at distance ~0, the matrix
     of (g, q) is the transpose of (q, g), and bf16 ranks agree with fp32 on the planted set."""
-    q, gal, gt, _ = synth.retrieval_problem(6816, 10000, seed=5, hard_fraction=0.0)
+    q, gal, gt, _ = synth.retrieval_problem(6816, 10000, seed=5, hard_fraction=0.0,
+                                               positives_per_query=1)
     q, gal = q.to(dev), gal.to(dev)
-    gal[:100] = q[:100]
+    gal[10000 - 100:] = q[:100]
     d = ops.pairwise_sqdist(q, gal, "fp32")
     vals, idx = ops.row_topk(d, 10)
-    assert torch.equal(idx[:100, 0].cpu(), torch.arange(100, dtype=torch.int32))
+    assert torch.equal(idx[:100, 0].cpu(), torch.arange(9900, 10000, dtype=torch.int32))
     assert vals[:100, 0].abs().max().item() < 1e-5
     dt = ops.pairwise_sqdist(gal[:512].contiguous(), q[:640].contiguous(), "fp32")
     assert (dt.t() - d[:640, :512]).abs().max().item() < 1e-5

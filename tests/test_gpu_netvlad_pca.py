@@ -42,7 +42,7 @@ def test_netvlad(dev, N, h, w, precision, normalize_input):
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_pca_golden(dev, tag, precision):
     g = load_golden("pca")
-    w = torch.from_numpy(g[f"weight_{tag}"]).to(dev)
+    w = torch.from_numpy(g[f"weight_{tag}"]).contiguous().to(dev)
     b = torch.from_numpy(g[f"bias_{tag}"]).to(dev)
     v = torch.from_numpy(g["data"]).to(dev)
     out = ops.pca(v, ops.cast(w, precision), b)
