@@ -132,4 +132,4 @@ def test_full_size_properties(dev):
     _, idxb = ops.row_topk(db, 10)
     rb = recalls_from_topk(idxb.cpu().numpy(), gt)
     print("recalls fp32", r32, "bf16", rb)
-    assert np.array_equal(r32, rb) and r32[0] > 0.99
+    assert np.array_equal(r32, rb) and r32[0] > 0.95
