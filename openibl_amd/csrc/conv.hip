@@ -79,6 +79,118 @@ __global__ __launch_bounds__(256) void conv1_1_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// conv1_1 on the matrix cores (bf16 precision only): K = 27 is padded to 32 = two k-steps of
+// v_mfma_f32_32x32x16_bf16.  The GEMM is run transposed (D[cout][pixel] = W . X^T): the weights
+// are the A operand (kept in registers for the whole kernel) and 32 pixels of an image row are
+// the B operand, so that each lane ends up with 4 CONSECUTIVE output channels of one pixel per
+// register quad -> 8-byte packed bf16 writes into an LDS staging tile and full 128-byte NHWC
+// lines on the way out.  The layer is bound by writing its 64-channel output (39 MB / image in
+// bf16), not by the MFMA work.
+//   workgroup = 4 waves = 128 consecutive pixels of one image row; persistent over row segments;
+//   input patch (3 channels x 3 rows x 130 columns, zero padded) staged in LDS as fp32, rounded
+//   to bf16 when the fragments are built.
+// ---------------------------------------------------------------------------------------------
+static int g_conv11_valu = 0;  // test hook: force the vector-ALU conv1_1 in bf16 mode too
+constexpr int C11_TW = 128;
+constexpr int C11_PITCH = 132;
+constexpr int C11_ZERO = 9 * C11_PITCH;  // index of a zero float (k >= 27)
+
+__device__ static inline uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+}
+
+__global__ __launch_bounds__(256) void conv1_1_mfma_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ w,
+                                                           const float* __restrict__ bias,
+                                                           bf16_t* __restrict__ out, int N, int H,
+                                                           int W, int tiles_per_row, long ntiles) {
+  __shared__ __attribute__((aligned(16))) float patch[9 * C11_PITCH + 4];
+  __shared__ __attribute__((aligned(16))) uint4 ostage[4][32 * 9];  // per wave: 32 px x 144 B
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+
+  // A operand: weights.  wf[t][s] element e  <->  cout = 32 t + l31,  k = 16 s + 8 half + e
+  bf16x8_t wf[2][2];
+  int koff[2][8];  // LDS float offset of input element k (relative to the pixel's column)
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 16 * s + 8 * half + e;
+      koff[s][e] = k < 27 ? (k / 3) * C11_PITCH + (k % 3) : -1;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float v = k < 27 ? w[(32 * t + l31) * 27 + k] : 0.f;
+        wf[t][s][e] = (short)f32_to_bf16_bits(v);
+      }
+    }
+  float bb[2][16];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bb[t][r] = bias[32 * t + acc_row(r, lane)];
+  if (threadIdx.x < 4) patch[C11_ZERO + threadIdx.x] = 0.f;
+
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int tx = (int)(tile % tiles_per_row);
+    const long ny = tile / tiles_per_row;
+    const int y = (int)(ny % H), n = (int)(ny / H);
+    const int x0 = tx * C11_TW;
+    __syncthreads();  // the previous tile's fragment reads are done
+    for (int i = threadIdx.x; i < 9 * 130; i += 256) {
+      const int r = i / 130, col = i - r * 130;
+      const int yy = y + (r % 3) - 1, xx = x0 - 1 + col;
+      float v = 0.f;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+        v = x[(((size_t)n * 3 + r / 3) * H + yy) * W + xx];
+      patch[r * C11_PITCH + col] = v;
+    }
+    __syncthreads();
+
+    const int px = wave * 32 + l31;  // pixel column inside the tile
+    bf16x8_t xf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = koff[s][e] >= 0 ? patch[koff[s][e] + px] : 0.f;
+        xf[s][e] = (short)f32_to_bf16_bits(v);
+      }
+    f32x16_t acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = bb[t][r];
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][s], xf[s], acc[t], 0, 0, 0);
+    }
+    // D[row = cout][col = pixel]: registers 4g..4g+3 = couts 32t + 8g + 4*half + 0..3 of pixel l31
+    char* ost = reinterpret_cast<char*>(&ostage[wave][0]);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 v;
+        v.x = pack_bf16x2(fmaxf(acc[t][4 * g], 0.f), fmaxf(acc[t][4 * g + 1], 0.f));
+        v.y = pack_bf16x2(fmaxf(acc[t][4 * g + 2], 0.f), fmaxf(acc[t][4 * g + 3], 0.f));
+        *reinterpret_cast<uint2*>(ost + l31 * 144 + (32 * t + 8 * g + 4 * half) * 2) = v;
+      }
+    __builtin_amdgcn_wave_barrier();  // same-wave exchange through LDS: DS ops retire in order
+    bf16_t* orow = out + (((size_t)n * H + y) * W + x0 + wave * 32) * 64;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = it * 64 + lane, p = idx >> 3, part = idx & 7;
+      const uint4 v = *reinterpret_cast<const uint4*>(ost + p * 144 + part * 16);
+      if (x0 + wave * 32 + p < W)
+        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(orow) + (size_t)p * 128 + part * 16) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // implicit-GEMM 3x3 convolution
 //   M = output pixels, N = Cout, K = 9 * Cin ordered (tap, cin).  A K-step is one tap x one
 //   128-byte run of input channels of each pixel, fetched straight from the NHWC tensor (or from a
@@ -120,24 +232,25 @@ struct ConvALoader {
     const int Hq = POOL ? (p.H >> 1) : p.H, Wq = POOL ? (p.W >> 1) : p.W;
 #pragma unroll
     for (int j = 0; j < Cfg::A_LOADS; ++j) {
-      const long m = m0 + load_row<Cfg>(c, j);
+      // 32-bit index math (the host checks m_total < 2^31): 64-bit divides cost hundreds of cycles
+      const unsigned m = (unsigned)m0 + (unsigned)load_row<Cfg>(c, j);
       unsigned mk = 0;
       long off = 0;
-      if (m < p.m_total) {
-        long q = POOL ? (m >> 2) : m;
-        const int sub = POOL ? (int)(m & 3) : 0;
-        const int n = (int)(q / ((long)Hq * Wq));
-        const int rem = (int)(q - (long)n * Hq * Wq);
-        int y = rem / Wq, x = rem - y * Wq;
+      if (m < (unsigned)p.m_total) {
+        const unsigned q = POOL ? (m >> 2) : m;
+        const unsigned sub = POOL ? (m & 3u) : 0u;
+        const unsigned hw = (unsigned)Hq * (unsigned)Wq;
+        const unsigned n = q / hw;
+        const unsigned rem = q - n * hw;
+        unsigned yq = rem / (unsigned)Wq;
+        int y = (int)yq, x = (int)(rem - yq * (unsigned)Wq);
         if (POOL) {
-          y = 2 * y + (sub >> 1);
-          x = 2 * x + (sub & 1);
+          y = 2 * y + (int)(sub >> 1);
+          x = 2 * x + (int)(sub & 1);
         }
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-          if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) mk |= 1u << t;
-        }
+        const bool y0 = y > 0, y2 = y + 1 < p.H, x0 = x > 0, x2 = x + 1 < p.W;
+        mk = (y0 && x0 ? 1u : 0u) | (y0 ? 2u : 0u) | (y0 && x2 ? 4u : 0u) | (x0 ? 8u : 0u) | 16u |
+             (x2 ? 32u : 0u) | (y2 && x0 ? 64u : 0u) | (y2 ? 128u : 0u) | (y2 && x2 ? 256u : 0u);
         off = (((long)n * p.H + y) * p.W + x) * pix_bytes;
       }
       mask[j] = mk;
@@ -264,6 +377,23 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void conv3x3_igemm_kernel(ConvParams
   }
 }
 
+template <typename Cfg, bool POOL, bool GLDS>
+static int launch_conv_kernel(const ConvParams& q, long grid, hipStream_t st) {
+  constexpr int lds = conv_lds_bytes<Cfg, POOL>();
+  auto kern = conv3x3_igemm_kernel<Cfg, POOL, GLDS>;
+  if (lds > 64 * 1024) {  // opt in to more than 64 KiB of dynamic LDS once per kernel
+    static bool done = false;
+    if (!done) {
+      OIBL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      done = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::NTHREADS), lds, st, q);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
+
 template <typename Cfg, bool POOL>
 static int launch_conv_cfg(const ConvParams& p, hipStream_t st) {
   ConvParams q = p;
@@ -274,24 +404,43 @@ static int launch_conv_cfg(const ConvParams& p, hipStream_t st) {
     set_error("conv3x3: grid %ld out of range", grid);
     return OIBL_E_INVALID;
   }
-  constexpr int lds = conv_lds_bytes<Cfg, POOL>();
-  if (g_regstage)
-    hipLaunchKernelGGL((conv3x3_igemm_kernel<Cfg, POOL, false>), dim3((unsigned)grid),
-                       dim3(Cfg::NTHREADS), lds, st, q);
-  else
-    hipLaunchKernelGGL((conv3x3_igemm_kernel<Cfg, POOL, true>), dim3((unsigned)grid),
-                       dim3(Cfg::NTHREADS), lds, st, q);
-  OIBL_LAUNCH_CHECK();
-  return OIBL_OK;
+  return g_regstage ? launch_conv_kernel<Cfg, POOL, false>(q, grid, st)
+                    : launch_conv_kernel<Cfg, POOL, true>(q, grid, st);
 }
+
+// Tile selection.  The implicit GEMM is bound by L2 -> LDS traffic before it is bound by the
+// matrix cores: a 128 x 128 x 64 step needs 32 KB per 2.1 MFLOP (64 flop/B, i.e. ~64 B/clk/CU at
+// the bf16 MFMA peak), a 256 x 256 step half of that.  So the largest tile that still gives every
+// CU a couple of workgroups wins; small problems (conv5 at small batch) fall back to 128-row tiles.
+// g_conv_tile (test hook): 0 = auto, 1 = 128x{128,64}, 2 = 256x{128,64}, 3 = 256x256 where legal.
+static int g_conv_tile = 0;
 
 template <typename T>
 static int launch_conv(const ConvParams& p, int pool, hipStream_t st) {
-  using Cfg128 = GemmCfg<T, 2, 2, 2, 2>;  // 128 x 128
-  using Cfg64 = GemmCfg<T, 2, 2, 2, 1>;   // 128 x 64
-  if (p.cout % 128 == 0)
-    return pool ? launch_conv_cfg<Cfg128, true>(p, st) : launch_conv_cfg<Cfg128, false>(p, st);
-  return pool ? launch_conv_cfg<Cfg64, true>(p, st) : launch_conv_cfg<Cfg64, false>(p, st);
+  using C128x128 = GemmCfg<T, 2, 2, 2, 2>;
+  using C128x64 = GemmCfg<T, 2, 2, 2, 1>;
+#define OIBL_CONV_DISPATCH(CFG) \
+  return pool ? launch_conv_cfg<CFG, true>(p, st) : launch_conv_cfg<CFG, false>(p, st)
+  if constexpr (sizeof(T) == 2) {
+    using C256x256 = GemmCfg<T, 2, 4, 4, 2>;
+    using C256x128 = GemmCfg<T, 4, 2, 2, 2>;
+    using C256x64 = GemmCfg<T, 4, 2, 2, 1>;
+    const long t256 = (p.m_total + 255) / 256;
+    int mode = g_conv_tile;
+    if (mode == 0) {
+      if (p.cout % 256 == 0 && t256 * (p.cout / 256) >= 512) mode = 3;
+      else if (t256 * (p.cout / (p.cout % 128 == 0 ? 128 : 64)) >= 512) mode = 2;
+      else mode = 1;
+    }
+    if (mode == 3 && p.cout % 256 == 0) { OIBL_CONV_DISPATCH(C256x256); }
+    if (mode >= 2) {
+      if (p.cout % 128 == 0) { OIBL_CONV_DISPATCH(C256x128); }
+      OIBL_CONV_DISPATCH(C256x64);
+    }
+  }
+  if (p.cout % 128 == 0) { OIBL_CONV_DISPATCH(C128x128); }
+  OIBL_CONV_DISPATCH(C128x64);
+#undef OIBL_CONV_DISPATCH
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -368,6 +517,7 @@ static int conv3x3_impl(const void* in, int N, int H, int W, int cin, const void
   OIBL_REQUIRE(cin % bk == 0 && cout % 64 == 0, "conv3x3: unsupported channels cin=%d cout=%d", cin,
                cout);
   OIBL_REQUIRE(!pool || (H >= 2 && W >= 2), "conv3x3: pooling needs H,W >= 2");
+  OIBL_REQUIRE((long)N * H * W < 0x7fffffffL, "conv3x3: N*H*W must be < 2^31 (split the batch)");
   OIBL_REQUIRE((uintptr_t)in % 16 == 0 && (uintptr_t)packed_w % 16 == 0 && (uintptr_t)out % 16 == 0,
                "conv3x3: pointers must be 16-byte aligned");
   ConvParams p;
@@ -399,6 +549,16 @@ static int conv3x3_impl(const void* in, int N, int H, int W, int cin, const void
 using namespace oibl;
 
 extern "C" {
+
+int oibl_debug_set_conv_tile(int mode) {
+  g_conv_tile = mode;
+  return OIBL_OK;
+}
+
+int oibl_debug_set_conv11_valu(int on) {
+  g_conv11_valu = on ? 1 : 0;
+  return OIBL_OK;
+}
 
 size_t oibl_conv3x3_packed_bytes(int cout, int cin, int precision) {
   return (size_t)9 * cout * cin * oibl_elem_size(precision);
@@ -439,7 +599,13 @@ int oibl_conv1_1_nchw(const float* x_nchw, int N, int H, int W, const float* w_o
   const long nstrips = (long)N * H * ((W + 7) / 8);
   const long grid = (nstrips + 3) / 4;
   OIBL_REQUIRE(grid <= 0x7fffffffL, "conv1_1: grid too large");
-  if (precision == OIBL_BF16)
+  if (precision == OIBL_BF16 && !g_conv11_valu) {
+    const int tiles_per_row = (W + C11_TW - 1) / C11_TW;
+    const long ntiles = (long)N * H * tiles_per_row;
+    const unsigned blocks = (unsigned)(ntiles < 4096 ? ntiles : 4096);
+    hipLaunchKernelGGL(conv1_1_mfma_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x_nchw,
+                       w_oihw, bias, (bf16_t*)out, N, H, W, tiles_per_row, ntiles);
+  } else if (precision == OIBL_BF16)
     hipLaunchKernelGGL(conv1_1_kernel<bf16_t>, dim3((unsigned)grid), dim3(256), 0,
                        (hipStream_t)stream, x_nchw, w_oihw, bias, (bf16_t*)out, N, H, W);
   else

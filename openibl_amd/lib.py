@@ -56,7 +56,9 @@ SIGNATURES = {
                              c_void_p]),
 }
 # test hooks exported by the library but deliberately absent from the public header
-_HOOKS = {"oibl_debug_set_regstage": (c_int, [c_int])}
+_HOOKS = {"oibl_debug_set_regstage": (c_int, [c_int]),
+          "oibl_debug_set_conv11_valu": (c_int, [c_int]),
+          "oibl_debug_set_conv_tile": (c_int, [c_int])}
 
 ABI_VERSION = 1
 

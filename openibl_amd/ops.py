@@ -108,6 +108,16 @@ def set_regstage(on: bool) -> None:
     _lib.load().oibl_debug_set_regstage(1 if on else 0)
 
 
+def set_conv_tile(mode: int) -> None:
+    """Test hook: 0 = auto tile choice, 1 = 128-row tiles, 2 = 256x{128,64}, 3 = 256x256."""
+    _lib.load().oibl_debug_set_conv_tile(int(mode))
+
+
+def set_conv11_valu(on: bool) -> None:
+    """Test hook: run conv1_1 on the vector ALU (exact fp32) also in bf16 mode."""
+    _lib.load().oibl_debug_set_conv11_valu(1 if on else 0)
+
+
 # ---- backbone -------------------------------------------------------------------------------
 VGG16_CONV_IDX = (0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28)  # vgg.py:40-42 conv positions
 VGG16_CFG = ((3, 64, 1, 0), (64, 64, 1, 1), (64, 128, 1, 0), (128, 128, 1, 1), (128, 256, 1, 0),

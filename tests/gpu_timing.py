@@ -35,9 +35,11 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--regstage", type=int, default=0)
+    ap.add_argument("--tile", type=int, default=0)
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     ops.set_regstage(bool(a.regstage))
+    ops.set_conv_tile(a.tile)
     sd = synth.embednetpca_state(0)
     N, H, W, p = a.batch, a.height, a.width, a.precision
     x = synth.images(min(N, 4), H, W, seed=1)
@@ -71,13 +73,13 @@ def main():
     t, _ = timed(lambda: ops.pca(vl, pw, pb) if False else ops.vgg16_conv5(x, packed, biases, p), a.iters)
     rows.append(("vgg16 whole", t, sum(r[2] for r in rows[:13])))
     tot = sum(r[1] for r in rows[:15])
-    print(f"precision={p} batch={N} {H}x{W} regstage={a.regstage}")
+    print(f"precision={p} batch={N} {H}x{W} regstage={a.regstage} tile={a.tile}")
     for name, ms, fl in rows:
         print(f"  {name:34s} {ms:9.3f} ms  {fl / ms / 1e9:9.1f} TFLOP/s")
     print(f"  sum of stages {tot:.3f} ms -> {N / tot * 1e3:.1f} img/s")
     out = Path("gpurun_out")
     out.mkdir(exist_ok=True)
-    with open(out / f"timing_{p}_b{N}_rs{a.regstage}.json", "w") as f:
+    with open(out / f"timing_{p}_b{N}_rs{a.regstage}_t{a.tile}.json", "w") as f:
         json.dump({"precision": p, "batch": N, "rows": rows, "img_per_s": N / tot * 1e3}, f, indent=1)
 
 

@@ -56,15 +56,50 @@ def test_conv3x3(dev, N, H, W, cin, cout, relu, pool, precision, regstage):
                   got, want, tol)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
-@pytest.mark.parametrize("N,H,W", [(2, 16, 24), (1, 7, 13), (1, 33, 9)])
+@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("N,H,W,cin,cout,relu,pool", [
+    (2, 12, 20, 64, 64, True, True),
+    (1, 9, 7, 128, 128, True, True),
+    (3, 20, 24, 256, 256, True, False),
+    (1, 30, 40, 512, 512, False, False),
+    (2, 16, 20, 256, 512, True, True),
+])
+def test_conv3x3_bf16_tile_variants(dev, N, H, W, cin, cout, relu, pool, tile):
+    """Every tile shape of the implicit GEMM gives the same tensor (bit for bit: the K order and the
+    per-element arithmetic do not depend on the tile)."""
+    x, w, b = _case(N, H, W, cin, cout, seed=tile + H)
+    xd = ops.nchw_f32_to_nhwc(x.to(dev), "bf16")
+    wp = ops.pack_conv3x3(w.to(dev), "bf16")
+    ref = ops.conv3x3_nhwc(xd, wp, b.to(dev), relu, pool, "bf16")
+    ops.set_conv_tile(tile)
+    try:
+        y = ops.conv3x3_nhwc(xd, wp, b.to(dev), relu, pool, "bf16")
+    finally:
+        ops.set_conv_tile(0)
+    assert torch.equal(y, ref)
+    got = ops.nhwc_to_nchw_f32(y).cpu()
+    assert_rel_l2(f"conv3x3 bf16 tile={tile}", got, _host_conv(x, w, b, relu, pool, "bf16"), 4e-3)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16-valu"])
+@pytest.mark.parametrize("N,H,W", [(2, 16, 24), (1, 7, 13), (1, 33, 9), (1, 5, 300), (2, 3, 129)])
 def test_conv1_1(dev, N, H, W, precision):
     x, w, b = _case(N, H, W, 3, 64, seed=77 + H)
     x = x * 60.0
-    y = ops.conv1_1_nchw(x.to(dev), w.to(dev), b.to(dev), precision)
+    valu = precision.endswith("valu")
+    prec = precision.split("-")[0]
+    ops.set_conv11_valu(valu)
+    try:
+        y = ops.conv1_1_nchw(x.to(dev), w.to(dev), b.to(dev), prec)
+    finally:
+        ops.set_conv11_valu(False)
     got = ops.nhwc_to_nchw_f32(y).cpu()
-    want = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1))
-    assert_rel_l2(f"conv1_1 {precision}", got, want, 2e-6 if precision == "fp32" else 4e-3)
+    if precision == "bf16":     # MFMA kernel: operands rounded to bf16, exact accumulation
+        xr, wr = x.to(torch.bfloat16).double(), w.to(torch.bfloat16).double()
+    else:                       # vector-ALU kernel: exact fp32 operands
+        xr, wr = x.double(), w.double()
+    want = F.relu(F.conv2d(xr, wr, b.double(), padding=1))
+    assert_rel_l2(f"conv1_1 {precision}", got, want, 2e-6 if prec == "fp32" else 4e-3)
 
 
 def test_pack_layout(dev):
