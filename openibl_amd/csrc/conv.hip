@@ -211,6 +211,8 @@ struct ConvParams {
   long out_rows;  // rows of the output tensor ( = m_total or m_total / 4)
   int tiles_n;
   int relu;
+  int ablate;  // timing experiments only (wrong results): 1 = A loads only at tap 0, 2 = B loads
+               // only at the first step, 3 = both
 };
 
 template <typename Cfg, bool POOL>
@@ -219,14 +221,15 @@ struct ConvALoader {
   unsigned mask[Cfg::A_LOADS];
   const char* zero;
   long tap_off;
-  int tap, cc, cchunks, W;
+  int tap, cc, cchunks, W, ablate;
   long pix_bytes;
 
-  __device__ inline void init(const WaveCoord& c, const ConvParams& p, long m0) {
+  __device__ inline void init(const WaveCoord& c, const ConvParams& p, long m0, int tap0) {
     using T = typename Cfg::T;
     const int piece = load_piece_bytes<Cfg>(c);
     pix_bytes = (long)p.cin * sizeof(T);
     W = p.W;
+    ablate = p.ablate;
     cchunks = p.cin / Cfg::BK;
     zero = reinterpret_cast<const char*>(p.zero) + (c.lane & 7) * 16;
     const int Hq = POOL ? (p.H >> 1) : p.H, Wq = POOL ? (p.W >> 1) : p.W;
@@ -256,17 +259,18 @@ struct ConvALoader {
       mask[j] = mk;
       base[j] = reinterpret_cast<const char*>(p.in) + off + piece;
     }
-    tap = 0;
+    tap = tap0;
     cc = 0;
-    tap_off = (long)(-W - 1) * pix_bytes;
+    tap_off = (long)((tap / 3 - 1) * W + (tap % 3 - 1)) * pix_bytes;
   }
   __device__ inline const char* src(int j) const {
     return ((mask[j] >> tap) & 1u) ? base[j] + tap_off + cc * 128 : zero;
   }
+  __device__ inline bool active() const { return !((ablate & 1) && tap != 0); }
   __device__ inline void next() {
     if (++cc == cchunks) {
       cc = 0;
-      ++tap;
+      if (++tap == 9) tap = 0;
       tap_off = (long)((tap / 3 - 1) * W + (tap % 3 - 1)) * pix_bytes;
     }
   }
@@ -274,30 +278,34 @@ struct ConvALoader {
 
 template <typename Cfg>
 struct ConvBLoader {
-  const char* p[Cfg::B_LOADS];
-  long wrap_bytes;
-  int cc, cchunks;
-  __device__ inline void init(const WaveCoord& c, const ConvParams& prm, long n0) {
+  const char* p0[Cfg::B_LOADS];  // row pointers at (tap 0, channel chunk 0)
+  long tap_stride, off;
+  int tap, cc, cchunks, ablate, step;
+  __device__ inline bool active() const { return !((ablate & 2) && step != 0); }
+  __device__ inline void init(const WaveCoord& c, const ConvParams& prm, long n0, int tap0) {
     using T = typename Cfg::T;
     const int piece = load_piece_bytes<Cfg>(c);
     cchunks = prm.cin / Cfg::BK;
     cc = 0;
-    wrap_bytes = (long)prm.cin * sizeof(T) * (prm.cout - 1);
+    tap = tap0;
+    ablate = prm.ablate;
+    step = 0;
+    tap_stride = (long)prm.cin * sizeof(T) * prm.cout;
+    off = tap * tap_stride;
 #pragma unroll
     for (int j = 0; j < Cfg::B_LOADS; ++j) {
       const long n = n0 + load_row<Cfg>(c, j);
-      p[j] = reinterpret_cast<const char*>(prm.w) + n * prm.cin * (long)sizeof(T) + piece;
+      p0[j] = reinterpret_cast<const char*>(prm.w) + n * prm.cin * (long)sizeof(T) + piece;
     }
   }
-  __device__ inline const char* src(int j) const { return p[j]; }
+  __device__ inline const char* src(int j) const { return p0[j] + off; }
   __device__ inline void next() {
-    long d = 128;
+    ++step;
     if (++cc == cchunks) {
       cc = 0;
-      d += wrap_bytes;
+      if (++tap == 9) tap = 0;
     }
-#pragma unroll
-    for (int j = 0; j < Cfg::B_LOADS; ++j) p[j] += d;
+    off = tap * tap_stride + cc * 128;
   }
 };
 
@@ -320,8 +328,11 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void conv3x3_igemm_kernel(ConvParams
 
   ConvALoader<Cfg, POOL> la;
   ConvBLoader<Cfg> lb;
-  la.init(c, p, m0);
-  lb.init(c, p, n0);
+  // ablate bit 2 (experiment): start the tap loop at a per-tile offset so that concurrently
+  // running workgroups do not all stream the same weight lines at the same time
+  const int tap0 = (p.ablate & 4) ? (tm % 9) : 0;
+  la.init(c, p, m0, tap0);
+  lb.init(c, p, n0, tap0);
 
   f32x16_t acc[TM][TN];
 #pragma unroll
@@ -414,6 +425,7 @@ static int launch_conv_cfg(const ConvParams& p, hipStream_t st) {
 // CU a couple of workgroups wins; small problems (conv5 at small batch) fall back to 128-row tiles.
 // g_conv_tile (test hook): 0 = auto, 1 = 128x{128,64}, 2 = 256x{128,64}, 3 = 256x256 where legal.
 static int g_conv_tile = 0;
+static int g_conv_ablate = 0;
 
 template <typename T>
 static int launch_conv(const ConvParams& p, int pool, hipStream_t st) {
@@ -441,6 +453,288 @@ static int launch_conv(const ConvParams& p, int pool, hipStream_t st) {
   if (p.cout % 128 == 0) { OIBL_CONV_DISPATCH(C128x128); }
   OIBL_CONV_DISPATCH(C128x64);
 #undef OIBL_CONV_DISPATCH
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cin = 64 convolutions (conv1_2, conv2_1) — "resident weights + LDS halo" kernel, bf16.
+// With K = 9 * 64 the generic implicit GEMM has only nine K-steps per tile: its cost is the
+// per-tile prologue / epilogue and the L2 -> LDS traffic of re-fetching every input pixel once per
+// tap, not the matrix cores.  Here a persistent workgroup
+//   * keeps ALL weights of its 64-output-channel slice in LDS (9 taps x 64 x 64 bf16 = 72 KiB,
+//     fetched once),
+//   * stages the (8+2) x (32+2) pixel halo of an 8 x 32 output tile ONCE (42.5 KiB instead of
+//     9 x 32 KiB), double-buffered so the next tile's halo streams in (global_load_lds) while the
+//     current one is multiplied,
+//   * runs the 9 taps x 4 k-steps = 144 MFMAs per wave straight out of LDS with no barrier,
+//   * reuses the consumed halo buffer as the staging area of the coalesced NHWC store.
+// LDS: 72 KiB + 2 x 43 KiB = 158 KiB of the CU's 160 KiB -> one workgroup (4 waves) per CU.
+// The halo image is XOR-swizzled by f(hy, hx) = ((hx >> 1) & 7) ^ ((hy & 1) << 2) (halo rows are
+// 34 x 128 B = 17 bank rows, so banks depend on hx only; the hy term separates the two image rows
+// a pooled quad spans): every ds_read_b128 lane group is conflict-free for all nine taps in both
+// the linear and the quad-major (pooling) pixel order (checked exhaustively).
+// ---------------------------------------------------------------------------------------------
+constexpr int C64_HW = 34;                         // halo width  (32 + 2)
+constexpr int C64_HALO_ROWS = 344;                 // 10 x 34 = 340 halo pixels, padded to 43 x 8
+constexpr int C64_HALO_BYTES = C64_HALO_ROWS * 128;
+constexpr int C64_W_BYTES = 9 * 64 * 128;
+constexpr int C64_LDS_BYTES = C64_W_BYTES + 2 * C64_HALO_BYTES;
+constexpr int C64_HALO_LOADS = 11;                 // ceil(43 wave-instructions / 4 waves)
+constexpr int C64_WAVE_REGION = 10880;             // per-wave epilogue staging inside a halo buffer
+static int g_conv_c64 = 1;
+
+struct C64Params {
+  const char* in;
+  const char* w;
+  const float* bias;
+  char* out;
+  const char* zero;
+  int N, H, W, cout, relu;
+  int tiles_x, tiles_y;
+  int ntiles;
+  unsigned long long* prof;  // optional (test hook): per-phase shader-clock totals of block 0 wave 0
+};
+static unsigned long long* g_prof_buf = nullptr;
+
+__device__ static inline int c64_swz(int hy, int hx) { return ((hx >> 1) & 7) ^ ((hy & 1) << 2); }
+
+template <bool POOL>
+__global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(C64Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const wl = smem;
+  char* const hb = smem + C64_W_BYTES;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int co0 = blockIdx.y * 64;
+
+  // weights of this 64-channel slice -> LDS rows r = tap * 64 + c (same swizzle as the GEMM core)
+  {
+    const int piece = ((lane & 7) ^ (4 * (wave & 1) + (lane >> 4))) * 16;
+#pragma unroll
+    for (int j = 0; j < 18; ++j) {
+      const int q = j * 4 + wave;
+      const int r = q * 8 + (lane >> 3);
+      const int tap = r >> 6, c = r & 63;
+      glds16(p.w + ((long)(tap * p.cout + co0 + c) * 64) * 2 + piece, wl + q * 1024);
+    }
+  }
+  // halo loader: instruction j of this wave fills halo pixels r = (4j + wave) * 8 + (lane >> 3)
+  int h_rel[C64_HALO_LOADS];    // hy << 8 | hx   (hy >= 10: padding row, always zero)
+  int h_piece[C64_HALO_LOADS];
+#pragma unroll
+  for (int j = 0; j < C64_HALO_LOADS; ++j) {
+    const int r = (j * 4 + wave) * 8 + (lane >> 3);
+    const int hy = r / C64_HW, hx = r - hy * C64_HW;
+    h_rel[j] = (hy << 8) | hx;
+    h_piece[j] = ((lane & 7) ^ c64_swz(hy, hx)) * 16;
+  }
+  const char* const zsrc = p.zero + (lane & 7) * 16;
+  const long row_bytes = (long)p.W * 128, img_bytes = (long)p.H * row_bytes;
+
+  auto issue_halo = [&](int tile, char* buf) {
+    const unsigned r2 = (unsigned)tile / (unsigned)p.tiles_x;
+    const int tx = tile - (int)r2 * p.tiles_x;
+    const int n = (int)(r2 / (unsigned)p.tiles_y), ty = (int)r2 - n * p.tiles_y;
+    const int y0 = ty * 8 - 1, x0 = tx * 32 - 1;
+    const char* base = p.in + n * img_bytes;
+#pragma unroll
+    for (int j = 0; j < C64_HALO_LOADS; ++j) {
+      const int q = j * 4 + wave;
+      if (q < C64_HALO_ROWS / 8) {  // wave-uniform
+        const int hy = h_rel[j] >> 8, hx = h_rel[j] & 255;
+        const int y = y0 + hy, x = x0 + hx;
+        const bool ok = hy < 10 && y >= 0 && y < p.H && x >= 0 && x < p.W;
+        glds16(ok ? base + y * row_bytes + (long)x * 128 + h_piece[j] : zsrc, buf + q * 1024);
+      }
+    }
+  };
+
+  // lane geometry inside the wave's 2 tile rows x 32 columns
+  int lhy[2], lhx[2];  // halo coordinates (tap 0,0) of this lane's pixel in M-tile i
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (POOL) {
+      lhy[i] = 2 * wave + ((l31 >> 1) & 1);
+      lhx[i] = 16 * i + 2 * (l31 >> 2) + (l31 & 1);
+    } else {
+      lhy[i] = 2 * wave + i;
+      lhx[i] = l31;
+    }
+  }
+  int w_off[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) w_off[kk] = l31 * 128 + (((2 * kk + half) ^ ((l31 >> 1) & 7)) << 4);
+  float bvals[2];
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) bvals[tn] = p.bias[co0 + tn * 32 + l31];
+
+  int tile = blockIdx.x;
+  if (tile < p.ntiles) issue_halo(tile, hb);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const bool prof = p.prof != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0;
+  unsigned long long pt[6] = {0, 0, 0, 0, 0, 0};
+#define C64_TICK(i)                                        \
+  if (prof) {                                              \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    pt[i] += now_ - t_prev;                                \
+    t_prev = now_;                                         \
+  }
+  for (int it = 0; tile < p.ntiles; tile += gridDim.x, ++it) {
+    unsigned long long t_prev = prof ? __builtin_amdgcn_s_memtime() : 0;
+    char* const cur = hb + (it & 1) * C64_HALO_BYTES;
+    const int nxt = tile + (int)gridDim.x;
+    if (nxt < p.ntiles) issue_halo(nxt, hb + ((it & 1) ^ 1) * C64_HALO_BYTES);
+    C64_TICK(0)
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][tn][r] = 0.f;
+
+    // 36 steps (tap-major, 4 k-steps per tap), fragment reads software-pipelined one step ahead:
+    // with one wave per SIMD nothing else hides the LDS latency.
+    bf16x8_t fa[2][2], fb[2][2];
+    auto load_step = [&](int sidx, bf16x8_t (&a)[2], bf16x8_t (&b)[2]) {
+      const int tap = sidx >> 2, kk = sidx & 3;
+      const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int hy = lhy[i] + ky, hx = lhx[i] + kx;
+        a[i] = *reinterpret_cast<const bf16x8_t*>(
+            cur + (hy * C64_HW + hx) * 128 + (((2 * kk + half) ^ c64_swz(hy, hx)) << 4));
+      }
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+        b[tn] = *reinterpret_cast<const bf16x8_t*>(wl + tap * 8192 + tn * 4096 + w_off[kk]);
+    };
+    load_step(0, fa[0], fb[0]);
+#pragma unroll
+    for (int sidx = 0; sidx < 36; ++sidx) {
+      if (sidx + 1 < 36) load_step(sidx + 1, fa[(sidx + 1) & 1], fb[(sidx + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);  // keep the next step's reads AHEAD of this step's MFMAs
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+          acc[i][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sidx & 1][i], fb[sidx & 1][tn],
+                                                               acc[i][tn], 0, 0, 0);
+    }
+    // The next tile's halo (issued before the MFMAs) has landed; every wave is done reading `cur`,
+    // which now becomes the store staging area.  Raw s_barrier + explicit counters: __syncthreads()
+    // would also wait (vmcnt(0)) for the global stores of the epilogue below, a 1-2 us bubble per
+    // tile; they are left in flight and only waited for after the next tile's MFMAs.
+    C64_TICK(1)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    C64_TICK(2)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    C64_TICK(3)
+
+    const unsigned r2 = (unsigned)tile / (unsigned)p.tiles_x;
+    const int tx = tile - (int)r2 * p.tiles_x;
+    const int n = (int)(r2 / (unsigned)p.tiles_y), ty = (int)r2 - n * p.tiles_y;
+    char* const st = cur + wave * C64_WAVE_REGION;  // wave-private: no barrier for the exchange
+    if (POOL) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float v = fmaxf(fmaxf(acc[i][tn][4 * g], acc[i][tn][4 * g + 1]),
+                            fmaxf(acc[i][tn][4 * g + 2], acc[i][tn][4 * g + 3])) + bvals[tn];
+            if (p.relu) v = fmaxf(v, 0.f);
+            const int qx = 8 * i + 2 * g + half;
+            *reinterpret_cast<uint16_t*>(st + qx * 144 + (tn * 32 + l31) * 2) = f32_to_bf16_bits(v);
+          }
+      __builtin_amdgcn_wave_barrier();
+      const int Ho = p.H >> 1, Wo = p.W >> 1;
+      const int oy = ty * 4 + wave;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int idx = k * 64 + lane, qx = idx >> 3, part = idx & 7;
+        const int ox = tx * 16 + qx;
+        const uint4 v = *reinterpret_cast<const uint4*>(st + qx * 144 + part * 16);
+        if (oy < Ho && ox < Wo)
+          *reinterpret_cast<uint4*>(p.out + (((long)n * Ho + oy) * Wo + ox) * p.cout * 2 + co0 * 2 +
+                                    part * 16) = v;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[i][tn][r] + bvals[tn];
+            if (p.relu) v = fmaxf(v, 0.f);
+            const int prow = i * 32 + acc_row(r, lane);
+            *reinterpret_cast<uint16_t*>(st + prow * 144 + (tn * 32 + l31) * 2) = f32_to_bf16_bits(v);
+          }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int idx = k * 64 + lane, prow = idx >> 3, part = idx & 7;
+        const int y = ty * 8 + 2 * wave + (prow >> 5), x = tx * 32 + (prow & 31);
+        const uint4 v = *reinterpret_cast<const uint4*>(st + prow * 144 + part * 16);
+        if (y < p.H && x < p.W)
+          *reinterpret_cast<uint4*>(p.out + (((long)n * p.H + y) * p.W + x) * p.cout * 2 + co0 * 2 +
+                                    part * 16) = v;
+      }
+    }
+    // staging reads retired before the next iteration's LDS-DMA overwrites this buffer
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    C64_TICK(4)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    C64_TICK(5)
+  }
+#undef C64_TICK
+  if (prof && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) p.prof[i] = pt[i];
+  }
+}
+
+static int launch_conv_c64(const void* in, int N, int H, int W, const void* w, const float* bias,
+                           int cout, int relu, int pool, void* out, hipStream_t st) {
+  C64Params p;
+  p.in = (const char*)in;
+  p.w = (const char*)w;
+  p.bias = bias;
+  p.out = (char*)out;
+  p.zero = (const char*)zero_line_device_ptr();
+  OIBL_REQUIRE(p.zero != nullptr, "conv3x3: zero line symbol not found");
+  p.N = N;
+  p.H = H;
+  p.W = W;
+  p.cout = cout;
+  p.relu = relu;
+  p.prof = g_prof_buf;
+  p.tiles_x = (W + 31) / 32;
+  p.tiles_y = (H + 7) / 8;
+  const long nt = (long)N * p.tiles_x * p.tiles_y;
+  OIBL_REQUIRE(nt < 0x7fffffffL, "conv3x3: too many tiles");
+  p.ntiles = (int)nt;
+  const int slices = cout / 64;
+  int gx = 256 / slices;  // one resident workgroup per CU
+  if (gx < 1) gx = 1;
+  if (gx > p.ntiles) gx = p.ntiles;
+  static bool attr_done[2] = {false, false};
+  auto kern = pool ? conv3x3_c64_kernel<true> : conv3x3_c64_kernel<false>;
+  if (!attr_done[pool ? 1 : 0]) {
+    OIBL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS_BYTES));
+    attr_done[pool ? 1 : 0] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(gx, slices), dim3(256), C64_LDS_BYTES, st, p);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -520,6 +814,8 @@ static int conv3x3_impl(const void* in, int N, int H, int W, int cin, const void
   OIBL_REQUIRE((long)N * H * W < 0x7fffffffL, "conv3x3: N*H*W must be < 2^31 (split the batch)");
   OIBL_REQUIRE((uintptr_t)in % 16 == 0 && (uintptr_t)packed_w % 16 == 0 && (uintptr_t)out % 16 == 0,
                "conv3x3: pointers must be 16-byte aligned");
+  if (precision == OIBL_BF16 && cin == 64 && g_conv_c64 && !g_regstage && !g_conv_ablate)
+    return launch_conv_c64(in, N, H, W, packed_w, bias, cout, relu, pool, out, st);
   ConvParams p;
   p.in = in;
   p.w = packed_w;
@@ -533,6 +829,7 @@ static int conv3x3_impl(const void* in, int N, int H, int W, int cin, const void
   p.cin = cin;
   p.cout = cout;
   p.relu = relu;
+  p.ablate = g_conv_ablate;
   p.tiles_n = 0;
   if (pool) {
     p.out_rows = (long)N * (H / 2) * (W / 2);
@@ -549,6 +846,21 @@ static int conv3x3_impl(const void* in, int N, int H, int W, int cin, const void
 using namespace oibl;
 
 extern "C" {
+
+int oibl_debug_set_prof_buffer(void* dev_u64x8) {
+  g_prof_buf = (unsigned long long*)dev_u64x8;
+  return OIBL_OK;
+}
+
+int oibl_debug_set_conv_c64(int on) {
+  g_conv_c64 = on ? 1 : 0;
+  return OIBL_OK;
+}
+
+int oibl_debug_set_conv_ablate(int mode) {
+  g_conv_ablate = mode;
+  return OIBL_OK;
+}
 
 int oibl_debug_set_conv_tile(int mode) {
   g_conv_tile = mode;

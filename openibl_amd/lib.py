@@ -58,7 +58,10 @@ SIGNATURES = {
 # test hooks exported by the library but deliberately absent from the public header
 _HOOKS = {"oibl_debug_set_regstage": (c_int, [c_int]),
           "oibl_debug_set_conv11_valu": (c_int, [c_int]),
-          "oibl_debug_set_conv_tile": (c_int, [c_int])}
+          "oibl_debug_set_conv_tile": (c_int, [c_int]),
+          "oibl_debug_set_conv_ablate": (c_int, [c_int]),
+          "oibl_debug_set_conv_c64": (c_int, [c_int]),
+          "oibl_debug_set_prof_buffer": (c_int, [c_void_p])}
 
 ABI_VERSION = 1
 

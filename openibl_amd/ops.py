@@ -113,6 +113,11 @@ def set_conv_tile(mode: int) -> None:
     _lib.load().oibl_debug_set_conv_tile(int(mode))
 
 
+def set_conv_c64(on: bool) -> None:
+    """Test hook: enable / disable the resident-weights kernel for Cin = 64 layers (bf16)."""
+    _lib.load().oibl_debug_set_conv_c64(1 if on else 0)
+
+
 def set_conv11_valu(on: bool) -> None:
     """Test hook: run conv1_1 on the vector ALU (exact fp32) also in bf16 mode."""
     _lib.load().oibl_debug_set_conv11_valu(1 if on else 0)

@@ -36,10 +36,15 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--regstage", type=int, default=0)
     ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--ablate", type=int, default=0)
+    ap.add_argument("--c64", type=int, default=1)
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     ops.set_regstage(bool(a.regstage))
     ops.set_conv_tile(a.tile)
+    ops.set_conv_c64(bool(a.c64))
+    from openibl_amd import lib as _l
+    _l.load().oibl_debug_set_conv_ablate(a.ablate)
     sd = synth.embednetpca_state(0)
     N, H, W, p = a.batch, a.height, a.width, a.precision
     x = synth.images(min(N, 4), H, W, seed=1)
@@ -73,7 +78,7 @@ def main():
     t, _ = timed(lambda: ops.pca(vl, pw, pb) if False else ops.vgg16_conv5(x, packed, biases, p), a.iters)
     rows.append(("vgg16 whole", t, sum(r[2] for r in rows[:13])))
     tot = sum(r[1] for r in rows[:15])
-    print(f"precision={p} batch={N} {H}x{W} regstage={a.regstage} tile={a.tile}")
+    print(f"precision={p} batch={N} {H}x{W} regstage={a.regstage} tile={a.tile} ablate={a.ablate}")
     for name, ms, fl in rows:
         print(f"  {name:34s} {ms:9.3f} ms  {fl / ms / 1e9:9.1f} TFLOP/s")
     print(f"  sum of stages {tot:.3f} ms -> {N / tot * 1e3:.1f} img/s")

@@ -81,6 +81,36 @@ def test_conv3x3_bf16_tile_variants(dev, N, H, W, cin, cout, relu, pool, tile):
     assert_rel_l2(f"conv3x3 bf16 tile={tile}", got, _host_conv(x, w, b, relu, pool, "bf16"), 4e-3)
 
 
+@pytest.mark.parametrize("N,H,W,cout,relu,pool", [
+    (1, 8, 32, 64, True, False),       # exactly one tile
+    (2, 24, 96, 64, True, True),       # several tiles, pooled (conv1_2 shape family)
+    (1, 21, 45, 64, True, True),       # ragged tiles, odd sizes: pooling floors
+    (1, 21, 45, 128, True, False),     # two output-channel slices (conv2_1 family), ragged
+    (3, 10, 70, 128, False, False),
+    (1, 60, 80, 64, False, True),
+    (2, 7, 5, 64, True, True),         # smaller than one tile
+])
+def test_conv3x3_cin64_resident_kernel(dev, N, H, W, cout, relu, pool):
+    """The resident-weights / LDS-halo kernel against the host convolution and against the generic
+    implicit-GEMM kernel (same operands, different summation order -> equal up to bf16 rounding of
+    the output)."""
+    x, w, b = _case(N, H, W, 64, cout, seed=W * 3 + cout)
+    xd = ops.nchw_f32_to_nhwc(x.to(dev), "bf16")
+    wp = ops.pack_conv3x3(w.to(dev), "bf16")
+    y = ops.conv3x3_nhwc(xd, wp, b.to(dev), relu, pool, "bf16")
+    ops.set_conv_c64(False)
+    try:
+        y_ref = ops.conv3x3_nhwc(xd, wp, b.to(dev), relu, pool, "bf16")
+    finally:
+        ops.set_conv_c64(True)
+    got = ops.nhwc_to_nchw_f32(y).cpu()
+    assert_rel_l2("c64 vs host", got, _host_conv(x, w, b, relu, pool, "bf16"), 4e-3)
+    assert_rel_l2("c64 vs igemm", got, ops.nhwc_to_nchw_f32(y_ref).cpu(), 4e-3)
+    mism = (y.float() != y_ref.float()).float().mean().item()
+    print(f"fraction of outputs differing from the igemm kernel by an ulp: {mism:.4f}")
+    assert mism < 0.05
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16-valu"])
 @pytest.mark.parametrize("N,H,W", [(2, 16, 24), (1, 7, 13), (1, 33, 9), (1, 5, 300), (2, 3, 129)])
 def test_conv1_1(dev, N, H, W, precision):
