@@ -109,7 +109,7 @@ def _gather_all(local: torch.Tensor, sync_gather: bool, rank: int, world: int) -
         if rank == 0:
             print("gathering features from rank no.{}".format(k))
         dist.broadcast(buf, k)
-        parts.append(buf.cpu())
+        parts.append(buf.to("cpu", copy=True))   # the buffer is reused for the next rank
     return torch.cat(parts)
 
 

@@ -1,0 +1,92 @@
+"""The C-ABI shared library: it builds (hipcc cross-compiles for gfx950 without a GPU), loads, and
+exports exactly the entry points include/openibl_amd.h declares.  No compute call is made here —
+only argument validation, which returns before any HIP call."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+HEADER = ROOT / "include" / "openibl_amd.h"
+
+
+def declared_functions():
+    text = re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
+    return sorted(set(re.findall(r"\b(oibl_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_builds_and_loads():
+    from openibl_amd import build, lib
+    path = build.build(verbose=False)
+    assert path.exists()
+    h = lib.load()
+    assert h.oibl_abi_version() == lib.ABI_VERSION
+    assert h.oibl_target_arch() == b"gfx950"
+    assert h.oibl_elem_size(0) == 2 and h.oibl_elem_size(1) == 4 and h.oibl_elem_size(7) == 0
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    from openibl_amd import lib
+    names = declared_functions()
+    assert len(names) >= 25
+    raw = ctypes.CDLL(str(lib.lib_path()))
+    for n in names:
+        assert hasattr(raw, n), f"{n} is declared in the header but not exported"
+    assert sorted(lib.SIGNATURES) == names, "lib.SIGNATURES and the header disagree"
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary is C: the header must compile as C with no HIP / C++ / torch includes."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "t.c"
+    src.write_text('#include "openibl_amd.h"\nint main(void) { return OIBL_OK; }\n')
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-I", str(HEADER.parent), "-c", str(src),
+                    "-o", str(tmp_path / "t.o")], check=True)
+
+
+def test_argument_validation_reports_errors():
+    from openibl_amd import lib
+    h = lib.load()
+    rc = h.oibl_pca_forward(None, 1, 64, None, None, 128, 0, 1, None, None, 0, None)
+    assert rc == -1 and b"null" in h.oibl_last_error()
+    rc = h.oibl_conv3x3_nhwc(None, 1, 8, 8, 64, None, None, 64, 1, 0, 0, None, None)
+    assert rc == -1
+    rc = h.oibl_row_topk(None, None, 1, 1, 1, 10, 0, None, None, None)
+    assert rc == -1
+    with pytest.raises(lib.OpenIBLAmdError):
+        lib.check(rc, "row_topk")
+    assert h.oibl_vgg16_workspace_bytes(1, 8, 8, 0) == 0           # image too small
+    assert h.oibl_vgg16_workspace_bytes(32, 480, 640, 0) >= 2 * 32 * 480 * 640 * 64
+
+
+def test_product_has_no_cpu_fallback():
+    """Forward on a CPU tensor fails loudly instead of silently computing somewhere else."""
+    import torch
+    import hubconf
+    from openibl_amd.lib import OpenIBLAmdError
+    m = hubconf.vgg16_netvlad().eval()
+    with pytest.raises((OpenIBLAmdError, RuntimeError)):
+        m(torch.zeros(1, 3, 32, 32))
+
+
+def test_oracle_is_not_imported_by_the_product():
+    import ast
+    bad = []
+    for pkg in ("openibl_amd", "ibl"):
+        for f in (ROOT / pkg).rglob("*.py"):
+            tree = ast.parse(f.read_text())
+            for node in ast.walk(tree):
+                mods = []
+                if isinstance(node, ast.Import):
+                    mods = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom) and node.module:
+                    mods = [node.module]
+                if any(m == "oracle" or m.startswith("oracle.") for m in mods):
+                    bad.append(str(f))
+    hub = ast.parse((ROOT / "hubconf.py").read_text())
+    assert not bad, bad
