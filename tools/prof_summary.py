@@ -1,0 +1,102 @@
+#!/usr/bin/env python
+"""Condense one tests/run_gpu_round.sh output directory (gpurun_out/<tag>/) into the tracked
+summaries under profiles/:  <tag>_bench.json, <tag>_kernel_stats.md, <tag>_hbm_traffic.md,
+<tag>_timing.txt.
+
+HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are in
+KiB and collected in separate --pmc passes; on gfx950 FETCH_SIZE reports half of the bytes of a
+wide coalesced read, so it is doubled ("corrected" column).
+
+    python tools/prof_summary.py gpurun_out/r01_b [--tag r01_b]
+"""
+import argparse
+import csv
+import re
+import shutil
+from collections import defaultdict
+from pathlib import Path
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = name.replace("oibl::", "")
+    return name if len(name) <= 110 else name[:107] + "..."
+
+
+def kernel_stats(path):
+    rows = list(csv.DictReader(open(path)))
+    out = ["| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
+    for r in rows[:24]:
+        out.append(f"| `{short(r['Name'])}` | {r['Calls']} | {int(r['TotalDurationNs']) / 1e6:.3f} | "
+                   f"{float(r['AverageNs']) / 1e3:.1f} | {int(r['MinNs']) / 1e3:.1f} | "
+                   f"{int(r['MaxNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
+    return out
+
+
+def counter_avg(path, counter):
+    acc = defaultdict(lambda: [0, 0.0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        a = acc[r["Kernel_Name"]]
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+        a[2] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    return acc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("dir")
+    ap.add_argument("--tag", default=None)
+    ap.add_argument("--note", default="")
+    a = ap.parse_args()
+    d = Path(a.dir)
+    tag = a.tag or d.name
+    prof = Path(__file__).resolve().parent.parent / "profiles"
+    prof.mkdir(exist_ok=True)
+    if (d / "bench.json").exists():
+        shutil.copy(d / "bench.json", prof / f"{tag}_bench.json")
+    with open(prof / f"{tag}_timing.txt", "w") as f:
+        for n in ("gpu.txt", "timing_bf16.log", "timing_fp32.log", "pcie.log", "convbench.log"):
+            if (d / n).exists():
+                f.write(f"==== {n}\n" + (d / n).read_text() + "\n")
+        if (d / "pytest_gpu.log").exists():
+            f.write("==== pytest -m gpu (tail)\n"
+                    + "\n".join((d / "pytest_gpu.log").read_text().splitlines()[-4:]) + "\n")
+        if (d / "smoke.log").exists():
+            f.write("==== smoke\n" + "\n".join((d / "smoke.log").read_text().splitlines()[-2:]) + "\n")
+    for sub, title in (
+            ("prof_stats", "python bench.py --steps 5 --warmup 2 --skip-matching --skip-cpu-baseline"),
+            ("prof_match", "python bench.py --steps 2 --warmup 1 --skip-cpu-baseline (with matching)")):
+        p = d / sub / "bench_kernel_stats.csv"
+        if p.exists():
+            lines = [f"# {tag}: rocprofv3 --kernel-trace --stats -- {title}", "", a.note, ""] + kernel_stats(p)
+            name = f"{tag}_kernel_stats.md" if sub == "prof_stats" else f"{tag}_kernel_stats_matching.md"
+            (prof / name).write_text("\n".join(lines) + "\n")
+    fp = d / "prof_fetch" / "bench_counter_collection.csv"
+    wp = d / "prof_write" / "bench_counter_collection.csv"
+    if fp.exists() and wp.exists():
+        fe, wr = counter_avg(fp, "FETCH_SIZE"), counter_avg(wp, "WRITE_SIZE")
+        lines = [f"# {tag}: HBM traffic per launch (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)",
+                 "",
+                 "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of a wide coalesced read); "
+                 "MB = 1e6 bytes; GB/s over the kernel's own duration in the FETCH pass.", "",
+                 "| kernel | launches | fetch MB (raw) | fetch MB (corrected) | write MB | avg us | "
+                 "corrected (fetch+write) GB/s |",
+                 "|---|---|---|---|---|---|---|"]
+        for k, (n, v, t) in sorted(fe.items(), key=lambda kv: -kv[1][2]):
+            if n == 0 or "at::native" in k or "rocclr" in k:
+                continue
+            f_raw = v / n * 1024 / 1e6
+            w = wr.get(k, [1, 0.0, 1])
+            w_mb = w[1] / max(w[0], 1) * 1024 / 1e6
+            us = t / n / 1e3
+            lines.append(f"| `{short(k)}` | {n} | {f_raw:.1f} | {2 * f_raw:.1f} | {w_mb:.1f} | {us:.1f} | "
+                         f"{(2 * f_raw + w_mb) / us * 1e3:.0f} |")
+        (prof / f"{tag}_hbm_traffic.md").write_text("\n".join(lines) + "\n")
+    print("wrote", sorted(p.name for p in prof.glob(f"{tag}_*")))
+
+
+if __name__ == "__main__":
+    main()
