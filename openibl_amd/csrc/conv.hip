@@ -1,6 +1,7 @@
 // VGG16 conv1_1..conv5_3 on gfx950: NHWC activations, 3x3 convolutions as implicit-GEMM on the
 // shared MFMA core (gemm_core.h), bias + ReLU + 2x2 max-pool fused into the epilogue.
 // Reference behaviour: ibl/models/vgg.py:40-42 (layer list), :61-70 (forward).
+#include "conv_ring.h"
 #include "gemm_core.h"
 
 namespace oibl {
@@ -419,12 +420,54 @@ static int launch_conv_cfg(const ConvParams& p, hipStream_t st) {
                     : launch_conv_kernel<Cfg, POOL, true>(q, grid, st);
 }
 
+// ring-schedule kernel (conv_ring.h): bf16, Cin % 128 == 0, Cout % 256 == 0
+template <bool POOL>
+static int launch_conv_ring(const ConvParams& p, hipStream_t st) {
+  RingParams q;
+  q.in = p.in;
+  q.w = p.w;
+  q.bias = p.bias;
+  q.out = p.out;
+  q.in_bytes = (unsigned)((size_t)p.N * p.H * p.W * p.cin * 2);
+  q.w_bytes = (unsigned)((size_t)9 * p.cout * p.cin * 2);
+  q.N = p.N;
+  q.H = p.H;
+  q.W = p.W;
+  q.cin = p.cin;
+  q.cout = p.cout;
+  q.m_total = (int)p.m_total;
+  q.out_rows = (int)p.out_rows;
+  q.tiles_n = p.cout / RG_BN;
+  q.relu = p.relu;
+  const long tiles_m = (p.m_total + RG_BM - 1) / RG_BM;
+  const long grid = tiles_m * q.tiles_n;
+  constexpr int lds = ring_lds_bytes<POOL>();
+  auto kern = conv3x3_ring_kernel<POOL>;
+  static bool done = false;
+  if (!done) {
+    OIBL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, q);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
+
+static bool ring_eligible(const ConvParams& p) {
+  return p.cin % 128 == 0 && p.cout % RG_BN == 0 &&
+         (size_t)p.N * p.H * p.W * p.cin * 2 < (size_t)0xE0000000u && p.m_total < 0x7fffff00L;
+}
+
 // Tile selection.  The implicit GEMM is bound by L2 -> LDS traffic before it is bound by the
 // matrix cores: a 128 x 128 x 64 step needs 32 KB per 2.1 MFLOP (64 flop/B, i.e. ~64 B/clk/CU at
 // the bf16 MFMA peak), a 256 x 256 step half of that.  So the largest tile that still gives every
 // CU a couple of workgroups wins; small problems (conv5 at small batch) fall back to 128-row tiles.
-// g_conv_tile (test hook): 0 = auto, 1 = 128x{128,64}, 2 = 256x{128,64}, 3 = 256x256 where legal.
+// g_conv_tile (test hook): 0 = auto, 1 = 128x{128,64}, 2 = 256x{128,64}, 3 = 256x256 where legal,
+// 4 = ring schedule where legal.  Auto prefers the ring kernel whenever its 256x256 tiling gives
+// every CU at least one workgroup.
 static int g_conv_tile = 0;
+static long g_ring_min_tiles = 256;
 static int g_conv_ablate = 0;
 
 template <typename T>
@@ -439,6 +482,10 @@ static int launch_conv(const ConvParams& p, int pool, hipStream_t st) {
     using C256x64 = GemmCfg<T, 4, 2, 2, 1>;
     const long t256 = (p.m_total + 255) / 256;
     int mode = g_conv_tile;
+    if ((mode == 4 || (mode == 0 && t256 * (p.cout / 256) >= g_ring_min_tiles)) && ring_eligible(p) &&
+        !g_regstage && !p.ablate)
+      return pool ? launch_conv_ring<true>(p, st) : launch_conv_ring<false>(p, st);
+    if (mode == 4) mode = 0;
     if (mode == 0) {
       if (p.cout % 256 == 0 && t256 * (p.cout / 256) >= 512) mode = 3;
       else if (t256 * (p.cout / (p.cout % 128 == 0 ? 128 : 64)) >= 512) mode = 2;

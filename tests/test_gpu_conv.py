@@ -56,13 +56,16 @@ def test_conv3x3(dev, N, H, W, cin, cout, relu, pool, precision, regstage):
                   got, want, tol)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
 @pytest.mark.parametrize("N,H,W,cin,cout,relu,pool", [
     (2, 12, 20, 64, 64, True, True),
     (1, 9, 7, 128, 128, True, True),
     (3, 20, 24, 256, 256, True, False),
     (1, 30, 40, 512, 512, False, False),
     (2, 16, 20, 256, 512, True, True),
+    (1, 17, 23, 128, 256, True, True),    # ring kernel: one partial 256-row tile, pooling floors
+    (5, 21, 19, 128, 256, True, False),   # ring kernel: several M tiles, ragged tail
+    (2, 10, 14, 512, 256, False, True),
 ])
 def test_conv3x3_bf16_tile_variants(dev, N, H, W, cin, cout, relu, pool, tile):
     """Every tile shape of the implicit GEMM gives the same tensor (bit for bit: the K order and the
