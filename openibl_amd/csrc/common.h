@@ -54,7 +54,10 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 __host__ __device__ static inline uint16_t f32_to_bf16_bits(float f) {
-  // round-to-nearest-even; NaN kept quiet.
+  // round-to-nearest-even; NaN kept quiet.  Device code: one v_cvt_pk_bf16_f32 (same rounding).
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_bit_cast(uint16_t, (__bf16)f);
+#endif
   union {
     float f;
     uint32_t u;
