@@ -420,9 +420,11 @@ static int launch_conv_cfg(const ConvParams& p, hipStream_t st) {
                     : launch_conv_kernel<Cfg, POOL, true>(q, grid, st);
 }
 
-// ring-schedule kernel (conv_ring.h): bf16, Cin % 128 == 0, Cout % 256 == 0
-template <bool POOL>
-static int launch_conv_ring(const ConvParams& p, hipStream_t st) {
+// ring-schedule kernel (conv_ring.h): bf16, Cin % 64 == 0; WM = 2: 256 x 256 tile (Cout % 256 == 0),
+// WM = 4: 512 x 128 tile (Cout % 128 == 0)
+template <int WM, bool POOL, bool ODD>
+static int launch_conv_ring_impl(const ConvParams& p, hipStream_t st) {
+  using G = RingGeo<WM>;
   RingParams q;
   q.in = p.in;
   q.w = p.w;
@@ -437,12 +439,12 @@ static int launch_conv_ring(const ConvParams& p, hipStream_t st) {
   q.cout = p.cout;
   q.m_total = (int)p.m_total;
   q.out_rows = (int)p.out_rows;
-  q.tiles_n = p.cout / RG_BN;
+  q.tiles_n = p.cout / G::BN;
   q.relu = p.relu;
-  const long tiles_m = (p.m_total + RG_BM - 1) / RG_BM;
+  const long tiles_m = (p.m_total + G::BM - 1) / G::BM;
   const long grid = tiles_m * q.tiles_n;
-  constexpr int lds = ring_lds_bytes<POOL>();
-  auto kern = conv3x3_ring_kernel<POOL>;
+  constexpr int lds = ring_lds_bytes<WM, POOL>();
+  auto kern = conv3x3_ring_kernel<WM, POOL, ODD>;
   static bool done = false;
   if (!done) {
     OIBL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -454,9 +456,23 @@ static int launch_conv_ring(const ConvParams& p, hipStream_t st) {
   return OIBL_OK;
 }
 
-static bool ring_eligible(const ConvParams& p) {
-  return p.cin % 128 == 0 && p.cout % RG_BN == 0 &&
-         (size_t)p.N * p.H * p.W * p.cin * 2 < (size_t)0xE0000000u && p.m_total < 0x7fffff00L;
+template <int WM, bool POOL>
+static int launch_conv_ring(const ConvParams& p, hipStream_t st) {
+  // an odd number of K-tiles happens only for Cin = 64, which only the 512 x 128 variant serves
+  if constexpr (WM == 4) {
+    if ((9 * (p.cin / 64)) & 1) return launch_conv_ring_impl<WM, POOL, true>(p, st);
+  }
+  return launch_conv_ring_impl<WM, POOL, false>(p, st);
+}
+
+// 0 = not eligible, else the wave-row count of the instantiation to use
+static int ring_variant(const ConvParams& p) {
+  if (p.cin % 64 != 0 || (size_t)p.N * p.H * p.W * p.cin * 2 >= (size_t)0xE0000000u ||
+      p.m_total >= 0x7fffff00L)
+    return 0;
+  if (p.cout % 256 == 0 && p.cin % 128 == 0) return 2;
+  if (p.cout % 128 == 0) return 4;
+  return 0;
 }
 
 // Tile selection.  The implicit GEMM is bound by L2 -> LDS traffic before it is bound by the
@@ -482,9 +498,12 @@ static int launch_conv(const ConvParams& p, int pool, hipStream_t st) {
     using C256x64 = GemmCfg<T, 4, 2, 2, 1>;
     const long t256 = (p.m_total + 255) / 256;
     int mode = g_conv_tile;
-    if ((mode == 4 || (mode == 0 && t256 * (p.cout / 256) >= g_ring_min_tiles)) && ring_eligible(p) &&
-        !g_regstage && !p.ablate)
-      return pool ? launch_conv_ring<true>(p, st) : launch_conv_ring<false>(p, st);
+    const int rv = (g_regstage || p.ablate) ? 0 : ring_variant(p);
+    const long ring_tiles = rv == 2 ? t256 * (p.cout / 256) : ((p.m_total + 511) / 512) * (p.cout / 128);
+    if (rv && (mode == 4 || (mode == 0 && ring_tiles >= g_ring_min_tiles))) {
+      if (rv == 2) return pool ? launch_conv_ring<2, true>(p, st) : launch_conv_ring<2, false>(p, st);
+      return pool ? launch_conv_ring<4, true>(p, st) : launch_conv_ring<4, false>(p, st);
+    }
     if (mode == 4) mode = 0;
     if (mode == 0) {
       if (p.cout % 256 == 0 && t256 * (p.cout / 256) >= 512) mode = 3;
@@ -861,7 +880,10 @@ static int conv3x3_impl(const void* in, int N, int H, int W, int cin, const void
   OIBL_REQUIRE((long)N * H * W < 0x7fffffffL, "conv3x3: N*H*W must be < 2^31 (split the batch)");
   OIBL_REQUIRE((uintptr_t)in % 16 == 0 && (uintptr_t)packed_w % 16 == 0 && (uintptr_t)out % 16 == 0,
                "conv3x3: pointers must be 16-byte aligned");
-  if (precision == OIBL_BF16 && cin == 64 && g_conv_c64 && !g_regstage && !g_conv_ablate)
+  // Cin = 64: the resident-weights / LDS-halo kernel serves Cout = 64 (conv1_2); from Cout = 128 on
+  // the 512 x 128 ring kernel is faster (conv2_1: 795 vs 680 TFLOP/s) unless the hook forces c64.
+  if (precision == OIBL_BF16 && cin == 64 && g_conv_c64 && !g_regstage && !g_conv_ablate &&
+      (g_conv_c64 == 2 || cout % 128 != 0))
     return launch_conv_c64(in, N, H, W, packed_w, bias, cout, relu, pool, out, st);
   ConvParams p;
   p.in = in;
@@ -899,8 +921,8 @@ int oibl_debug_set_prof_buffer(void* dev_u64x8) {
   return OIBL_OK;
 }
 
-int oibl_debug_set_conv_c64(int on) {
-  g_conv_c64 = on ? 1 : 0;
+int oibl_debug_set_conv_c64(int on) {  // 0 = off, 1 = auto, 2 = every Cin = 64 layer
+  g_conv_c64 = on < 0 ? 0 : (on > 2 ? 2 : on);
   return OIBL_OK;
 }
 

@@ -1,4 +1,4 @@
-// Implicit-GEMM 3x3 convolution, bf16, 256 x 256 tile — "ring" schedule for gfx950.
+// Implicit-GEMM 3x3 convolution, bf16, 256 x 256 or 512 x 128 tile — "ring" schedule for gfx950.
 //
 // Same contraction and the same summation order as conv3x3_igemm_kernel (conv.hip): M = output
 // pixels, N = Cout, K = 9 * Cin ordered (tap, cin), one K-tile = 64 bf16 = one 128-byte line per
@@ -47,12 +47,23 @@
 
 namespace oibl {
 
-constexpr int RG_BM = 256, RG_BN = 256;
-constexpr int RG_UNIT = 16384;          // 128 rows x 128 B
-constexpr int RG_TILE = 4 * RG_UNIT;    // A0 A1 B0 B1
-constexpr int RG_MAIN_LDS = 2 * RG_TILE;
-constexpr int RG_U_A0 = 0, RG_U_A1 = 1, RG_U_B0 = 2, RG_U_B1 = 3;
 constexpr unsigned RG_OOB = 0xF0000000u;  // voffset of an out-of-image tap (>= num_records)
+
+// Geometry of one instantiation.  WM = wave rows (2 or 4); the 8 waves form a WM x (8 / WM) grid,
+// every wave owns 128 x 64 outputs, so the tile is 256 x 256 (WM = 2, Cout % 256 == 0) or
+// 512 x 128 (WM = 4, Cout % 128 == 0).  Stagger group of a wave = wave >> 2 (waves w and w + 4
+// share a SIMD).
+template <int WM_>
+struct RingGeo {
+  static constexpr int WM = WM_, WN = 8 / WM_;
+  static constexpr int BM = WM * 128, BN = WN * 64;
+  static constexpr int NA = WM;       // LDS-DMA instructions per wave per A unit (WM * 64 rows)
+  static constexpr int NB = WN / 2;   // ... per B unit (WN * 32 rows)
+  static constexpr int A_UNIT = WM * 64 * 128, B_UNIT = WN * 32 * 128;
+  static constexpr int TILE = 2 * A_UNIT + 2 * B_UNIT;  // one K-tile: A0 A1 B0 B1
+  static constexpr int MAIN_LDS = 2 * TILE;
+  static_assert(WM == 2 || WM == 4, "wave grid");
+};
 
 struct RingParams {
   const void* in;
@@ -67,11 +78,12 @@ struct RingParams {
   int relu;
 };
 
-template <bool POOL>
+template <int WM, bool POOL>
 constexpr int ring_lds_bytes() {
-  constexpr int rows = POOL ? RG_BM / 4 : RG_BM;
-  constexpr int epi = rows * (RG_BN * 2 + 16);
-  return epi > RG_MAIN_LDS ? epi : RG_MAIN_LDS;
+  using G = RingGeo<WM>;
+  constexpr int rows = POOL ? G::BM / 4 : G::BM;
+  constexpr int epi = rows * (G::BN * 2 + 16);
+  return epi > G::MAIN_LDS ? epi : G::MAIN_LDS;
 }
 
 __device__ static inline void buf_glds16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff,
@@ -82,47 +94,46 @@ __device__ static inline void buf_glds16(__amdgpu_buffer_rsrc_t rsrc, unsigned v
 
 template <int N>
 __device__ static inline void wait_vmcnt() {
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else static_assert(N < 0, "unsupported vmcnt");
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <bool POOL>
+template <int WM, bool POOL, bool ODD>
 __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
+  using G = RingGeo<WM>;
+  constexpr int NA = G::NA, NB = G::NB;
+  constexpr int OFF_A0 = 0, OFF_A1 = G::A_UNIT, OFF_B0 = 2 * G::A_UNIT, OFF_B1 = 2 * G::A_UNIT + G::B_UNIT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 2, wn = wave & 3;  // wave row (= stagger group) / wave column
+  const int wm = wave / G::WN, wn = wave % G::WN;
+  const int group = wave >> 2;  // stagger group: one wave of each group on every SIMD
   const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
-  const int m0 = tm * RG_BM, n0 = tn * RG_BN;
+  const int m0 = tm * G::BM, n0 = tn * G::BN;
   const int pix_bytes = p.cin * 2;
   const int cchunks = p.cin >> 6;
-  const int nsteps = 9 * cchunks;  // even, >= 18 (host guarantees cin % 128 == 0)
+  const int nsteps = 9 * cchunks;
 
   const __amdgpu_buffer_rsrc_t rs_a =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_b =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
 
-  // ---- staging geometry: LDS-DMA instruction i (0/1) of this wave fills unit rows
-  //      u = 8 * (wave + 8 i) + (lane >> 3); lane's 16-B piece is XOR-swizzled on the SOURCE side.
+  // ---- staging geometry: LDS-DMA instruction i of this wave fills unit rows
+  //      u = 8 * (wave + 8 i) + (lane >> 3); lane's 16-B piece is XOR-swizzled on the SOURCE side
+  //      (physical slot = logical ^ ((u >> 1) & 7) = logical ^ (4 (wave & 1) + (lane >> 4))).
   const int piece = ((lane & 7) ^ (4 * (wave & 1) + (lane >> 4))) * 16;
-  unsigned a_base[4];  // [2 h + i]: byte offset of the pixel (centre tap) + piece
-  unsigned a_mask[4];  // 9-bit tap validity
-  unsigned b_off[4];   // [2 h + i]: byte offset of the weight row (tap 0, chunk 0) + piece
+  unsigned a_base[2 * NA];  // [NA h + i]: byte offset of the pixel (centre tap) + piece
+  unsigned a_mask[2 * NA];  // 9-bit tap validity
+  unsigned b_off[2 * NB];   // [NB h + i]: byte offset of the weight row (tap 0, chunk 0) + piece
   {
     const int Hq = POOL ? (p.H >> 1) : p.H, Wq = POOL ? (p.W >> 1) : p.W;
     const unsigned hw = (unsigned)Hq * (unsigned)Wq;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < NA; ++i) {
         const int u = 8 * (wave + 8 * i) + (lane >> 3);
         const unsigned m = (unsigned)m0 + (unsigned)((u >> 6) * 128 + h * 64 + (u & 63));
         unsigned mk = 0, off = 0;
@@ -142,19 +153,25 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
                (x2 ? 32u : 0u) | (y2 && x0 ? 64u : 0u) | (y2 ? 128u : 0u) | (y2 && x2 ? 256u : 0u);
           off = ((n * (unsigned)p.H + (unsigned)y) * (unsigned)p.W + (unsigned)x) * (unsigned)pix_bytes;
         }
-        a_mask[2 * h + i] = mk;
-        a_base[2 * h + i] = off + piece;
+        a_mask[NA * h + i] = mk;
+        a_base[NA * h + i] = off + piece;
+      }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int u = 8 * (wave + 8 * i) + (lane >> 3);
         const int col = (u >> 5) * 64 + h * 32 + (u & 31);
-        b_off[2 * h + i] = (unsigned)(n0 + col) * (unsigned)pix_bytes + piece;
+        b_off[NB * h + i] = (unsigned)(n0 + col) * (unsigned)pix_bytes + piece;
       }
   }
   const unsigned tap_stride = (unsigned)p.cout * (unsigned)pix_bytes;
 
   // staging cursor: describes the K-tile whose units are currently being issued
   int s_tap = 0, s_cc = -1;
-  unsigned a_cur[4] = {0, 0, 0, 0};  // per-tap A offsets (RG_OOB when the tap leaves the image)
+  unsigned a_cur[2 * NA];  // per-tap A offsets (RG_OOB when the tap leaves the image)
   unsigned a_soff = 0, b_soff = 0;
-  auto begin_tile = [&]() {
+  auto begin_tile = [&]() __attribute__((always_inline)) {
     ++s_cc;
     if (s_cc == cchunks) {
       s_cc = 0;
@@ -164,22 +181,22 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
       const int ky = (s_tap * 11) >> 5, kx = s_tap - 3 * ky;
       const int toff = ((ky - 1) * p.W + (kx - 1)) * pix_bytes;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 2 * NA; ++j)
         a_cur[j] = ((a_mask[j] >> s_tap) & 1u) ? a_base[j] + (unsigned)toff : RG_OOB;
     }
     a_soff = (unsigned)s_cc * 128u;
     b_soff = (unsigned)s_tap * tap_stride + (unsigned)s_cc * 128u;
   };
   char* const st_base = smem + wave * 1024;
-  auto stage_a = [&](int buf, int h) {
-    char* d = st_base + buf * RG_TILE + (h ? RG_U_A1 : RG_U_A0) * RG_UNIT;
-    buf_glds16(rs_a, a_cur[2 * h], a_soff, d);
-    buf_glds16(rs_a, a_cur[2 * h + 1], a_soff, d + 8192);
+  auto stage_a = [&](int buf, int h) __attribute__((always_inline)) {
+    char* d = st_base + buf * G::TILE + (h ? OFF_A1 : OFF_A0);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) buf_glds16(rs_a, a_cur[NA * h + i], a_soff, d + i * 8192);
   };
-  auto stage_b = [&](int buf, int h) {
-    char* d = st_base + buf * RG_TILE + (RG_U_B0 + h) * RG_UNIT;
-    buf_glds16(rs_b, b_off[2 * h], b_soff, d);
-    buf_glds16(rs_b, b_off[2 * h + 1], b_soff, d + 8192);
+  auto stage_b = [&](int buf, int h) __attribute__((always_inline)) {
+    char* d = st_base + buf * G::TILE + (h ? OFF_B1 : OFF_B0);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) buf_glds16(rs_b, b_off[NB * h + i], b_soff, d + i * 8192);
   };
 
   // ---- fragment read geometry
@@ -189,20 +206,20 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) frag_off[kk] = row * 128 + (((2 * kk + half) ^ swz) * 16);
   }
-  const char* const rd_a = smem + wm * 8192;  // + buf * RG_TILE + unit * RG_UNIT + i2 * 4096
-  const char* const rd_b = smem + wn * 4096;
+  const char* const rd_a = smem + wm * 8192;  // + buf * TILE + OFF_A{h} + i2 * 4096
+  const char* const rd_b = smem + wn * 4096;  // + buf * TILE + OFF_B{h}
 
   bf16x8_t fa[2][4], fbx[4], fby[4];
-  auto read_a = [&](int buf, int h) {
-    const char* s = rd_a + buf * RG_TILE + (h ? RG_U_A1 : RG_U_A0) * RG_UNIT;
+  auto read_a = [&](int buf, int h) __attribute__((always_inline)) {
+    const char* s = rd_a + buf * G::TILE + (h ? OFF_A1 : OFF_A0);
 #pragma unroll
     for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
         fa[i2][kk] = *reinterpret_cast<const bf16x8_t*>(s + i2 * 4096 + frag_off[kk]);
   };
-  auto read_b = [&](int buf, int h, bf16x8_t (&f)[4]) {
-    const char* s = rd_b + buf * RG_TILE + (RG_U_B0 + h) * RG_UNIT;
+  auto read_b = [&](int buf, int h, bf16x8_t (&f)[4]) __attribute__((always_inline)) {
+    const char* s = rd_b + buf * G::TILE + (h ? OFF_B1 : OFF_B0);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) f[kk] = *reinterpret_cast<const bf16x8_t*>(s + frag_off[kk]);
   };
@@ -215,7 +232,7 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  auto compute = [&](auto h_c, auto j_c, const bf16x8_t (&fb)[4]) {
+  auto compute = [&](auto h_c, auto j_c, const bf16x8_t (&fb)[4]) __attribute__((always_inline)) {
     constexpr int h = decltype(h_c)::value, j = decltype(j_c)::value;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -229,7 +246,7 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto bar = [&]() {
+  auto bar = [&]() __attribute__((always_inline)) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -249,24 +266,27 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
   stage_b(1, 0);
   stage_a(1, 0);
   stage_b(1, 1);
-  wait_vmcnt<10>();  // B0(0), A0(0) of this wave have landed
+  wait_vmcnt<2 * NA + 3 * NB>();  // B0(0), A0(0) of this wave have landed
   bar();
   read_b(0, 0, fbx);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if (wm == 1) bar();  // wave row 1 runs one barrier behind wave row 0
+  if (group == 1) bar();  // group 1 runs one barrier behind group 0
 
   // One K-tile = 4 phases.  PAR = tile parity (LDS buffer; which register set holds B0).
   // TAIL: 0 = steady state, 1 = tile nsteps-2, 2 = tile nsteps-1 (nothing left to stage).
-  auto ktile = [&](auto par_c, auto tail_c) {
+  // The counted waits leave exactly the five youngest units in flight (steady state); in the tail
+  // the units that are no longer issued are subtracted.
+  auto ktile = [&](auto par_c, auto tail_c) __attribute__((always_inline)) {
     constexpr int PAR = decltype(par_c)::value;
     constexpr int TAIL = decltype(tail_c)::value;
     bf16x8_t(&b0)[4] = PAR ? fby : fbx;  // B0 of this tile
     bf16x8_t(&b1)[4] = PAR ? fbx : fby;  // B1 of this tile; from P3 on: B0 of the next tile
     // P0: A0 x B0
     read_a(PAR, 0);
-    if constexpr (TAIL <= 1) stage_a(PAR ^ 1, 1);  // A1(t+1)
-    if constexpr (TAIL <= 1) wait_vmcnt<10>();
-    else wait_vmcnt<2>();
+    if constexpr (TAIL <= 1) {
+      stage_a(PAR ^ 1, 1);  // A1(t+1)
+      wait_vmcnt<3 * NA + 2 * NB>();
+    } else wait_vmcnt<NA>();
     bar();
     compute(I0{}, I0{}, b0);
     bar();
@@ -275,8 +295,8 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
     if constexpr (TAIL == 0) {
       begin_tile();
       stage_b(PAR, 0);  // B0(t+2)
-      wait_vmcnt<10>();
-    } else if constexpr (TAIL == 1) wait_vmcnt<8>();
+      wait_vmcnt<2 * NA + 3 * NB>();
+    } else if constexpr (TAIL == 1) wait_vmcnt<2 * NA + 2 * NB>();
     else wait_vmcnt<0>();
     bar();
     compute(I0{}, I1{}, b1);
@@ -285,8 +305,8 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
     read_a(PAR, 1);
     if constexpr (TAIL == 0) {
       stage_a(PAR, 0);  // A0(t+2)
-      wait_vmcnt<10>();
-    } else if constexpr (TAIL == 1) wait_vmcnt<6>();
+      wait_vmcnt<3 * NA + 2 * NB>();
+    } else if constexpr (TAIL == 1) wait_vmcnt<2 * NA + NB>();
     bar();
     compute(I1{}, I1{}, b1);
     bar();
@@ -294,25 +314,31 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
     if constexpr (TAIL <= 1) read_b(PAR ^ 1, 0, b1);
     if constexpr (TAIL == 0) {
       stage_b(PAR, 1);  // B1(t+2)
-      wait_vmcnt<10>();
-    } else if constexpr (TAIL == 1) wait_vmcnt<4>();
+      wait_vmcnt<2 * NA + 3 * NB>();
+    } else if constexpr (TAIL == 1) wait_vmcnt<NA + NB>();
     bar();
     compute(I1{}, I0{}, b0);
     bar();
   };
-  for (int t = 0; t < nsteps - 2; t += 2) {
+  for (int t = 0; t + 3 < nsteps; t += 2) {  // pairs of steady-state tiles
     ktile(I0{}, I0{});
     ktile(I1{}, I0{});
   }
-  ktile(I0{}, I1{});
-  ktile(I1{}, I2{});
-  if (wm == 0) bar();
+  if constexpr (ODD) {  // Cin = 64: nine K-tiles
+    ktile(I0{}, I0{});
+    ktile(I1{}, I1{});
+    ktile(I0{}, I2{});
+  } else {
+    ktile(I0{}, I1{});
+    ktile(I1{}, I2{});
+  }
+  if (group == 0) bar();
   __syncthreads();  // staging LDS is free for the epilogue
 
   // ---- epilogue: bias (+ReLU) (+2x2 max-pool over register quads), transpose through LDS,
   //      full-line NHWC stores
-  constexpr int PITCH = RG_BN * 2 + 16;
-  constexpr int OUT_ROWS = POOL ? RG_BM / 4 : RG_BM;
+  constexpr int PITCH = G::BN * 2 + 16;
+  constexpr int OUT_ROWS = POOL ? G::BM / 4 : G::BM;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = wn * 64 + j * 32 + (lane & 31);
@@ -340,7 +366,7 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
     }
   }
   __syncthreads();
-  constexpr int CPR = RG_BN * 2 / 16;  // 16-byte chunks per output row
+  constexpr int CPR = G::BN * 2 / 16;  // 16-byte chunks per output row
   const long row0 = POOL ? (m0 >> 2) : m0;
   char* obase = reinterpret_cast<char*>(p.out) + (long)n0 * 2;
   const long orow_bytes = (long)p.cout * 2;

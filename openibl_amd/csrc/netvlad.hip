@@ -125,44 +125,57 @@ __global__ __launch_bounds__(256) void netvlad_aggregate_kernel(
   float colsum = 0.f;  // threads 0..63: sum_p a[p][tid]
 
   // staging roles: a chunk = 32 x 64 floats = 512 float4 (2 per thread);
-  //                x chunk = 32 pixels x 64 channels (8 threads per pixel, 8 channels each)
+  //                x chunk = 32 pixels x 64 channels (8 threads per pixel, 8 channels each).
+  // The next chunk's global loads are issued before the current chunk's MFMAs (register
+  // prefetch): one workgroup per CU has nothing else to hide the load latency behind.
   const int xp = threadIdx.x >> 3, xc = (threadIdx.x & 7) * 8;
-  for (int p0 = 0; p0 < P; p0 += 32) {
+  float4 pa[2];
+  uint4 px0, px1;  // bf16: px0 only (8 elements); fp32: px0, px1
+  float psc;
+  auto prefetch = [&](int p0) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int idx = threadIdx.x + q * 256;  // float4 index
       const int pr = idx >> 4, cq = (idx & 15) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p0 + pr < P) v = *reinterpret_cast<const float4*>(abase + (size_t)(p0 + pr) * 64 + cq);
-      *reinterpret_cast<float4*>(&a_s[pr][cq]) = v;
+      pa[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p0 + pr < P) pa[q] = *reinterpret_cast<const float4*>(abase + (size_t)(p0 + pr) * 64 + cq);
+    }
+    px0 = make_uint4(0, 0, 0, 0);
+    px1 = make_uint4(0, 0, 0, 0);
+    psc = 0.f;
+    if (p0 + xp < P) {
+      psc = ibase[p0 + xp];
+      const T* src = fbase + (size_t)(p0 + xp) * C + xc;
+      px0 = *reinterpret_cast<const uint4*>(src);
+      if constexpr (sizeof(T) == 4) px1 = *reinterpret_cast<const uint4*>(src + 4);
+    }
+  };
+  prefetch(0);
+  for (int p0 = 0; p0 < P; p0 += 32) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int idx = threadIdx.x + q * 256;
+      *reinterpret_cast<float4*>(&a_s[idx >> 4][(idx & 15) * 4]) = pa[q];
     }
     {
       float xv[8];
-      if (p0 + xp < P) {
-        const float sc = ibase[p0 + xp];
-        const T* src = fbase + (size_t)(p0 + xp) * C + xc;
-        if constexpr (sizeof(T) == 2) {
-          const uint4 raw8 = *reinterpret_cast<const uint4*>(src);  // 8 bf16, 16-byte aligned
-          const uint32_t wds[4] = {raw8.x, raw8.y, raw8.z, raw8.w};
+      if constexpr (sizeof(T) == 2) {
+        const uint32_t wds[4] = {px0.x, px0.y, px0.z, px0.w};
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            xv[2 * k] = bf16_bits_to_f32((uint16_t)(wds[k] & 0xffffu)) * sc;
-            xv[2 * k + 1] = bf16_bits_to_f32((uint16_t)(wds[k] >> 16)) * sc;
-          }
-        } else {
-          const float4 lo = *reinterpret_cast<const float4*>(src);
-          const float4 hi = *reinterpret_cast<const float4*>(src + 4);
-          xv[0] = lo.x * sc, xv[1] = lo.y * sc, xv[2] = lo.z * sc, xv[3] = lo.w * sc;
-          xv[4] = hi.x * sc, xv[5] = hi.y * sc, xv[6] = hi.z * sc, xv[7] = hi.w * sc;
+        for (int k = 0; k < 4; ++k) {
+          xv[2 * k] = bf16_bits_to_f32((uint16_t)(wds[k] & 0xffffu)) * psc;
+          xv[2 * k + 1] = bf16_bits_to_f32((uint16_t)(wds[k] >> 16)) * psc;
         }
       } else {
+        const uint32_t wds[8] = {px0.x, px0.y, px0.z, px0.w, px1.x, px1.y, px1.z, px1.w};
 #pragma unroll
-        for (int k = 0; k < 8; ++k) xv[k] = 0.f;
+        for (int k = 0; k < 8; ++k) xv[k] = __uint_as_float(wds[k]) * psc;
       }
       *reinterpret_cast<float4*>(&x_s[xp][xc]) = make_float4(xv[0], xv[1], xv[2], xv[3]);
       *reinterpret_cast<float4*>(&x_s[xp][xc + 4]) = make_float4(xv[4], xv[5], xv[6], xv[7]);
     }
     __syncthreads();
+    if (p0 + 32 < P) prefetch(p0 + 32);
     if (threadIdx.x < 64) {
 #pragma unroll
       for (int p = 0; p < 32; ++p) colsum += a_s[p][threadIdx.x];
@@ -188,36 +201,52 @@ __global__ __launch_bounds__(256) void netvlad_aggregate_kernel(
 }
 
 // intra-normalise every cluster row, then L2-normalise the flattened K*C vector (k-major).
-__global__ __launch_bounds__(256) void netvlad_finalize_kernel(const float* __restrict__ raw,
-                                                               float* __restrict__ out, int K,
+// Two launches with one wave per (image, cluster) row — N*K/4 workgroups instead of N:
+//   rowstats: iv = 1 / max(|r|, eps) and s2 = |r * iv|^2 of every row;
+//   apply   : ginv = 1 / max(sqrt(sum_k s2[n][k]), eps) (fixed-order wave reduction), out = r * iv * ginv.
+__global__ __launch_bounds__(256) void netvlad_rowstats_kernel(const float* __restrict__ raw,
+                                                               float* __restrict__ stats, long rows,
                                                                int C) {
-  __shared__ float row_inv[64];
-  __shared__ float part[4];
-  const int n = blockIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float* rb = raw + (size_t)n * K * C;
-  float tot = 0.f;
-  for (int k = wave; k < K; k += 4) {
-    const float* r = rb + (size_t)k * C;
-    float s = 0.f;
-    for (int i = lane; i < C; i += 64) s = fmaf(r[i], r[i], s);
-    s = wave_sum(s);
-    const float iv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
-    float s2 = 0.f;
-    for (int i = lane; i < C; i += 64) {
-      const float v = r[i] * iv;
-      s2 = fmaf(v, v, s2);
-    }
-    s2 = wave_sum(s2);
-    if (lane == 0) row_inv[k] = iv;
-    tot += s2;
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* r = raw + row * C;
+  float s = 0.f;
+  for (int i = lane; i < C; i += 64) s = fmaf(r[i], r[i], s);
+  s = wave_sum(s);
+  const float iv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+  float s2 = 0.f;
+  for (int i = lane; i < C; i += 64) {
+    const float v = r[i] * iv;
+    s2 = fmaf(v, v, s2);
   }
-  if (lane == 0) part[wave] = tot;
-  __syncthreads();
-  const float total = part[0] + part[1] + part[2] + part[3];
-  const float ginv = 1.0f / fmaxf(sqrtf(total), 1e-12f);
-  float* ob = out + (size_t)n * K * C;
-  for (int i = threadIdx.x; i < K * C; i += 256) ob[i] = rb[i] * row_inv[i / C] * ginv;
+  s2 = wave_sum(s2);
+  if (lane == 0) {
+    stats[2 * row] = iv;
+    stats[2 * row + 1] = s2;
+  }
+}
+
+__global__ __launch_bounds__(256) void netvlad_apply_kernel(const float* __restrict__ raw,
+                                                            const float* __restrict__ stats,
+                                                            float* __restrict__ out, long rows, int K,
+                                                            int C) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const long n = row / K;
+  float t = 0.f;
+  for (int k = lane; k < K; k += 64) t += stats[2 * (n * K + k) + 1];
+  t = wave_sum(t);
+  const float iv = stats[2 * row];
+  const float ginv = 1.0f / fmaxf(sqrtf(t), 1e-12f);
+  const float* r = raw + row * C;
+  float* o = out + row * C;
+  for (int i = lane * 4; i < C; i += 256) {  // C % 64 == 0 and 16-byte aligned rows
+    const float4 v = *reinterpret_cast<const float4*>(r + i);
+    *reinterpret_cast<float4*>(o + i) =
+        make_float4(v.x * iv * ginv, v.y * iv * ginv, v.z * iv * ginv, v.w * iv * ginv);
+  }
 }
 
 }  // namespace oibl
@@ -234,9 +263,13 @@ static size_t nv_off_w(int N, int P, int K, int C) {
   return nv_off_raw(N, P) + align_up((size_t)N * K * C * sizeof(float), 256);
 }
 
+static size_t nv_off_stats(int N, int P, int K, int C) {
+  return nv_off_w(N, P, K, C) + align_up((size_t)K * C * sizeof(uint16_t), 256);
+}
+
 size_t oibl_netvlad_workspace_bytes(int N, int P, int K, int C) {
   if (N <= 0 || P <= 0 || K <= 0 || C <= 0) return 0;
-  return nv_off_w(N, P, K, C) + align_up((size_t)K * C * sizeof(uint16_t), 256);
+  return nv_off_stats(N, P, K, C) + align_up((size_t)N * K * 2 * sizeof(float), 256);
 }
 
 int oibl_netvlad_forward(const void* feat, int N, int P, int K, int C, int precision,
@@ -302,7 +335,13 @@ int oibl_netvlad_forward(const void* feat, int N, int P, int K, int C, int preci
     OIBL_LAUNCH_CHECK();
   }
   if (vlad_norm) {
-    hipLaunchKernelGGL(netvlad_finalize_kernel, dim3(N), dim3(256), 0, st, raw, vlad_norm, K, C);
+    float* stats = (float*)(wsb + nv_off_stats(N, P, K, C));
+    const long vrows = (long)N * K;
+    const unsigned fgrid = (unsigned)((vrows + 3) / 4);
+    hipLaunchKernelGGL(netvlad_rowstats_kernel, dim3(fgrid), dim3(256), 0, st, raw, stats, vrows, C);
+    OIBL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(netvlad_apply_kernel, dim3(fgrid), dim3(256), 0, st, raw, stats, vlad_norm,
+                       vrows, K, C);
     OIBL_LAUNCH_CHECK();
   }
   return OIBL_OK;

@@ -61,27 +61,37 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void pca_partial_kernel(PcaParams p)
       }
 }
 
-// out[n][:] = normalize(sum_s part[s][n][:] + b)
+// out[n][:] = normalize(sum_s part[s][n][:] + b), two launches of N x ceil(d / 256) workgroups:
+//   reduce: fixed-order sum of the split-K partials + bias, block partial of the squared norm;
+//   scale : fixed-order sum of the block partials, out *= 1 / max(sqrt(.), eps).
 __global__ __launch_bounds__(256) void pca_reduce_kernel(const float* __restrict__ part,
                                                          const float* __restrict__ bias,
-                                                         float* __restrict__ out, int N, int d,
-                                                         int splits, int l2norm) {
+                                                         float* __restrict__ out,
+                                                         float* __restrict__ ss_part, int N, int d,
+                                                         int splits) {
   __shared__ float red[4];
-  const int n = blockIdx.x;
+  const int n = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
   float ss = 0.f;
-  for (int j = threadIdx.x; j < d; j += 256) {
+  if (j < d) {
     float v = 0.f;
     for (int s = 0; s < splits; ++s) v += part[((size_t)s * N + n) * d + j];
     v += bias[j];
     out[(size_t)n * d + j] = v;
-    ss = fmaf(v, v, ss);
+    ss = v * v;
   }
-  if (!l2norm) return;
   ss = wave_sum(ss);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
   __syncthreads();
-  const float inv = 1.0f / fmaxf(sqrtf(red[0] + red[1] + red[2] + red[3]), 1e-12f);
-  for (int j = threadIdx.x; j < d; j += 256) out[(size_t)n * d + j] *= inv;
+  if (threadIdx.x == 0) ss_part[(size_t)n * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void pca_scale_kernel(float* __restrict__ out,
+                                                        const float* __restrict__ ss_part, int d) {
+  const int n = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+  float t = 0.f;
+  for (unsigned b = 0; b < gridDim.x; ++b) t += ss_part[(size_t)n * gridDim.x + b];
+  const float inv = 1.0f / fmaxf(sqrtf(t), 1e-12f);
+  if (j < d) out[(size_t)n * d + j] *= inv;
 }
 
 static int pca_splits(int N, int D, int d, int precision) {
@@ -104,7 +114,8 @@ size_t oibl_pca_workspace_bytes(int N, int D, int d, int precision) {
   if (N <= 0 || D <= 0 || d <= 0) return 0;
   const int s = pca_splits(N, D, d, precision);
   return align_up((size_t)N * D * oibl_elem_size(precision), 256) +
-         align_up((size_t)s * N * d * sizeof(float), 256);
+         align_up((size_t)s * N * d * sizeof(float), 256) +
+         align_up((size_t)N * ((d + 255) / 256) * sizeof(float), 256);
 }
 
 int oibl_pca_forward(const float* v, int N, int D, const void* w, const float* b, int d,
@@ -113,6 +124,7 @@ int oibl_pca_forward(const float* v, int N, int D, const void* w, const float* b
   OIBL_REQUIRE(v && w && b && out && ws, "pca: null pointer");
   OIBL_REQUIRE(precision == OIBL_BF16 || precision == OIBL_F32, "pca: bad precision %d", precision);
   const int bk = precision == OIBL_BF16 ? 64 : 32;
+  OIBL_REQUIRE(N <= 65535, "pca: at most 65535 rows per call (got %d)", N);
   OIBL_REQUIRE(N > 0 && D > 0 && d > 0 && D % bk == 0 && d % 128 == 0,
                "pca: unsupported shape N=%d D=%d d=%d", N, D, d);
   OIBL_REQUIRE((uintptr_t)ws % 256 == 0 && (uintptr_t)w % 16 == 0 && (uintptr_t)v % 16 == 0,
@@ -159,9 +171,15 @@ int oibl_pca_forward(const float* v, int N, int D, const void* w, const float* b
                          Cfg::MAIN_LDS_BYTES, st, p);
   }
   OIBL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(pca_reduce_kernel, dim3(N), dim3(256), 0, st, p.part, b, out, N, d, p.splits,
-                     l2norm);
+  float* ss_part = (float*)((char*)p.part + align_up((size_t)p.splits * N * d * sizeof(float), 256));
+  const dim3 rgrid((unsigned)((d + 255) / 256), (unsigned)N);
+  hipLaunchKernelGGL(pca_reduce_kernel, rgrid, dim3(256), 0, st, p.part, b, out, ss_part, N, d,
+                     p.splits);
   OIBL_LAUNCH_CHECK();
+  if (l2norm) {
+    hipLaunchKernelGGL(pca_scale_kernel, rgrid, dim3(256), 0, st, out, ss_part, d);
+    OIBL_LAUNCH_CHECK();
+  }
   return OIBL_OK;
 }
 

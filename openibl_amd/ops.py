@@ -113,9 +113,10 @@ def set_conv_tile(mode: int) -> None:
     _lib.load().oibl_debug_set_conv_tile(int(mode))
 
 
-def set_conv_c64(on: bool) -> None:
-    """Test hook: enable / disable the resident-weights kernel for Cin = 64 layers (bf16)."""
-    _lib.load().oibl_debug_set_conv_c64(1 if on else 0)
+def set_conv_c64(on) -> None:
+    """Test hook: resident-weights kernel for Cin = 64 layers (bf16): False/0 = never, True/1 = auto
+    (Cout = 64 only; wider layers go to the ring kernel), 2 = every Cin = 64 layer."""
+    _lib.load().oibl_debug_set_conv_c64(int(on))
 
 
 def set_conv11_valu(on: bool) -> None:

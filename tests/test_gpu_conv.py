@@ -66,6 +66,8 @@ def test_conv3x3(dev, N, H, W, cin, cout, relu, pool, precision, regstage):
     (1, 17, 23, 128, 256, True, True),    # ring kernel: one partial 256-row tile, pooling floors
     (5, 21, 19, 128, 256, True, False),   # ring kernel: several M tiles, ragged tail
     (2, 10, 14, 512, 256, False, True),
+    (3, 33, 21, 128, 128, True, True),    # ring kernel, 512 x 128 tile: ragged, pooled
+    (2, 40, 30, 256, 128, False, False),  # ring kernel, 512 x 128 tile: several M tiles
 ])
 def test_conv3x3_bf16_tile_variants(dev, N, H, W, cin, cout, relu, pool, tile):
     """Every tile shape of the implicit GEMM gives the same tensor (bit for bit: the K order and the
@@ -100,11 +102,14 @@ def test_conv3x3_cin64_resident_kernel(dev, N, H, W, cout, relu, pool):
     x, w, b = _case(N, H, W, 64, cout, seed=W * 3 + cout)
     xd = ops.nchw_f32_to_nhwc(x.to(dev), "bf16")
     wp = ops.pack_conv3x3(w.to(dev), "bf16")
-    y = ops.conv3x3_nhwc(xd, wp, b.to(dev), relu, pool, "bf16")
-    ops.set_conv_c64(False)
+    ops.set_conv_c64(2)          # force the resident kernel also where auto would pick the ring kernel
     try:
+        y = ops.conv3x3_nhwc(xd, wp, b.to(dev), relu, pool, "bf16")
+        ops.set_conv_c64(False)
+        ops.set_conv_tile(1)
         y_ref = ops.conv3x3_nhwc(xd, wp, b.to(dev), relu, pool, "bf16")
     finally:
+        ops.set_conv_tile(0)
         ops.set_conv_c64(True)
     got = ops.nhwc_to_nchw_f32(y).cpu()
     assert_rel_l2("c64 vs host", got, _host_conv(x, w, b, relu, pool, "bf16"), 4e-3)
@@ -112,6 +117,31 @@ def test_conv3x3_cin64_resident_kernel(dev, N, H, W, cout, relu, pool):
     mism = (y.float() != y_ref.float()).float().mean().item()
     print(f"fraction of outputs differing from the igemm kernel by an ulp: {mism:.4f}")
     assert mism < 0.05
+
+
+@pytest.mark.parametrize("N,H,W,cout,relu,pool", [
+    (1, 21, 45, 128, True, False),
+    (2, 12, 20, 128, True, True),
+    (3, 30, 34, 256, False, False),
+])
+def test_conv3x3_ring_cin64(dev, N, H, W, cout, relu, pool):
+    """Cin = 64 gives nine K-tiles (odd): the ring kernel's odd-count schedule against the generic
+    implicit GEMM (same K order -> identical tensors)."""
+    x, w, b = _case(N, H, W, 64, cout, seed=W + cout)
+    xd = ops.nchw_f32_to_nhwc(x.to(dev), "bf16")
+    wp = ops.pack_conv3x3(w.to(dev), "bf16")
+    ops.set_conv_c64(False)
+    try:
+        ops.set_conv_tile(1)
+        ref = ops.conv3x3_nhwc(xd, wp, b.to(dev), relu, pool, "bf16")
+        ops.set_conv_tile(4)
+        y = ops.conv3x3_nhwc(xd, wp, b.to(dev), relu, pool, "bf16")
+    finally:
+        ops.set_conv_tile(0)
+        ops.set_conv_c64(True)
+    assert torch.equal(y, ref)
+    assert_rel_l2("ring cin64 vs host", ops.nhwc_to_nchw_f32(y).cpu(),
+                  _host_conv(x, w, b, relu, pool, "bf16"), 4e-3)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16-valu"])
