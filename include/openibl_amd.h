@@ -102,6 +102,17 @@ int oibl_nhwc_to_nchw_f32(const void* feat, int N, int P, int C, int precision, 
 int oibl_nchw_f32_to_nhwc(const float* x, int N, int C, int P, int precision, void* out,
                           void* stream);
 
+/* Fused VGG stem, bf16: conv1_1 + ReLU + conv1_2 + ReLU + 2x2/2 max-pool in one launch —
+ * replaces modules 0-4 of VGG.base (ibl/models/vgg.py:40-42; forward :61-62):
+ *   x_nchw [N][3][H][W] fp32 -> out [N][H/2][W/2][64] bf16 (NHWC).
+ * w1_oihw / b1: conv1_1 in the state-dict layout (fp32); packed_w2: conv1_2 packed by
+ * oibl_pack_conv3x3_weights(..., OIBL_BF16).  Bit-identical to oibl_conv1_1_nchw followed by
+ * oibl_conv3x3_nhwc(relu=1, pool=1) in OIBL_BF16; the conv1_1 activations never reach HBM.
+ * oibl_vgg16_conv5_forward uses it automatically in OIBL_BF16. */
+int oibl_vgg16_stem_bf16(const float* x_nchw, int N, int H, int W, const float* w1_oihw,
+                         const float* b1, const void* packed_w2, const float* b2, void* out,
+                         void* stream);
+
 /* Whole backbone: x [N][3][H][W] fp32 -> feat [N][P][512] T, P = (H/16)*(W/16) (floor at
  * every pool).  packed_w_host / bias_host are HOST arrays of 13 DEVICE pointers: entry 0
  * is the plain [64][3][3][3] fp32 conv1_1 weight, entries 1..12 are packed by

@@ -804,6 +804,298 @@ static int launch_conv_c64(const void* in, int N, int H, int W, const void* w, c
 }
 
 // ---------------------------------------------------------------------------------------------
+// VGG stem, fused (bf16): conv1_1 + ReLU + conv1_2 + ReLU + 2x2 max-pool in ONE launch.
+//   x [N][3][H][W] fp32  ->  out [N][H/2][W/2][64] bf16
+// Unfused, conv1_1 writes its 64-channel output (39 MB / image) to HBM only for conv1_2 to read it
+// straight back: together 23 % of the step for 12.6 % of its FLOPs.  Here the conv1_1 activations
+// never leave the CU.  A persistent workgroup of 8 waves is split by role (waves w and w + 4 share
+// a SIMD, so every SIMD hosts one wave of each role):
+//   producers (waves 4-7): for the NEXT 8 x 32 output tile, gather the 3-channel input window of
+//     the (8+2) x (32+2) halo straight from global memory (coalesced dword buffer loads, an
+//     out-of-image tap is an out-of-range offset -> 0), run conv1_1 on the matrix cores (K = 27
+//     padded to 32, transposed GEMM as in conv1_1_mfma_kernel: 4 MFMAs per 32 halo pixels),
+//     bias + ReLU + bf16, and write the halo tile into LDS in exactly the swizzled image the
+//     conv1_2 main loop reads (halo pixels outside the image are written as zeros: conv1_2's
+//     padding);
+//   consumers (waves 0-3): the conv3x3_c64_kernel main loop (resident conv1_2 weights, 144 MFMAs
+//     per wave per tile out of LDS), pool in registers, store the pooled pixels directly.
+// One raw s_barrier per tile hands the halo buffers over (two buffers, producer one tile ahead).
+// Numerics are those of the unfused bf16 path, operation for operation (same MFMA k order, same
+// rounding points) -> bit-identical output.
+// LDS: 72 KiB conv1_2 weights + 2 x 42.5 KiB halo = 157 KiB.
+// ---------------------------------------------------------------------------------------------
+constexpr int ST_HALO_PX = 10 * C64_HW;              // 340
+constexpr int ST_HALO_BYTES = ST_HALO_PX * 128;      // 43520
+constexpr int ST_LDS_BYTES = C64_W_BYTES + 2 * ST_HALO_BYTES;
+constexpr int ST_BLOCKS = (ST_HALO_PX + 31) / 32;    // 11 blocks of 32 halo pixels
+constexpr unsigned ST_OOB = 0xF0000000u;
+static int g_stem_fused = 1;
+
+struct StemParams {
+  const float* x;
+  const float* w1;   // conv1_1 [64][3][3][3] fp32
+  const float* b1;
+  const char* w2;    // conv1_2 packed [9][64][64] bf16
+  const float* b2;
+  char* out;
+  unsigned x_bytes;
+  int N, H, W;
+  int tiles_x, tiles_y, ntiles;
+};
+
+__global__ __launch_bounds__(512) void vgg_stem_kernel(StemParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const wl = smem;
+  char* const hb = smem + C64_W_BYTES;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int first = blockIdx.x, stride = gridDim.x;
+  int niter = 0;
+  if (first < p.ntiles) niter = (p.ntiles - first + stride - 1) / stride;
+  const int Ho = p.H >> 1, Wo = p.W >> 1;
+
+  if (wave >= 4) {
+    // ================================ producers ================================================
+    const int pw = wave - 4;
+    const __amdgpu_buffer_rsrc_t rs_x =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    // conv1_1 weights as the A operand: wf[t][s] element e <-> cout = 32 t + l31, k = 16 s + 8 half + e
+    bf16x8_t wf[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = 16 * s + 8 * half + e;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const float v = k < 27 ? p.w1[(32 * t + l31) * 27 + k] : 0.f;
+          wf[t][s][e] = (short)f32_to_bf16_bits(v);
+        }
+      }
+    float bb[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bb[t][r] = p.b1[32 * t + acc_row(r, lane)];
+    const int plane = p.H * p.W;
+
+    auto produce = [&](int tile, char* buf) __attribute__((always_inline)) {
+      const unsigned r2 = (unsigned)tile / (unsigned)p.tiles_x;
+      const int tx = tile - (int)r2 * p.tiles_x;
+      const int n = (int)(r2 / (unsigned)p.tiles_y), ty = (int)r2 - n * p.tiles_y;
+      const int y0 = ty * 8 - 1, x0 = tx * 32 - 1;
+      float xv[3][16];
+      bool pix_ok[3];
+      int hrow[3], hswz[3];
+#pragma unroll
+      for (int bi = 0; bi < 3; ++bi) {
+        const int b = pw + 4 * bi;  // wave-uniform
+        const int r = 32 * b + l31;
+        const int hy = r / C64_HW, hx = r - hy * C64_HW;
+        const int y = y0 + hy, x = x0 + hx;
+        hrow[bi] = r;
+        hswz[bi] = c64_swz(hy, hx);
+        pix_ok[bi] = b < ST_BLOCKS && r < ST_HALO_PX && y >= 0 && y < p.H && x >= 0 && x < p.W;
+        // validity of the three input rows / columns around (y, x); an invalid tap or a pixel
+        // that is not produced at all loads from an out-of-range offset (-> 0.0f)
+        unsigned mk = 0;
+        if (pix_ok[bi]) {
+          const bool ya = y > 0, yc = y + 1 < p.H, xa = x > 0, xc = x + 1 < p.W;
+          mk = (ya && xa ? 1u : 0u) | (ya ? 2u : 0u) | (ya && xc ? 4u : 0u) | (xa ? 8u : 0u) | 16u |
+               (xc ? 32u : 0u) | (yc && xa ? 64u : 0u) | (yc ? 128u : 0u) | (yc && xc ? 256u : 0u);
+        }
+        const int base = ((n * 3) * p.H + y) * p.W + x;  // element index of (n, c = 0, y, x)
+        if (b >= ST_BLOCKS) continue;  // wave-uniform: this wave has no third block
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            // k = 16 s + 8 half + e: two compile-time candidates, selected by the lane half
+            const int kA = 16 * s + e, kB = kA + 8;
+            const int cA = kA / 9, tA = kA % 9, cB = kB / 9, tB = kB % 9;
+            const int dA = cA * plane + (tA / 3 - 1) * p.W + (tA % 3 - 1);
+            const int dB = cB * plane + (tB / 3 - 1) * p.W + (tB % 3 - 1);
+            const bool okA = kA < 27 && ((mk >> tA) & 1u), okB = kB < 27 && ((mk >> tB) & 1u);
+            const bool ok = half ? okB : okA;
+            const unsigned off = ok ? (unsigned)(base + (half ? dB : dA)) * 4u : ST_OOB;
+            xv[bi][8 * s + e] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)off, 0, 0));
+          }
+      }
+#pragma unroll
+      for (int bi = 0; bi < 3; ++bi) {
+        const int b = pw + 4 * bi;
+        if (b >= ST_BLOCKS) continue;  // wave-uniform
+        bf16x8_t xf[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xf[s][e] = (short)f32_to_bf16_bits(xv[bi][8 * s + e]);
+        f32x16_t acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][r] = bb[t][r];
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][s], xf[s], acc[t], 0, 0, 0);
+        }
+        // D[row = cout][col = pixel]: registers 4g..4g+3 = couts 32 t + 8 g + 4 half + 0..3 of the
+        // lane's pixel -> 8 bytes of its 128-byte halo row, 16-B slot 4 t + g (swizzled), +8 half
+        if (hrow[bi] < ST_HALO_PX) {
+          char* row = buf + hrow[bi] * 128 + 8 * half;
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              uint2 v = make_uint2(0u, 0u);
+              if (pix_ok[bi]) {
+                v.x = pack_bf16x2(fmaxf(acc[t][4 * g], 0.f), fmaxf(acc[t][4 * g + 1], 0.f));
+                v.y = pack_bf16x2(fmaxf(acc[t][4 * g + 2], 0.f), fmaxf(acc[t][4 * g + 3], 0.f));
+              }
+              *reinterpret_cast<uint2*>(row + (((4 * t + g) ^ hswz[bi]) << 4)) = v;
+            }
+        }
+      }
+    };
+
+    if (niter > 0) produce(first, hb);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int it = 0; it < niter; ++it) {
+      if (it + 1 < niter) produce(first + (it + 1) * stride, hb + ((it + 1) & 1) * ST_HALO_BYTES);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    return;
+  }
+
+  // ================================== consumers ================================================
+  {
+    const int piece = ((lane & 7) ^ (4 * (wave & 1) + (lane >> 4))) * 16;
+#pragma unroll
+    for (int j = 0; j < 18; ++j) {
+      const int q = j * 4 + wave;
+      const int r = q * 8 + (lane >> 3);
+      const int tap = r >> 6, c = r & 63;
+      glds16(p.w2 + ((long)(tap * 64 + c) * 64) * 2 + piece, wl + q * 1024);
+    }
+  }
+  int lhy[2], lhx[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    lhy[i] = 2 * wave + ((l31 >> 1) & 1);
+    lhx[i] = 16 * i + 2 * (l31 >> 2) + (l31 & 1);
+  }
+  int w_off[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) w_off[kk] = l31 * 128 + (((2 * kk + half) ^ ((l31 >> 1) & 7)) << 4);
+  float bvals[2];
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) bvals[tn] = p.b2[tn * 32 + l31];
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int it = 0; it < niter; ++it) {
+    const int tile = first + it * stride;
+    const char* const cur = hb + (it & 1) * ST_HALO_BYTES;
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][tn][r] = 0.f;
+    bf16x8_t fa[2][2], fb[2][2];
+    auto load_step = [&](int sidx, bf16x8_t (&a)[2], bf16x8_t (&b)[2]) __attribute__((always_inline)) {
+      const int tap = sidx >> 2, kk = sidx & 3;
+      const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int hy = lhy[i] + ky, hx = lhx[i] + kx;
+        a[i] = *reinterpret_cast<const bf16x8_t*>(
+            cur + (hy * C64_HW + hx) * 128 + (((2 * kk + half) ^ c64_swz(hy, hx)) << 4));
+      }
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+        b[tn] = *reinterpret_cast<const bf16x8_t*>(wl + tap * 8192 + tn * 4096 + w_off[kk]);
+    };
+    load_step(0, fa[0], fb[0]);
+#pragma unroll
+    for (int sidx = 0; sidx < 36; ++sidx) {
+      if (sidx + 1 < 36) load_step(sidx + 1, fa[(sidx + 1) & 1], fb[(sidx + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+          acc[i][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sidx & 1][i], fb[sidx & 1][tn],
+                                                               acc[i][tn], 0, 0, 0);
+    }
+    // all fragment reads of `cur` have been consumed by the MFMAs above: hand the buffer back
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // pooled epilogue straight from registers: lanes 0-31 / 32-63 each write the 32 channels of one
+    // pooled pixel (64 contiguous bytes); the two tn halves complete the 128-byte line
+    const unsigned r2 = (unsigned)tile / (unsigned)p.tiles_x;
+    const int tx = tile - (int)r2 * p.tiles_x;
+    const int n = (int)(r2 / (unsigned)p.tiles_y), ty = (int)r2 - n * p.tiles_y;
+    const int oy = ty * 4 + wave;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int ox = tx * 16 + 8 * i + 2 * g + half;
+        if (oy < Ho && ox < Wo) {
+          uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + (((long)n * Ho + oy) * Wo + ox) * 64 + l31;
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn) {
+            const float v = fmaxf(fmaxf(acc[i][tn][4 * g], acc[i][tn][4 * g + 1]),
+                                  fmaxf(acc[i][tn][4 * g + 2], acc[i][tn][4 * g + 3])) + bvals[tn];
+            o[tn * 32] = f32_to_bf16_bits(fmaxf(v, 0.f));
+          }
+        }
+      }
+  }
+}
+
+static int launch_vgg_stem(const float* x, int N, int H, int W, const float* w1, const float* b1,
+                           const void* packed_w2, const float* b2, void* out, hipStream_t st) {
+  StemParams p;
+  p.x = x;
+  p.w1 = w1;
+  p.b1 = b1;
+  p.w2 = (const char*)packed_w2;
+  p.b2 = b2;
+  p.out = (char*)out;
+  p.x_bytes = (unsigned)((size_t)N * 3 * H * W * 4);
+  p.N = N;
+  p.H = H;
+  p.W = W;
+  p.tiles_x = (W + 31) / 32;
+  p.tiles_y = (H + 7) / 8;
+  const long nt = (long)N * p.tiles_x * p.tiles_y;
+  OIBL_REQUIRE(nt < 0x7fffffffL, "vgg stem: too many tiles");
+  p.ntiles = (int)nt;
+  int gx = 256;  // one persistent workgroup per CU
+  if (gx > p.ntiles) gx = p.ntiles;
+  static bool attr_done = false;
+  if (!attr_done) {
+    OIBL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(vgg_stem_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_BYTES));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(vgg_stem_kernel, dim3(gx), dim3(512), ST_LDS_BYTES, st, p);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
+
+static bool stem_eligible(int N, int H, int W) {
+  return H >= 2 && W >= 2 && (size_t)N * 3 * H * W * 4 < (size_t)0xE0000000u;
+}
+
+// ---------------------------------------------------------------------------------------------
 // small layout / pooling helpers
 // ---------------------------------------------------------------------------------------------
 template <typename T>
@@ -919,6 +1211,22 @@ extern "C" {
 int oibl_debug_set_prof_buffer(void* dev_u64x8) {
   g_prof_buf = (unsigned long long*)dev_u64x8;
   return OIBL_OK;
+}
+
+int oibl_debug_set_stem_fused(int on) {
+  g_stem_fused = on ? 1 : 0;
+  return OIBL_OK;
+}
+
+int oibl_vgg16_stem_bf16(const float* x_nchw, int N, int H, int W, const float* w1_oihw,
+                         const float* b1, const void* packed_w2, const float* b2, void* out,
+                         void* stream) {
+  OIBL_REQUIRE(x_nchw && w1_oihw && b1 && packed_w2 && b2 && out, "vgg16_stem: null pointer");
+  OIBL_REQUIRE(N > 0 && H >= 2 && W >= 2, "vgg16_stem: bad shape N=%d H=%d W=%d", N, H, W);
+  OIBL_REQUIRE(stem_eligible(N, H, W), "vgg16_stem: input of %d x 3 x %d x %d exceeds 3.5 GB", N, H, W);
+  OIBL_REQUIRE((uintptr_t)packed_w2 % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)x_nchw % 4 == 0,
+               "vgg16_stem: packed weights / output must be 16-byte aligned");
+  return launch_vgg_stem(x_nchw, N, H, W, w1_oihw, b1, packed_w2, b2, out, (hipStream_t)stream);
 }
 
 int oibl_debug_set_conv_c64(int on) {  // 0 = off, 1 = auto, 2 = every Cin = 64 layer
@@ -1101,13 +1409,27 @@ int oibl_vgg16_conv5_forward_ev(const float* x_nchw, int N, int H, int W,
   char* bufA = (char*)ws;
   char* bufB = bufA + align_up(ea * es, 256);
 
-  int rc = oibl_conv1_1_nchw(x_nchw, N, H, W, (const float*)packed_w_host[0], bias_host[0],
-                             precision, bufA, stream);
-  if (rc) return rc;
-  if (ev_igemm_begin) OIBL_HIP_CHECK(hipEventRecord((hipEvent_t)ev_igemm_begin, (hipStream_t)stream));
-  int h = H, w = W;
+  int rc;
+  int h = H, w = W, l0 = 1;
   const void* cur = bufA;
-  for (int l = 1; l < OIBL_VGG16_NUM_CONV; ++l) {
+  if (precision == OIBL_BF16 && g_stem_fused && stem_eligible(N, H, W) && !g_regstage &&
+      !g_conv_ablate) {
+    // conv1_1 + conv1_2 + pool in one launch (the matrix-core span then starts with it)
+    if (ev_igemm_begin) OIBL_HIP_CHECK(hipEventRecord((hipEvent_t)ev_igemm_begin, (hipStream_t)stream));
+    rc = launch_vgg_stem(x_nchw, N, H, W, (const float*)packed_w_host[0], bias_host[0],
+                         packed_w_host[1], bias_host[1], bufB, (hipStream_t)stream);
+    if (rc) return rc;
+    h /= 2;
+    w /= 2;
+    cur = bufB;
+    l0 = 2;
+  } else {
+    rc = oibl_conv1_1_nchw(x_nchw, N, H, W, (const float*)packed_w_host[0], bias_host[0], precision,
+                           bufA, stream);
+    if (rc) return rc;
+    if (ev_igemm_begin) OIBL_HIP_CHECK(hipEventRecord((hipEvent_t)ev_igemm_begin, (hipStream_t)stream));
+  }
+  for (int l = l0; l < OIBL_VGG16_NUM_CONV; ++l) {
     void* dst = (l == OIBL_VGG16_NUM_CONV - 1) ? feat : (l % 2 == 0 ? (void*)bufA : (void*)bufB);
     rc = conv3x3_impl(cur, N, h, w, kVgg[l].cin, packed_w_host[l], bias_host[l], kVgg[l].cout,
                       kVgg[l].relu, kVgg[l].pool, precision, dst, (hipStream_t)stream);

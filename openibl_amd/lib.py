@@ -39,6 +39,8 @@ SIGNATURES = {
     "oibl_vgg16_conv5_forward_ev": (c_int, [c_void_p, c_int, c_int, c_int, C.POINTER(c_void_p),
                                             C.POINTER(c_void_p), c_int, c_void_p, c_void_p,
                                             c_size_t, c_void_p, c_void_p, c_void_p]),
+    "oibl_vgg16_stem_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p]),
     "oibl_netvlad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "oibl_netvlad_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                      c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
@@ -61,6 +63,7 @@ _HOOKS = {"oibl_debug_set_regstage": (c_int, [c_int]),
           "oibl_debug_set_conv_tile": (c_int, [c_int]),
           "oibl_debug_set_conv_ablate": (c_int, [c_int]),
           "oibl_debug_set_conv_c64": (c_int, [c_int]),
+          "oibl_debug_set_stem_fused": (c_int, [c_int]),
           "oibl_debug_set_prof_buffer": (c_int, [c_void_p])}
 
 ABI_VERSION = 1

@@ -66,6 +66,9 @@ def main():
                      2 * N * h * w * cout * 9 * cin))
         if pool:
             h, w = h // 2, w // 2
+    if p == "bf16":
+        t, _ = timed(lambda: ops.vgg16_stem(x, packed[0], biases[0], packed[1], biases[1]), a.iters)
+        rows.append(("stem fused (conv1_1+conv01)", t, rows[0][2] + rows[1][2]))
     feat = act
     aw = sd["net_vlad.conv.weight"].reshape(64, 512).contiguous().to(dev)
     cent = sd["net_vlad.centroids"].to(dev)
@@ -77,7 +80,11 @@ def main():
     rows.append(("pca", t, 2 * N * 4096 * 32768))
     t, _ = timed(lambda: ops.pca(vl, pw, pb) if False else ops.vgg16_conv5(x, packed, biases, p), a.iters)
     rows.append(("vgg16 whole", t, sum(r[2] for r in rows[:13])))
-    tot = sum(r[1] for r in rows[:15])
+    named = dict((r[0], r[1]) for r in rows)
+    tot = sum(r[1] for r in rows if not r[0].startswith(("vgg16 whole", "stem fused")))
+    if "stem fused (conv1_1+conv01)" in named:
+        tot_f = tot - rows[0][1] - rows[1][1] + named["stem fused (conv1_1+conv01)"]
+        print(f"  (with the fused stem: {tot_f:.3f} ms -> {N / tot_f * 1e3:.1f} img/s)")
     print(f"precision={p} batch={N} {H}x{W} regstage={a.regstage} tile={a.tile} ablate={a.ablate}")
     for name, ms, fl in rows:
         print(f"  {name:34s} {ms:9.3f} ms  {fl / ms / 1e9:9.1f} TFLOP/s")

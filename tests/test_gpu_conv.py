@@ -170,3 +170,41 @@ def test_pack_layout(dev):
     p = ops.pack_conv3x3(w.to(dev), "fp32").cpu()
     assert tuple(p.shape) == (9, 128, 64)
     assert torch.equal(p, w.permute(2, 3, 0, 1).reshape(9, 128, 64))
+
+
+@pytest.mark.parametrize("N,H,W", [(1, 8, 32), (2, 16, 64), (1, 21, 45), (3, 30, 70), (1, 2, 2),
+                                   (2, 9, 33), (1, 64, 96)])
+def test_vgg_stem_fused(dev, N, H, W):
+    """conv1_1 + conv1_2 + pool in one launch: bit-identical to the two unfused bf16 launches, and
+    within bf16 rounding of the host convolutions."""
+    x, w1, b1 = _case(N, H, W, 3, 64, seed=5 * H + W)
+    x = x * 60.0
+    _, w2, b2 = _case(1, 4, 4, 64, 64, seed=H + 9 * W)
+    wp2 = ops.pack_conv3x3(w2.to(dev), "bf16")
+    y = ops.vgg16_stem(x.to(dev), w1.to(dev), b1.to(dev), wp2, b2.to(dev))
+    a1 = ops.conv1_1_nchw(x.to(dev), w1.to(dev), b1.to(dev), "bf16")
+    ref = ops.conv3x3_nhwc(a1, wp2, b2.to(dev), True, True, "bf16")
+    assert tuple(y.shape) == (N, H // 2, W // 2, 64)
+    assert torch.equal(y, ref)
+    h1 = F.relu(F.conv2d(x.to(torch.bfloat16).double(), w1.to(torch.bfloat16).double(), b1.double(),
+                         padding=1)).to(torch.bfloat16)
+    want = F.max_pool2d(F.relu(F.conv2d(h1.double(), w2.to(torch.bfloat16).double(), b2.double(),
+                                        padding=1)), 2, 2)
+    assert_rel_l2("fused stem vs host", ops.nhwc_to_nchw_f32(y).cpu(), want, 6e-3)
+
+
+def test_vgg16_backbone_stem_toggle(dev):
+    """The backbone entry gives the same feature map with and without the fused stem."""
+    from openibl_amd import synth
+    sd = synth.embednetpca_state(0)
+    x = synth.images(2, 64, 96, seed=4).to(dev)
+    ws = [sd[f"base_model.base.{i}.weight"].to(dev) for i in synth.CONV_IDX]
+    bs = [sd[f"base_model.base.{i}.bias"].to(dev) for i in synth.CONV_IDX]
+    packed = [ws[0]] + [ops.pack_conv3x3(w, "bf16") for w in ws[1:]]
+    a = ops.vgg16_conv5(x, packed, bs, "bf16")
+    ops.set_stem_fused(False)
+    try:
+        b = ops.vgg16_conv5(x, packed, bs, "bf16")
+    finally:
+        ops.set_stem_fused(True)
+    assert torch.equal(a, b)
