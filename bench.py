@@ -12,10 +12,12 @@ reference's own API (`hubconf.vgg16_netvlad()` -> `model(x)`).  Every rank runs 
 (weak scaling, no data-path collective); `value` is images/s over all ranks.
 
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
-  roofline      the implicit-GEMM convolution kernel (12 launches per step, 99.4 % of the FLOPs):
+  roofline      the matrix-core convolution kernels (12 launches per step, 99.8 % of the FLOPs: the
+                fused conv1_1+conv1_2+pool stem and the 11 implicit-GEMM launches conv2_1..conv5_3):
                 algorithmic FLOPs of the 12 launches / their measured span, bracketed with HIP
                 events recorded inside the C ABI on the launching stream, against the dense bf16
-                MFMA peak (2.5 PFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md).
+                MFMA peak (2.5 PFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md).  In fp32 mode
+                conv1_1 runs on the vector ALU outside the span and is not counted.
   cpu_baseline  the CPU oracle (a port of the reference's path onto plain torch-CPU ops) timed on
                 this box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
   matching      secondary metric of BASELINE.json: query x gallery squared-L2 pairs/s on a
@@ -123,14 +125,17 @@ def main():
 
     images = args.batch * args.steps * world
     value = images / elapsed
-    span_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)          # 12 igemm launches
-    fl_igemm = igemm_flops_per_image() * args.batch
+    span_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)          # 12 matrix-core launches
+    fl_conv11 = 2.0 * HEIGHT * WIDTH * 64 * 27 if args.precision == "bf16" else 0.0   # inside the stem
+    fl_igemm = (igemm_flops_per_image() + fl_conv11) * args.batch
     achieved = fl_igemm / (span_ms * 1e-3) / 1e12
     peak = BF16_MFMA_PEAK_TFLOPS if args.precision == "bf16" else F32_MFMA_PEAK_TFLOPS
     roofline = {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
         "frac": round(achieved / peak, 4), "traffic": None,
-        "kernel": "oibl::conv3x3_igemm_kernel (conv1_2..conv5_3, 12 launches/step)",
+        "kernel": ("oibl::vgg_stem_kernel (conv1_1+conv1_2+pool) + oibl::conv3x3_ring_kernel "
+                   "(conv2_1..conv5_3), 12 launches/step" if args.precision == "bf16" else
+                   "oibl::conv3x3_igemm_kernel (conv1_2..conv5_3, 12 launches/step)"),
         "launches_per_step": 12, "avg_launch_ms": round(span_ms / 12, 5),
         "flops_per_launch_avg": fl_igemm / 12,
         "end_to_end_tflops": round(total_flops_per_image() * value / 1e12, 2),

@@ -96,8 +96,20 @@ constexpr int C11_TW = 128;
 constexpr int C11_PITCH = 132;
 constexpr int C11_ZERO = 9 * C11_PITCH;  // index of a zero float (k >= 27)
 
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) short i16x2_t;
+// two floats -> one dword of two bf16 (lo in bits 0-15): a single v_cvt_pk_bf16_f32
 __device__ static inline uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+// ReLU on two packed bf16: as signed 16-bit integers every negative value (sign bit set, -0
+// included) is < 0, so max(x, 0) per half is exactly relu — one v_pk_max_i16 for two values, and
+// rounding first / clamping second gives the same bits as clamping first.
+__device__ static inline uint32_t relu_bf16x2(uint32_t packed) {
+  const i16x2_t z = {0, 0};
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, packed), z));
 }
 
 __global__ __launch_bounds__(256) void conv1_1_mfma_kernel(const float* __restrict__ x,
@@ -174,8 +186,8 @@ __global__ __launch_bounds__(256) void conv1_1_mfma_kernel(const float* __restri
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         uint2 v;
-        v.x = pack_bf16x2(fmaxf(acc[t][4 * g], 0.f), fmaxf(acc[t][4 * g + 1], 0.f));
-        v.y = pack_bf16x2(fmaxf(acc[t][4 * g + 2], 0.f), fmaxf(acc[t][4 * g + 3], 0.f));
+        v.x = relu_bf16x2(pack_bf16x2(acc[t][4 * g], acc[t][4 * g + 1]));
+        v.y = relu_bf16x2(pack_bf16x2(acc[t][4 * g + 2], acc[t][4 * g + 3]));
         *reinterpret_cast<uint2*>(ost + l31 * 144 + (32 * t + 8 * g + 4 * half) * 2) = v;
       }
     __builtin_amdgcn_wave_barrier();  // same-wave exchange through LDS: DS ops retire in order
@@ -841,6 +853,7 @@ struct StemParams {
   unsigned x_bytes;
   int N, H, W;
   int tiles_x, tiles_y, ntiles;
+  unsigned long long* prof;  // optional (test hook): shader-clock totals of block 0, waves 0 and 4
 };
 
 __global__ __launch_bounds__(512) void vgg_stem_kernel(StemParams p) {
@@ -858,6 +871,10 @@ __global__ __launch_bounds__(512) void vgg_stem_kernel(StemParams p) {
   if (wave >= 4) {
     // ================================ producers ================================================
     const int pw = wave - 4;
+    // The consumer wave on this SIMD keeps the matrix pipe saturated and, being the older wave,
+    // wins every arbitration: without a raised priority the producer's dozen MFMAs per tile only
+    // issue once the consumer's loop has ended and the two roles serialise.  The priority is
+    // raised around the MFMAs only; everything else in this role runs in the consumer's shadow.
     const __amdgpu_buffer_rsrc_t rs_x =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
     // conv1_1 weights as the A operand: wf[t][s] element e <-> cout = 32 t + l31, k = 16 s + 8 half + e
@@ -880,59 +897,101 @@ __global__ __launch_bounds__(512) void vgg_stem_kernel(StemParams p) {
       for (int r = 0; r < 16; ++r) bb[t][r] = p.b1[32 * t + acc_row(r, lane)];
     const int plane = p.H * p.W;
 
-    auto produce = [&](int tile, char* buf) __attribute__((always_inline)) {
+    // Tile-independent lane geometry.  Block b of this wave covers halo pixels r = 32 b + l31
+    // (clamped to the last pixel for the 12 surplus lanes of block 10: they load valid data that is
+    // never written).  g_rel = element offset of the pixel from the tile's halo origin, g_dk[j] =
+    // element offset of input element k(j) from the pixel (j = 8 s + e, k = 16 s + 8 half + e;
+    // slots with k >= 27 carry zero weights and simply re-read a valid tap of the same window).
+    int g_row[3], g_swz[3], g_hy[3], g_hx[3], g_rel[3];
+#pragma unroll
+    for (int bi = 0; bi < 3; ++bi) {
+      const int r = 32 * (pw + 4 * bi) + l31;
+      const int rc = r < ST_HALO_PX ? r : ST_HALO_PX - 1;
+      g_row[bi] = r;
+      g_hy[bi] = rc / C64_HW;
+      g_hx[bi] = rc - g_hy[bi] * C64_HW;
+      g_swz[bi] = c64_swz(g_hy[bi], g_hx[bi]);
+      g_rel[bi] = g_hy[bi] * p.W + g_hx[bi];
+      asm volatile("" : "+v"(g_rel[bi]));
+    }
+    int g_dk[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      int k = 16 * (j >> 3) + 8 * half + (j & 7);
+      if (k >= 27) k -= 8;
+      const int c = k / 9, t = k - 9 * c;
+      g_dk[j] = c * plane + (t / 3 - 1) * p.W + (t % 3 - 1);
+      asm volatile("" : "+v"(g_dk[j]));  // keep it in a register: re-deriving it costs a v_mul per load
+    }
+    auto tap_of = [&](int j) __attribute__((always_inline)) {  // border tiles only
+      const int kA = 16 * (j >> 3) + (j & 7), kB = kA + 8 >= 27 ? kA : kA + 8;
+      return half ? kB % 9 : kA % 9;
+    };
+
+    float xv[3][16];
+    auto decode = [&](int tile, int& n, int& ty, int& tx) __attribute__((always_inline)) {
       const unsigned r2 = (unsigned)tile / (unsigned)p.tiles_x;
-      const int tx = tile - (int)r2 * p.tiles_x;
-      const int n = (int)(r2 / (unsigned)p.tiles_y), ty = (int)r2 - n * p.tiles_y;
+      tx = tile - (int)r2 * p.tiles_x;
+      n = (int)(r2 / (unsigned)p.tiles_y);
+      ty = (int)r2 - n * p.tiles_y;
+    };
+    // a tile is interior when every halo pixel and every tap of every halo pixel lies in the image
+    auto is_interior = [&](int ty, int tx) __attribute__((always_inline)) {
+      return ty >= 1 && ty * 8 + 10 <= p.H && tx >= 1 && tx * 32 + 34 <= p.W;
+    };
+    // issue the input gathers of one tile (48 coalesced dword loads per lane); nothing waits here
+    auto issue_loads = [&](int tile) __attribute__((always_inline)) {
+      int n, ty, tx;
+      decode(tile, n, ty, tx);
       const int y0 = ty * 8 - 1, x0 = tx * 32 - 1;
-      float xv[3][16];
-      bool pix_ok[3];
-      int hrow[3], hswz[3];
+      const int origin = ((n * 3) * p.H + y0) * p.W + x0;  // may be "negative" for border tiles
+      if (is_interior(ty, tx)) {
 #pragma unroll
-      for (int bi = 0; bi < 3; ++bi) {
-        const int b = pw + 4 * bi;  // wave-uniform
-        const int r = 32 * b + l31;
-        const int hy = r / C64_HW, hx = r - hy * C64_HW;
-        const int y = y0 + hy, x = x0 + hx;
-        hrow[bi] = r;
-        hswz[bi] = c64_swz(hy, hx);
-        pix_ok[bi] = b < ST_BLOCKS && r < ST_HALO_PX && y >= 0 && y < p.H && x >= 0 && x < p.W;
-        // validity of the three input rows / columns around (y, x); an invalid tap or a pixel
-        // that is not produced at all loads from an out-of-range offset (-> 0.0f)
-        unsigned mk = 0;
-        if (pix_ok[bi]) {
-          const bool ya = y > 0, yc = y + 1 < p.H, xa = x > 0, xc = x + 1 < p.W;
-          mk = (ya && xa ? 1u : 0u) | (ya ? 2u : 0u) | (ya && xc ? 4u : 0u) | (xa ? 8u : 0u) | 16u |
-               (xc ? 32u : 0u) | (yc && xa ? 64u : 0u) | (yc ? 128u : 0u) | (yc && xc ? 256u : 0u);
+        for (int bi = 0; bi < 3; ++bi) {
+          if (pw + 4 * bi >= ST_BLOCKS) continue;  // wave-uniform
+          const int base = origin + g_rel[bi];
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            xv[bi][j] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (base + g_dk[j]) * 4, 0, 0));
         }
-        const int base = ((n * 3) * p.H + y) * p.W + x;  // element index of (n, c = 0, y, x)
-        if (b >= ST_BLOCKS) continue;  // wave-uniform: this wave has no third block
+      } else {
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            // k = 16 s + 8 half + e: two compile-time candidates, selected by the lane half
-            const int kA = 16 * s + e, kB = kA + 8;
-            const int cA = kA / 9, tA = kA % 9, cB = kB / 9, tB = kB % 9;
-            const int dA = cA * plane + (tA / 3 - 1) * p.W + (tA % 3 - 1);
-            const int dB = cB * plane + (tB / 3 - 1) * p.W + (tB % 3 - 1);
-            const bool okA = kA < 27 && ((mk >> tA) & 1u), okB = kB < 27 && ((mk >> tB) & 1u);
-            const bool ok = half ? okB : okA;
-            const unsigned off = ok ? (unsigned)(base + (half ? dB : dA)) * 4u : ST_OOB;
-            xv[bi][8 * s + e] = __builtin_bit_cast(
-                float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)off, 0, 0));
+        for (int bi = 0; bi < 3; ++bi) {
+          if (pw + 4 * bi >= ST_BLOCKS) continue;
+          const int y = y0 + g_hy[bi], x = x0 + g_hx[bi];
+          unsigned mk = 0;
+          if (y >= 0 && y < p.H && x >= 0 && x < p.W) {
+            const bool ya = y > 0, yc = y + 1 < p.H, xa = x > 0, xc = x + 1 < p.W;
+            mk = (ya && xa ? 1u : 0u) | (ya ? 2u : 0u) | (ya && xc ? 4u : 0u) | (xa ? 8u : 0u) | 16u |
+                 (xc ? 32u : 0u) | (yc && xa ? 64u : 0u) | (yc ? 128u : 0u) | (yc && xc ? 256u : 0u);
           }
+          const int base = origin + g_rel[bi];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const unsigned off = ((mk >> tap_of(j)) & 1u) ? (unsigned)(base + g_dk[j]) * 4u : ST_OOB;
+            xv[bi][j] = __builtin_bit_cast(float,
+                                           __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)off, 0, 0));
+          }
+        }
       }
+    };
+    // conv1_1 on the loaded window, bias + ReLU + bf16, halo tile -> LDS
+    auto finish = [&](int tile, char* buf) __attribute__((always_inline)) {
+      int n, ty, tx;
+      decode(tile, n, ty, tx);
+      const int y0 = ty * 8 - 1, x0 = tx * 32 - 1;
+      const bool interior = is_interior(ty, tx);
 #pragma unroll
       for (int bi = 0; bi < 3; ++bi) {
-        const int b = pw + 4 * bi;
-        if (b >= ST_BLOCKS) continue;  // wave-uniform
+        if (pw + 4 * bi >= ST_BLOCKS) continue;  // wave-uniform
         bf16x8_t xf[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
           for (int e = 0; e < 8; ++e) xf[s][e] = (short)f32_to_bf16_bits(xv[bi][8 * s + e]);
         f32x16_t acc[2];
+        __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -941,32 +1000,57 @@ __global__ __launch_bounds__(512) void vgg_stem_kernel(StemParams p) {
           for (int s = 0; s < 2; ++s)
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][s], xf[s], acc[t], 0, 0, 0);
         }
+        __builtin_amdgcn_s_setprio(0);
         // D[row = cout][col = pixel]: registers 4g..4g+3 = couts 32 t + 8 g + 4 half + 0..3 of the
-        // lane's pixel -> 8 bytes of its 128-byte halo row, 16-B slot 4 t + g (swizzled), +8 half
-        if (hrow[bi] < ST_HALO_PX) {
-          char* row = buf + hrow[bi] * 128 + 8 * half;
+        // lane's pixel -> 8 bytes of its 128-byte halo row, 16-B slot 4 t + g (swizzled), +8 half.
+        // A halo pixel outside the image is conv1_2's zero padding, not a conv1_1 output.
+        const int y = y0 + g_hy[bi], x = x0 + g_hx[bi];
+        const bool pix_ok = interior || (y >= 0 && y < p.H && x >= 0 && x < p.W);
+        if (g_row[bi] < ST_HALO_PX) {
+          char* row = buf + g_row[bi] * 128 + 8 * half;
 #pragma unroll
           for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-              uint2 v = make_uint2(0u, 0u);
-              if (pix_ok[bi]) {
-                v.x = pack_bf16x2(fmaxf(acc[t][4 * g], 0.f), fmaxf(acc[t][4 * g + 1], 0.f));
-                v.y = pack_bf16x2(fmaxf(acc[t][4 * g + 2], 0.f), fmaxf(acc[t][4 * g + 3], 0.f));
-              }
-              *reinterpret_cast<uint2*>(row + (((4 * t + g) ^ hswz[bi]) << 4)) = v;
+              uint2 v;
+              v.x = relu_bf16x2(pack_bf16x2(acc[t][4 * g], acc[t][4 * g + 1]));
+              v.y = relu_bf16x2(pack_bf16x2(acc[t][4 * g + 2], acc[t][4 * g + 3]));
+              if (!pix_ok) v = make_uint2(0u, 0u);
+              *reinterpret_cast<uint2*>(row + (((4 * t + g) ^ g_swz[bi]) << 4)) = v;
             }
         }
       }
     };
 
-    if (niter > 0) produce(first, hb);
+    const bool prof = p.prof != nullptr && blockIdx.x == 0 && wave == 4;
+    unsigned long long pt[2] = {0, 0};
+    // producer runs one tile ahead of the consumers; the gathers of the tile after that are
+    // already in flight while it waits at the hand-over barrier
+    if (niter > 0) {
+      issue_loads(first);
+      finish(first, hb);
+      if (niter > 1) issue_loads(first + stride);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     for (int it = 0; it < niter; ++it) {
-      if (it + 1 < niter) produce(first + (it + 1) * stride, hb + ((it + 1) & 1) * ST_HALO_BYTES);
+      const unsigned long long t0 = prof ? __builtin_amdgcn_s_memtime() : 0;
+      if (it + 1 < niter) {
+        finish(first + (it + 1) * stride, hb + ((it + 1) & 1) * ST_HALO_BYTES);
+        if (it + 2 < niter) issue_loads(first + (it + 2) * stride);
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const unsigned long long t1 = prof ? __builtin_amdgcn_s_memtime() : 0;
       __builtin_amdgcn_s_barrier();
+      if (prof) {
+        const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+        pt[0] += t1 - t0;
+        pt[1] += t2 - t1;
+      }
+    }
+    if (prof && lane == 0) {
+      p.prof[4] = pt[0];
+      p.prof[5] = pt[1];
     }
     return;
   }
@@ -995,9 +1079,12 @@ __global__ __launch_bounds__(512) void vgg_stem_kernel(StemParams p) {
 #pragma unroll
   for (int tn = 0; tn < 2; ++tn) bvals[tn] = p.b2[tn * 32 + l31];
 
+  const bool cprof = p.prof != nullptr && blockIdx.x == 0 && wave == 0;
+  unsigned long long ct[3] = {0, 0, 0};
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   for (int it = 0; it < niter; ++it) {
+    const unsigned long long c0 = cprof ? __builtin_amdgcn_s_memtime() : 0;
     const int tile = first + it * stride;
     const char* const cur = hb + (it & 1) * ST_HALO_BYTES;
     f32x16_t acc[2][2];
@@ -1035,20 +1122,26 @@ __global__ __launch_bounds__(512) void vgg_stem_kernel(StemParams p) {
     }
     // all fragment reads of `cur` have been consumed by the MFMAs above: hand the buffer back
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long c1 = cprof ? __builtin_amdgcn_s_memtime() : 0;
     __builtin_amdgcn_s_barrier();
+    const unsigned long long c2 = cprof ? __builtin_amdgcn_s_memtime() : 0;
     // pooled epilogue straight from registers: lanes 0-31 / 32-63 each write the 32 channels of one
     // pooled pixel (64 contiguous bytes); the two tn halves complete the 128-byte line
     const unsigned r2 = (unsigned)tile / (unsigned)p.tiles_x;
     const int tx = tile - (int)r2 * p.tiles_x;
     const int n = (int)(r2 / (unsigned)p.tiles_y), ty = (int)r2 - n * p.tiles_y;
     const int oy = ty * 4 + wave;
+    // lane's first pooled pixel (i = g = 0) of this wave's pooled row; pixel (i, g) is 8 i + 2 g
+    // pixels = (8 i + 2 g) * 128 bytes further: immediate offsets on one base address
+    char* const obase = p.out + ((((long)n * Ho + oy) * Wo + tx * 16 + half) * 64 + l31) * 2;
+    const bool full = oy < Ho && tx * 16 + 16 <= Wo;  // wave-uniform: no per-pixel predicate
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int ox = tx * 16 + 8 * i + 2 * g + half;
-        if (oy < Ho && ox < Wo) {
-          uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + (((long)n * Ho + oy) * Wo + ox) * 64 + l31;
+        if (full || (oy < Ho && ox < Wo)) {
+          uint16_t* o = reinterpret_cast<uint16_t*>(obase + (8 * i + 2 * g) * 128);
 #pragma unroll
           for (int tn = 0; tn < 2; ++tn) {
             const float v = fmaxf(fmaxf(acc[i][tn][4 * g], acc[i][tn][4 * g + 1]),
@@ -1057,6 +1150,17 @@ __global__ __launch_bounds__(512) void vgg_stem_kernel(StemParams p) {
           }
         }
       }
+    if (cprof) {
+      const unsigned long long c3 = __builtin_amdgcn_s_memtime();
+      ct[0] += c1 - c0;
+      ct[1] += c2 - c1;
+      ct[2] += c3 - c2;
+    }
+  }
+  if (cprof && lane == 0) {
+    p.prof[0] = ct[0];
+    p.prof[1] = ct[1];
+    p.prof[2] = ct[2];
   }
 }
 
@@ -1078,6 +1182,7 @@ static int launch_vgg_stem(const float* x, int N, int H, int W, const float* w1,
   const long nt = (long)N * p.tiles_x * p.tiles_y;
   OIBL_REQUIRE(nt < 0x7fffffffL, "vgg stem: too many tiles");
   p.ntiles = (int)nt;
+  p.prof = g_prof_buf;
   int gx = 256;  // one persistent workgroup per CU
   if (gx > p.ntiles) gx = p.ntiles;
   static bool attr_done = false;
