@@ -174,6 +174,23 @@ int oibl_pairwise_sqdist(const float* x, int m, const float* y, int n, int d,
                          int precision, float* dist, size_t ldd, void* ws, size_t ws_bytes,
                          void* stream);
 
+/* Fused distance + top-k: the k nearest gallery rows of every query without materialising the
+ * [m][n] matrix — what Evaluator.evaluate / evaluate_all need from pairwise_distance + argsort
+ * (ibl/evaluators.py:122-129, 143-159) when only ranks are consumed.
+ *   out_val [m][k] fp32 ascending, out_idx [m][k] int32 = index_base + gallery row; ties broken
+ *   by lowest index; n < k pads with (+inf, -1).  Same arithmetic as oibl_pairwise_sqdist, so the
+ *   result equals oibl_row_topk applied to its matrix.
+ * OIBL_BF16, large galleries: thresholds from a strided gallery sample, one filtered pass of the
+ * distance kernel that appends only candidates, exact selection over the candidates.  A candidate
+ * list that outgrows its capacity (possible only for degenerate data, e.g. thousands of duplicate
+ * rows) sets *overflow (device int32, may be NULL) to 1 and leaves that call's outputs undefined:
+ * repeat the call with exact = 1, which materialises distance tiles inside the workspace (always
+ * used for OIBL_F32 and small problems; *overflow stays 0).                                   */
+size_t oibl_sqdist_topk_workspace_bytes(int m, int n, int d, int k, int precision);
+int oibl_sqdist_topk(const float* x, int m, const float* y, int n, int d, int k, int index_base,
+                     int precision, int exact, float* out_val, int32_t* out_idx, int32_t* overflow,
+                     void* ws, size_t ws_bytes, void* stream);
+
 /* ---- top-k ------------------------------------------------------------------------ *
  * Replaces np.argsort(distmat, axis=1) (ibl/evaluators.py:143), of which evaluate_all only
  * consumes the first max(recall_topk) (or 12x that with nms) entries per row.

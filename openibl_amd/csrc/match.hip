@@ -2,6 +2,7 @@
 // Reference behaviour: pairwise_distance (ibl/evaluators.py:105-130) and the argsort consumed by
 // evaluate_all (ibl/evaluators.py:142-159).
 #include "gemm_core.h"
+#include "ring_core.h"
 
 namespace oibl {
 
@@ -75,6 +76,145 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void pairwise_kernel(PairParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// bf16 distance kernel on the ring schedule (ring_core.h): 256 x 256 tile, A = queries, B = gallery,
+// K = d.  Same K order and the same epilogue expression as pairwise_kernel -> identical matrices.
+// Tile order: the hardware deals block b to XCD b % 8; every XCD gets a contiguous range of tile
+// ids, and ids walk groups of 8 query tiles x all gallery tiles with the query tile fastest, so the
+// 32 workgroups resident on an XCD form an 8 x 4 block of tiles that shares 8 query panels and 4
+// gallery panels through that XCD's L2 (12 panel streams for 32 tiles instead of 33-64).
+//   FILTER = false: write dist[m][ldd].
+//   FILTER = true : fused top-k front end.  thr[row] is an upper bound of the row's k-th smallest
+//     distance (k-th smallest over a strided sample of the gallery, computed with this same kernel,
+//     so the sample's own distances reappear bit for bit); every distance <= thr[row] is appended
+//     to the row's candidate list (value, global index).  The matrix is never written: for
+//     8192 x 81920 the candidates are ~1 % of its 2.7 GB.  Lists that outgrow `cap` are counted,
+//     not stored (the caller sees cnt > cap and falls back to the exact path).
+// ---------------------------------------------------------------------------------------------
+struct PairRingParams {
+  const void* x;  // [m][d] bf16
+  const void* y;  // [n rows at y_row_bytes][d] bf16
+  const float* xn;
+  const float* yn;  // yn[col * yn_stride]
+  float* dist;
+  size_t ldd;
+  unsigned x_bytes, y_bytes;
+  long y_row_bytes;
+  int yn_stride;
+  int m, n, d, tiles_m, tiles_n;
+  const float* thr;  // thr[row * thr_stride]
+  int thr_stride;
+  float* cand_val;
+  int32_t* cand_idx;
+  int* cand_cnt;
+  int cap, index_base, index_stride;  // global index of column c = index_base + c * index_stride
+};
+
+template <bool FILTER>
+__global__ __launch_bounds__(512) void pairwise_ring_kernel(PairRingParams p) {
+  using G = RingGeo<2>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / G::WN, wn = wave % G::WN;
+  const unsigned id = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned width = 8u * (unsigned)p.tiles_n;
+  const unsigned grp = id / width, in_grp = id - grp * width;
+  const unsigned first_m = grp * 8u;
+  const unsigned gsz = (unsigned)p.tiles_m - first_m < 8u ? (unsigned)p.tiles_m - first_m : 8u;
+  const int tm = (int)(first_m + in_grp % gsz), tn = (int)(in_grp / gsz);
+  const int m0 = tm * G::BM, n0 = tn * G::BN;
+
+  const int piece = ring_piece(wave, lane);
+  int rows_a[4], rows_b[4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      rows_a[2 * h + i] = ring_a_row<2>(wave, lane, h, i);
+      rows_b[2 * h + i] = ring_b_row<2>(wave, lane, h, i);
+    }
+  RingRowLoader<2> la, lb;
+  la.init(p.x, p.x_bytes, m0, p.m, (long)p.d * 2, rows_a, piece);
+  lb.init(p.y, p.y_bytes, n0, p.n, p.y_row_bytes, rows_b, piece);
+
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  ring_mainloop<2, false>(acc, smem, wave, lane, la, lb, p.d >> 6);
+
+  // norms (and thresholds) of the tile's rows / columns -> LDS; out-of-range rows/columns are
+  // clamped here and masked at the store
+  float* const xn_s = reinterpret_cast<float*>(smem);
+  float* const yn_s = xn_s + 256;
+  float* const th_s = xn_s + 512;
+  if (threadIdx.x < 256) {
+    int r = m0 + (int)threadIdx.x;
+    if (r > p.m - 1) r = p.m - 1;
+    xn_s[threadIdx.x] = p.xn[r];
+    if (FILTER) th_s[threadIdx.x] = p.thr[(long)r * p.thr_stride];
+  } else {
+    int c = n0 + (int)threadIdx.x - 256;
+    if (c > p.n - 1) c = p.n - 1;
+    yn_s[threadIdx.x - 256] = p.yn[(long)c * p.yn_stride];
+  }
+  __syncthreads();
+  // lane geometry: column col0 + 32 j, rows row0 + 32 i + (r & 3) + 8 (r >> 2)
+  const int col0 = wn * 64 + (lane & 31), row0 = wm * 128 + 4 * (lane >> 5);
+  if constexpr (!FILTER) {
+    // stores go through a buffer descriptor based at the tile's first element: one 32-bit lane
+    // offset, everything else is scalar (the host guarantees 256 * ldd * 4 < 2^31)
+    const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(
+        p.dist + (size_t)m0 * p.ldd + n0, 0, 0x7fffffff, 0x00020000);
+    const unsigned ldd4 = (unsigned)p.ldd * 4u;
+    const unsigned voff = (unsigned)row0 * ldd4 + (unsigned)col0 * 4u;
+    const int rows_left = p.m - m0 - row0;  // row r of this lane is valid iff its offset < rows_left
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool nok = n0 + col0 + 32 * j < p.n;
+      const float yn = yn_s[col0 + 32 * j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ro = 32 * i + (r & 3) + 8 * (r >> 2);
+          const float dv = fmaf(-2.0f, acc[i][j][r], xn_s[row0 + ro] + yn);
+          if (nok && ro < rows_left)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dv), rs_d, (int)voff,
+                                                  (int)((unsigned)ro * ldd4 + 128u * j), 0);
+        }
+    }
+  } else {
+    const int rows_left = p.m - m0 - row0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + col0 + 32 * j;
+      const bool nok = n < p.n;
+      const float yn = yn_s[col0 + 32 * j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ro = 32 * i + (r & 3) + 8 * (r >> 2);
+          const float dv = fmaf(-2.0f, acc[i][j][r], xn_s[row0 + ro] + yn);
+          if (nok && ro < rows_left && dv <= th_s[row0 + ro]) {
+            const int m = m0 + row0 + ro;
+            const int pos = atomicAdd(p.cand_cnt + m, 1);
+            if (pos < p.cap) {
+              p.cand_val[(size_t)m * p.cap + pos] = dv;
+              p.cand_idx[(size_t)m * p.cap + pos] = p.index_base + n * p.index_stride;
+            }
+          }
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // per-row top-k (k smallest, ascending, lowest index first on ties)
 // One workgroup per row.  Every element becomes a 64-bit key (order-preserving bits of the value
 // << 32 | index); a running threshold (the k-th best key so far) filters the stream, survivors
@@ -115,17 +255,25 @@ __device__ static inline void bitonic_sort_lds(unsigned long long* buf, int n_po
   }
 }
 
+// row_n (optional): per-row element count (clamped to n); a count above n raises *overflow.
 __global__ __launch_bounds__(256) void row_topk_kernel(const float* __restrict__ vals,
                                                        const int32_t* __restrict__ idx_in, int n,
                                                        size_t ld, int k, int index_base,
                                                        float* __restrict__ out_val,
-                                                       int32_t* __restrict__ out_idx) {
+                                                       int32_t* __restrict__ out_idx,
+                                                       const int* __restrict__ row_n,
+                                                       int* __restrict__ overflow) {
   __shared__ unsigned long long cand[TOPK_CAP];
   __shared__ int cnt;
   __shared__ unsigned long long thr;
   const int row = blockIdx.x, tid = threadIdx.x;
   const float* vr = vals + (size_t)row * ld;
   const int32_t* ir = idx_in ? idx_in + (size_t)row * ld : nullptr;
+  if (row_n) {
+    const int have_n = row_n[row];
+    if (have_n > n && tid == 0 && overflow) atomicOr(overflow, 1);
+    n = have_n < n ? have_n : n;
+  }
   if (tid == 0) {
     cnt = 0;
     thr = TOPK_INF;
@@ -179,6 +327,13 @@ using namespace oibl;
 
 extern "C" {
 
+static int g_match_ring = 1;  // test hook: 0 = never, 1 = auto, 2 = whenever legal
+
+int oibl_debug_set_match_ring(int mode) {
+  g_match_ring = mode;
+  return OIBL_OK;
+}
+
 static size_t pw_off_yn(int m) { return align_up((size_t)m * sizeof(float), 256); }
 static size_t pw_off_xt(int m, int n) { return pw_off_yn(m) + align_up((size_t)n * sizeof(float), 256); }
 
@@ -190,31 +345,52 @@ size_t oibl_pairwise_workspace_bytes(int m, int n, int d, int precision) {
   return b;
 }
 
-int oibl_pairwise_sqdist(const float* x, int m, const float* y, int n, int d, int precision,
-                         float* dist, size_t ldd, void* ws, size_t ws_bytes, void* stream) {
-  OIBL_REQUIRE(x && y && dist && ws, "pairwise: null pointer");
-  OIBL_REQUIRE(precision == OIBL_BF16 || precision == OIBL_F32, "pairwise: bad precision %d",
-               precision);
-  OIBL_REQUIRE(m > 0 && n > 0 && d > 0 && d % 64 == 0 && ldd >= (size_t)n,
-               "pairwise: unsupported shape m=%d n=%d d=%d ldd=%zu", m, n, d, ldd);
-  OIBL_REQUIRE((uintptr_t)ws % 256 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0,
-               "pairwise: workspace must be 256-byte, x and y 16-byte aligned");
-  const size_t need = oibl_pairwise_workspace_bytes(m, n, d, precision);
-  if (ws_bytes < need) {
-    set_error("pairwise: workspace %zu < required %zu bytes", ws_bytes, need);
-    return OIBL_E_WORKSPACE;
+// ring kernel legality: bf16, an even number (>= 4) of 64-element K-tiles, 32-bit buffer offsets
+static bool pair_ring_legal(int m, int n, int d) {
+  const int ksteps = d / 64;
+  return d % 64 == 0 && ksteps >= 4 && (ksteps & 1) == 0 && (size_t)m * d * 2 < (size_t)0xE0000000u &&
+         (size_t)n * d * 2 < (size_t)0xE0000000u && n <= (1 << 20) && !g_regstage;
+}
+static bool pair_ring_wanted(int m, int n, int d) {
+  if (!g_match_ring || !pair_ring_legal(m, n, d)) return false;
+  // below ~64 tiles of 256 x 256 the 128 x 128 kernel fills the chip better
+  return g_match_ring == 2 || (long)((m + 255) / 256) * ((n + 255) / 256) >= 64;
+}
+
+extern "C++" {
+template <bool FILTER>
+static int launch_pairwise_ring(PairRingParams& p, hipStream_t st) {
+  p.tiles_m = (p.m + 255) / 256;
+  p.tiles_n = (p.n + 255) / 256;
+  const long grid = (long)p.tiles_m * p.tiles_n;
+  OIBL_REQUIRE(grid > 0 && grid <= 0x7fffffffL, "pairwise: grid out of range");
+  constexpr int lds = RingGeo<2>::MAIN_LDS;
+  auto kern = pairwise_ring_kernel<FILTER>;
+  static bool done = false;
+  if (!done) {
+    OIBL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    done = true;
   }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, p);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
+}  // extern "C++"
+
+// norms + (bf16) operand copies into the workspace; fills p.x / p.y / p.xn / p.yn
+static int pairwise_prepare(const float* x, int m, const float* y, int n, int d, int precision,
+                            char* wsb, const void** xo, const void** yo, float** xn, float** yn,
+                            void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  char* wsb = (char*)ws;
-  PairParams p;
-  p.xn = (float*)wsb;
-  p.yn = (float*)(wsb + pw_off_yn(m));
-  hipLaunchKernelGGL(row_sqnorm_kernel, dim3((m + 3) / 4), dim3(256), 0, st, x, (float*)p.xn, m, d);
+  *xn = (float*)wsb;
+  *yn = (float*)(wsb + pw_off_yn(m));
+  hipLaunchKernelGGL(row_sqnorm_kernel, dim3((m + 3) / 4), dim3(256), 0, st, x, *xn, m, d);
   OIBL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(row_sqnorm_kernel, dim3((n + 3) / 4), dim3(256), 0, st, y, (float*)p.yn, n, d);
+  hipLaunchKernelGGL(row_sqnorm_kernel, dim3((n + 3) / 4), dim3(256), 0, st, y, *yn, n, d);
   OIBL_LAUNCH_CHECK();
-  p.x = x;
-  p.y = y;
+  *xo = x;
+  *yo = y;
   if (precision == OIBL_BF16) {
     uint16_t* xt = (uint16_t*)(wsb + pw_off_xt(m, n));
     uint16_t* yt = (uint16_t*)((char*)xt + align_up((size_t)m * d * 2, 256));
@@ -222,16 +398,47 @@ int oibl_pairwise_sqdist(const float* x, int m, const float* y, int n, int d, in
     if (rc) return rc;
     rc = oibl_cast_f32_to_bf16(y, yt, (size_t)n * d, stream);
     if (rc) return rc;
-    p.x = xt;
-    p.y = yt;
+    *xo = xt;
+    *yo = yt;
   }
+  return OIBL_OK;
+}
+
+// dist[m rows starting at row0][ldd] from prepared operands
+static int pairwise_launch(const void* xo, const void* yo, const float* xn, const float* yn, int row0,
+                           int rows, int m_all, int n, int d, int precision, float* dist, size_t ldd,
+                           hipStream_t st) {
+  const size_t es = oibl_elem_size(precision);
+  if (precision == OIBL_BF16 && pair_ring_wanted(rows, n, d) && ldd <= ((size_t)1 << 20)) {
+    PairRingParams q = {};
+    q.x = (const char*)xo + (size_t)row0 * d * 2;
+    q.y = yo;
+    q.xn = xn + row0;
+    q.yn = yn;
+    q.dist = dist;
+    q.ldd = ldd;
+    q.x_bytes = (unsigned)((size_t)rows * d * 2);
+    q.y_bytes = (unsigned)((size_t)n * d * 2);
+    q.y_row_bytes = (long)d * 2;
+    q.yn_stride = 1;
+    q.m = rows;
+    q.n = n;
+    q.d = d;
+    return launch_pairwise_ring<false>(q, st);
+  }
+  PairParams p;
+  p.x = (const char*)xo + (size_t)row0 * d * es;
+  p.y = yo;
+  p.xn = xn + row0;
+  p.yn = yn;
   p.dist = dist;
   p.ldd = ldd;
-  p.m = m;
+  p.m = rows;
   p.n = n;
   p.d = d;
   p.tiles_n = (n + 127) / 128;
-  const long grid = (long)((m + 127) / 128) * p.tiles_n;
+  (void)m_all;
+  const long grid = (long)((rows + 127) / 128) * p.tiles_n;
   OIBL_REQUIRE(grid <= 0x7fffffffL, "pairwise: grid too large");
   if (precision == OIBL_BF16) {
     using Cfg = GemmCfg<bf16_t, 2, 2, 2, 2>;
@@ -254,13 +461,175 @@ int oibl_pairwise_sqdist(const float* x, int m, const float* y, int n, int d, in
   return OIBL_OK;
 }
 
+int oibl_pairwise_sqdist(const float* x, int m, const float* y, int n, int d, int precision,
+                         float* dist, size_t ldd, void* ws, size_t ws_bytes, void* stream) {
+  OIBL_REQUIRE(x && y && dist && ws, "pairwise: null pointer");
+  OIBL_REQUIRE(precision == OIBL_BF16 || precision == OIBL_F32, "pairwise: bad precision %d",
+               precision);
+  OIBL_REQUIRE(m > 0 && n > 0 && d > 0 && d % 64 == 0 && ldd >= (size_t)n,
+               "pairwise: unsupported shape m=%d n=%d d=%d ldd=%zu", m, n, d, ldd);
+  OIBL_REQUIRE((uintptr_t)ws % 256 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0,
+               "pairwise: workspace must be 256-byte, x and y 16-byte aligned");
+  const size_t need = oibl_pairwise_workspace_bytes(m, n, d, precision);
+  if (ws_bytes < need) {
+    set_error("pairwise: workspace %zu < required %zu bytes", ws_bytes, need);
+    return OIBL_E_WORKSPACE;
+  }
+  const void *xo, *yo;
+  float *xn, *yn;
+  int rc = pairwise_prepare(x, m, y, n, d, precision, (char*)ws, &xo, &yo, &xn, &yn, stream);
+  if (rc) return rc;
+  return pairwise_launch(xo, yo, xn, yn, 0, m, m, n, d, precision, dist, ldd, (hipStream_t)stream);
+}
+
+// ---- fused distance + top-k -------------------------------------------------------------------
+// Plan of one call (all sizes derived from m, n, d, k, precision only, so that the workspace query
+// and the call agree):
+//   fused (bf16, ring kernel legal, gallery large enough to sample):
+//     S = sample size, cap = candidate capacity per query
+//   exact: distance tiles of `chunk` query rows are materialised in the workspace and reduced
+//     with row_topk (the only path in fp32 mode; the fallback when a candidate list overflows).
+struct TopkPlan {
+  bool fused;
+  int S, stride, cap, chunk;
+  size_t off_prep, off_sample, off_sval, off_sidx, off_cnt, off_cval, off_cidx, off_chunk, total;
+};
+static TopkPlan topk_plan(int m, int n, int d, int k, int precision) {
+  TopkPlan t = {};
+  int S = 1024;
+  while (S < 4 * k) S *= 2;
+  t.fused = precision == OIBL_BF16 && g_match_ring && pair_ring_legal(m, n, d) && n >= 8 * S &&
+            (long)((m + 255) / 256) * ((n + 255) / 256) >= 64;
+  t.S = S;
+  t.stride = n / S;                       // sample = gallery rows 0, stride, 2 stride, ...
+  const long expect = (long)k * t.stride + k;  // ~ n k / S survivors per query
+  long cap = 4096;
+  while (cap < 6 * expect) cap *= 2;
+  t.cap = (int)cap;
+  long chunk = ((long)1 << 28) / n;       // <= 1 GiB of distances at a time
+  if (chunk < 1) chunk = 1;
+  if (chunk > m) chunk = m;
+  t.chunk = (int)chunk;
+  size_t o = 0;
+  t.off_prep = o;
+  o += align_up(oibl_pairwise_workspace_bytes(m, n, d, precision), 256);
+  t.off_sample = o;
+  o += align_up((size_t)m * S * sizeof(float), 256);
+  t.off_sval = o;
+  o += align_up((size_t)m * k * sizeof(float), 256);
+  t.off_sidx = o;
+  o += align_up((size_t)m * k * sizeof(int32_t), 256);
+  t.off_cnt = o;
+  o += align_up((size_t)(m + 1) * sizeof(int), 256);
+  t.off_cval = o;
+  o += align_up((size_t)m * t.cap * sizeof(float), 256);
+  t.off_cidx = o;
+  o += align_up((size_t)m * t.cap * sizeof(int32_t), 256);
+  t.off_chunk = o;
+  o += align_up((size_t)t.chunk * n * sizeof(float), 256);
+  t.total = o;
+  return t;
+}
+
+size_t oibl_sqdist_topk_workspace_bytes(int m, int n, int d, int k, int precision) {
+  if (m <= 0 || n <= 0 || d <= 0 || k <= 0) return 0;
+  return topk_plan(m, n, d, k, precision).total;
+}
+
+int oibl_sqdist_topk(const float* x, int m, const float* y, int n, int d, int k, int index_base,
+                     int precision, int exact, float* out_val, int32_t* out_idx, int32_t* overflow,
+                     void* ws, size_t ws_bytes, void* stream) {
+  OIBL_REQUIRE(x && y && out_val && out_idx && ws, "sqdist_topk: null pointer");
+  OIBL_REQUIRE(precision == OIBL_BF16 || precision == OIBL_F32, "sqdist_topk: bad precision %d",
+               precision);
+  OIBL_REQUIRE(m > 0 && n > 0 && d > 0 && d % 64 == 0, "sqdist_topk: unsupported shape m=%d n=%d d=%d",
+               m, n, d);
+  OIBL_REQUIRE(k >= 1 && k <= 1024, "sqdist_topk: k=%d outside [1, 1024]", k);
+  OIBL_REQUIRE((long)index_base + n <= 0x7fffffffL, "sqdist_topk: index_base + n overflows int32");
+  OIBL_REQUIRE((uintptr_t)ws % 256 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0,
+               "sqdist_topk: workspace must be 256-byte, x and y 16-byte aligned");
+  const TopkPlan t = topk_plan(m, n, d, k, precision);
+  if (ws_bytes < t.total) {
+    set_error("sqdist_topk: workspace %zu < required %zu bytes", ws_bytes, t.total);
+    return OIBL_E_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  char* wsb = (char*)ws;
+  if (overflow) OIBL_HIP_CHECK(hipMemsetAsync(overflow, 0, sizeof(int32_t), st));
+  const void *xo, *yo;
+  float *xn, *yn;
+  int rc = pairwise_prepare(x, m, y, n, d, precision, wsb + t.off_prep, &xo, &yo, &xn, &yn, stream);
+  if (rc) return rc;
+
+  if (t.fused && !exact) {
+    // 1. thresholds: k-th smallest distance to a strided sample of S gallery rows
+    float* sample = (float*)(wsb + t.off_sample);
+    float* sval = (float*)(wsb + t.off_sval);
+    int32_t* sidx = (int32_t*)(wsb + t.off_sidx);
+    PairRingParams q = {};
+    q.x = xo;
+    q.y = yo;
+    q.xn = xn;
+    q.yn = yn;
+    q.dist = sample;
+    q.ldd = (size_t)t.S;
+    q.x_bytes = (unsigned)((size_t)m * d * 2);
+    q.y_bytes = (unsigned)((size_t)n * d * 2);
+    q.y_row_bytes = (long)d * 2 * t.stride;
+    q.yn_stride = t.stride;
+    q.m = m;
+    q.n = t.S;
+    q.d = d;
+    rc = launch_pairwise_ring<false>(q, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(row_topk_kernel, dim3(m), dim3(256), 0, st, (const float*)sample,
+                       (const int32_t*)nullptr, t.S, (size_t)t.S, k, 0, sval, sidx,
+                       (const int*)nullptr, (int*)nullptr);
+    OIBL_LAUNCH_CHECK();
+    // 2. the full contraction, keeping only distances <= threshold
+    int* cnt = (int*)(wsb + t.off_cnt);
+    OIBL_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)m * sizeof(int), st));
+    q.dist = nullptr;
+    q.y_row_bytes = (long)d * 2;
+    q.yn_stride = 1;
+    q.n = n;
+    q.thr = sval + (k - 1);
+    q.thr_stride = k;
+    q.cand_val = (float*)(wsb + t.off_cval);
+    q.cand_idx = (int32_t*)(wsb + t.off_cidx);
+    q.cand_cnt = cnt;
+    q.cap = t.cap;
+    q.index_base = index_base;
+    q.index_stride = 1;
+    rc = launch_pairwise_ring<true>(q, st);
+    if (rc) return rc;
+    // 3. exact top-k of every candidate list ((value, index) keys: independent of append order)
+    hipLaunchKernelGGL(row_topk_kernel, dim3(m), dim3(256), 0, st, (const float*)q.cand_val,
+                       (const int32_t*)q.cand_idx, t.cap, (size_t)t.cap, k, 0, out_val, out_idx,
+                       (const int*)cnt, (int*)overflow);
+    OIBL_LAUNCH_CHECK();
+    return OIBL_OK;
+  }
+  float* tile = (float*)(wsb + t.off_chunk);
+  for (int r0 = 0; r0 < m; r0 += t.chunk) {
+    const int rows = m - r0 < t.chunk ? m - r0 : t.chunk;
+    rc = pairwise_launch(xo, yo, xn, yn, r0, rows, m, n, d, precision, tile, (size_t)n, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(row_topk_kernel, dim3(rows), dim3(256), 0, st, (const float*)tile,
+                       (const int32_t*)nullptr, n, (size_t)n, k, index_base, out_val + (size_t)r0 * k,
+                       out_idx + (size_t)r0 * k, (const int*)nullptr, (int*)nullptr);
+    OIBL_LAUNCH_CHECK();
+  }
+  return OIBL_OK;
+}
+
 int oibl_row_topk(const float* vals, const int32_t* idx_in, int m, int n, size_t ld, int k,
                   int index_base, float* out_val, int32_t* out_idx, void* stream) {
   OIBL_REQUIRE(vals && out_val && out_idx, "row_topk: null pointer");
   OIBL_REQUIRE(m > 0 && n > 0 && ld >= (size_t)n, "row_topk: bad shape m=%d n=%d ld=%zu", m, n, ld);
   OIBL_REQUIRE(k >= 1 && k <= 1024, "row_topk: k=%d outside [1, 1024]", k);
   hipLaunchKernelGGL(row_topk_kernel, dim3(m), dim3(256), 0, (hipStream_t)stream, vals, idx_in, n,
-                     ld, k, index_base, out_val, out_idx);
+                     ld, k, index_base, out_val, out_idx, (const int*)nullptr, (int*)nullptr);
   OIBL_LAUNCH_CHECK();
   return OIBL_OK;
 }

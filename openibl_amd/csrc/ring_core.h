@@ -1,0 +1,281 @@
+// "Ring" schedule for bf16 NT contractions on gfx950:  C[m][n] += sum_k A[m][k] * B[n][k], one
+// K-tile = 64 bf16 = one 128-byte line per row, 8 waves, 128 x 64 outputs per wave.
+// Users: the implicit-GEMM convolutions (conv_ring.h) and the query x gallery distance kernels
+// (match.hip); they differ in the Loader of each operand and in the epilogue.
+//
+// The generic core (gemm_core.h) drains its LDS-DMA queue (vmcnt(0)) and crosses one workgroup
+// barrier per K-tile, so the whole workgroup waits for the slowest line of every tile.  Here
+//
+//   * a K-tile is staged as four UNITS (A0, A1: the two 64-row halves of every wave row's 128
+//     rows; B0, B1: the two 32-column halves of every wave column's 64 columns), and LDS holds two
+//     K-tiles.  A unit is re-filled two phases after its last fragment read, i.e. with the data of
+//     K-tile t + 2, and is read six phases after it was issued: at any time five units are in
+//     flight, waited for with a COUNTED s_waitcnt vmcnt(N) — the queue is never drained inside
+//     the loop;
+//   * a K-tile is four PHASES, one per 64 x 32 quadrant of the wave's 128 x 64 accumulator
+//     (8 MFMAs 32x32x16 each).  Every phase is a LOAD segment (fragment ds_reads of the operand
+//     half that changes: 8, 4, 8, 4 reads; the LDS-DMA instructions of one unit; the counted wait)
+//     and a COMPUTE segment (lgkmcnt(0); 8 MFMAs), separated by raw s_barriers;
+//   * the two stagger groups (waves 0-3 / 4-7: one wave of each on every SIMD) run ONE BARRIER
+//     APART: while one wave of a SIMD is in its COMPUTE segment the other is in its LOAD segment,
+//     so the matrix pipe of the SIMD always has a wave with operands in registers (s_setprio 1
+//     around the MFMAs lets it win issue arbitration against the loading partner).
+//
+// Hazard rules (cdna_hip_programming.md, "256^2 8-phase template"), with phases numbered globally:
+//   RAW  a unit is read in phase >= w + 1 where w is the phase whose LOAD segment holds the
+//        vmcnt that retires it (own loads) and whose closing barriers make the other waves' loads
+//        visible;  here w = read - 1 and the wait after the phase's own issues leaves exactly the
+//        5 youngest units outstanding.
+//   WAR  a unit is re-staged in phase >= r + 2 where r is the last phase that reads it (the
+//        lagging group retires those reads after the barrier that ends phase r).
+// Unit schedule for K-tile t (phases 4t .. 4t+3), reads / (re)stages:
+//   P0: read A0(t)            stage A1(t+1)          P1: read B1(t)       stage B0(t+2)
+//   P2: read A1(t)            stage A0(t+2)          P3: read B0(t+1)     stage B1(t+2)
+// B0 lives in one of two fragment register sets (X/Y) that swap roles every K-tile, so that the
+// next tile's B0 can be fetched during P3 while the current B0 is still being multiplied.
+//
+// LDS image of a unit: rows of 128 B, 16-B slots XOR-swizzled by ((row >> 1) & 7) — applied on the
+// SOURCE side of the LDS-DMA (the destination is wave-linear) and on the fragment read, so every
+// ds_read_b128 lane group touches 16 distinct bank slots (same image as gemm_core.h).
+//
+// Loader concept (one object per operand, each with its own K cursor):
+//   void begin_tile();                 advance the cursor to the next K-tile; called once per
+//                                      K-tile and operand, before the first stage() of that tile
+//   void stage(int h, char* dst);      issue the N LDS-DMA instructions of half h of the cursor's
+//                                      K-tile; instruction i fills dst + i * 8192 (wave-relative)
+// Both operands are fetched with buffer_load_dwordx4 ... lds (16 B per lane); an offset beyond the
+// descriptor's num_records returns zeros, which is how the convolution pads.
+#pragma once
+
+#include <type_traits>
+
+#include "gemm_core.h"
+
+namespace oibl {
+
+constexpr unsigned RG_OOB = 0xF0000000u;  // voffset that is out of range for every descriptor here
+
+// Geometry of one instantiation.  WM = wave rows (2 or 4); the 8 waves form a WM x (8 / WM) grid,
+// every wave owns 128 x 64 outputs, so the tile is 256 x 256 (WM = 2) or 512 x 128 (WM = 4).
+// Stagger group of a wave = wave >> 2 (waves w and w + 4 share a SIMD).
+template <int WM_>
+struct RingGeo {
+  static constexpr int WM = WM_, WN = 8 / WM_;
+  static constexpr int BM = WM * 128, BN = WN * 64;
+  static constexpr int NA = WM;       // LDS-DMA instructions per wave per A unit (WM * 64 rows)
+  static constexpr int NB = WN / 2;   // ... per B unit (WN * 32 rows)
+  static constexpr int A_UNIT = WM * 64 * 128, B_UNIT = WN * 32 * 128;
+  static constexpr int TILE = 2 * A_UNIT + 2 * B_UNIT;  // one K-tile: A0 A1 B0 B1
+  static constexpr int MAIN_LDS = 2 * TILE;
+  static_assert(WM == 2 || WM == 4, "wave grid");
+};
+
+// Tile row of the unit row this lane fetches with LDS-DMA instruction i of half h.
+//   unit row u = 8 * (wave + 8 i) + (lane >> 3);  A: wave row u >> 6, B: wave column u >> 5.
+template <int WM>
+__device__ static inline int ring_a_row(int wave, int lane, int h, int i) {
+  const int u = 8 * (wave + 8 * i) + (lane >> 3);
+  return (u >> 6) * 128 + h * 64 + (u & 63);
+}
+template <int WM>
+__device__ static inline int ring_b_row(int wave, int lane, int h, int i) {
+  const int u = 8 * (wave + 8 * i) + (lane >> 3);
+  return (u >> 5) * 64 + h * 32 + (u & 31);
+}
+// Byte offset of this lane's (swizzled) 16-B piece inside its row's 128-byte K segment.
+__device__ static inline int ring_piece(int wave, int lane) {
+  return ((lane & 7) ^ (4 * (wave & 1) + (lane >> 4))) * 16;
+}
+
+__device__ static inline void buf_glds16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff,
+                                         char* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(
+      rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+}
+
+template <int N>
+__device__ static inline void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Plain row-major operand: row r of the tile is `base + min(row0 + r, nrows - 1) * ld_bytes`
+// (clamped so that partial tiles never read out of bounds; their results are discarded).
+template <int N_INSTR>
+struct RingRowLoader {
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned voff[2 * N_INSTR];
+  unsigned soff;
+  __device__ inline void init(const void* base, unsigned bytes, long row0, long nrows, long ld_bytes,
+                              const int (&tile_row)[2 * N_INSTR], int piece) {
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 2 * N_INSTR; ++j) {
+      long r = row0 + tile_row[j];
+      if (r > nrows - 1) r = nrows - 1;
+      voff[j] = (unsigned)(r * ld_bytes) + piece;
+    }
+    soff = 0u - 128u;
+  }
+  __device__ inline void begin_tile() { soff += 128u; }
+  __device__ inline void stage(int h, char* dst) const {
+#pragma unroll
+    for (int i = 0; i < N_INSTR; ++i) buf_glds16(rsrc, voff[N_INSTR * h + i], soff, dst + i * 8192);
+  }
+};
+
+// The main loop.  acc[i][j]: 32x32 tile (row tile i of 4, column tile j of 2) of this wave's
+// 128 x 64 block, in the MFMA C/D layout.  nsteps >= 3; ODD = nsteps is odd.
+// On return every wave has passed a workgroup barrier: the staging LDS is free.
+template <int WM, bool ODD, typename LA, typename LB>
+__device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, int wave, int lane,
+                                            LA& la, LB& lb, int nsteps) {
+  using G = RingGeo<WM>;
+  constexpr int NA = G::NA, NB = G::NB;
+  constexpr int OFF_A0 = 0, OFF_A1 = G::A_UNIT, OFF_B0 = 2 * G::A_UNIT,
+                OFF_B1 = 2 * G::A_UNIT + G::B_UNIT;
+  const int wm = wave / G::WN, wn = wave % G::WN;
+  const int group = wave >> 2;
+
+  char* const st_base = smem + wave * 1024;
+  auto stage_a = [&](int buf, int h) __attribute__((always_inline)) {
+    la.stage(h, st_base + buf * G::TILE + (h ? OFF_A1 : OFF_A0));
+  };
+  auto stage_b = [&](int buf, int h) __attribute__((always_inline)) {
+    lb.stage(h, st_base + buf * G::TILE + (h ? OFF_B1 : OFF_B0));
+  };
+
+  int frag_off[4];
+  {
+    const int row = lane & 31, half = lane >> 5, swz = (lane >> 1) & 7;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) frag_off[kk] = row * 128 + (((2 * kk + half) ^ swz) * 16);
+  }
+  const char* const rd_a = smem + wm * 8192;  // + buf * TILE + OFF_A{h} + i2 * 4096
+  const char* const rd_b = smem + wn * 4096;  // + buf * TILE + OFF_B{h}
+
+  bf16x8_t fa[2][4], fbx[4], fby[4];
+  auto read_a = [&](int buf, int h) __attribute__((always_inline)) {
+    const char* s = rd_a + buf * G::TILE + (h ? OFF_A1 : OFF_A0);
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        fa[i2][kk] = *reinterpret_cast<const bf16x8_t*>(s + i2 * 4096 + frag_off[kk]);
+  };
+  auto read_b = [&](int buf, int h, bf16x8_t (&f)[4]) __attribute__((always_inline)) {
+    const char* s = rd_b + buf * G::TILE + (h ? OFF_B1 : OFF_B0);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) f[kk] = *reinterpret_cast<const bf16x8_t*>(s + frag_off[kk]);
+  };
+
+  auto compute = [&](auto h_c, auto j_c, const bf16x8_t (&fb)[4]) __attribute__((always_inline)) {
+    constexpr int h = decltype(h_c)::value, j = decltype(j_c)::value;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2)
+        acc[2 * h + i2][j] =
+            __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i2][kk], fb[kk], acc[2 * h + i2][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto bar = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+
+  // ---- prologue: B0 A0 B1 A1 of K-tile 0, B0 A0 B1 of K-tile 1 (the steady-state issue order)
+  la.begin_tile();
+  lb.begin_tile();
+  stage_b(0, 0);
+  stage_a(0, 0);
+  stage_b(0, 1);
+  stage_a(0, 1);
+  lb.begin_tile();
+  stage_b(1, 0);
+  la.begin_tile();
+  stage_a(1, 0);
+  stage_b(1, 1);
+  wait_vmcnt<2 * NA + 3 * NB>();  // B0(0), A0(0) of this wave have landed
+  bar();
+  read_b(0, 0, fbx);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (group == 1) bar();  // group 1 runs one barrier behind group 0
+
+  // One K-tile = 4 phases.  PAR = tile parity (LDS buffer; which register set holds B0).
+  // TAIL: 0 = steady state, 1 = tile nsteps-2, 2 = tile nsteps-1 (nothing left to stage).
+  // The counted waits leave exactly the five youngest units in flight (steady state); in the tail
+  // the units that are no longer issued are subtracted.
+  // Cursor discipline: A1(t+1) is staged (P0) before la moves on to t+2 (P2); B0(t+2) is the first
+  // unit of tile t+2 (P1), so lb moves there.
+  auto ktile = [&](auto par_c, auto tail_c) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par_c)::value;
+    constexpr int TAIL = decltype(tail_c)::value;
+    bf16x8_t(&b0)[4] = PAR ? fby : fbx;  // B0 of this tile
+    bf16x8_t(&b1)[4] = PAR ? fbx : fby;  // B1 of this tile; from P3 on: B0 of the next tile
+    // P0: A0 x B0
+    read_a(PAR, 0);
+    if constexpr (TAIL <= 1) {
+      stage_a(PAR ^ 1, 1);  // A1(t+1)
+      wait_vmcnt<3 * NA + 2 * NB>();
+    } else wait_vmcnt<NA>();
+    bar();
+    compute(I0{}, I0{}, b0);
+    bar();
+    // P1: A0 x B1
+    read_b(PAR, 1, b1);
+    if constexpr (TAIL == 0) {
+      lb.begin_tile();
+      stage_b(PAR, 0);  // B0(t+2)
+      wait_vmcnt<2 * NA + 3 * NB>();
+    } else if constexpr (TAIL == 1) wait_vmcnt<2 * NA + 2 * NB>();
+    else wait_vmcnt<0>();
+    bar();
+    compute(I0{}, I1{}, b1);
+    bar();
+    // P2: A1 x B1
+    read_a(PAR, 1);
+    if constexpr (TAIL == 0) {
+      la.begin_tile();
+      stage_a(PAR, 0);  // A0(t+2)
+      wait_vmcnt<3 * NA + 2 * NB>();
+    } else if constexpr (TAIL == 1) wait_vmcnt<2 * NA + NB>();
+    bar();
+    compute(I1{}, I1{}, b1);
+    bar();
+    // P3: A1 x B0   (B0 of the next tile goes into the register set B1 just vacated)
+    if constexpr (TAIL <= 1) read_b(PAR ^ 1, 0, b1);
+    if constexpr (TAIL == 0) {
+      stage_b(PAR, 1);  // B1(t+2)
+      wait_vmcnt<2 * NA + 3 * NB>();
+    } else if constexpr (TAIL == 1) wait_vmcnt<NA + NB>();
+    bar();
+    compute(I1{}, I0{}, b0);
+    bar();
+  };
+  for (int t = 0; t + 3 < nsteps; t += 2) {  // pairs of steady-state tiles
+    ktile(I0{}, I0{});
+    ktile(I1{}, I0{});
+  }
+  if constexpr (ODD) {
+    ktile(I0{}, I0{});
+    ktile(I1{}, I1{});
+    ktile(I0{}, I2{});
+  } else {
+    ktile(I0{}, I1{});
+    ktile(I1{}, I2{});
+  }
+  if (group == 0) bar();
+  __syncthreads();
+}
+
+}  // namespace oibl

@@ -52,6 +52,9 @@ SIGNATURES = {
     "oibl_pairwise_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "oibl_pairwise_sqdist": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
                                      c_size_t, c_void_p, c_size_t, c_void_p]),
+    "oibl_sqdist_topk_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "oibl_sqdist_topk": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "oibl_row_topk": (c_int, [c_void_p, c_void_p, c_int, c_int, c_size_t, c_int, c_int, c_void_p,
                               c_void_p, c_void_p]),
     "oibl_gemm_nt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t,
@@ -64,6 +67,7 @@ _HOOKS = {"oibl_debug_set_regstage": (c_int, [c_int]),
           "oibl_debug_set_conv_ablate": (c_int, [c_int]),
           "oibl_debug_set_conv_c64": (c_int, [c_int]),
           "oibl_debug_set_stem_fused": (c_int, [c_int]),
+          "oibl_debug_set_match_ring": (c_int, [c_int]),
           "oibl_debug_set_prof_buffer": (c_int, [c_void_p])}
 
 ABI_VERSION = 1

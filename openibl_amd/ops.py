@@ -377,6 +377,43 @@ def row_topk(vals: torch.Tensor, k: int, index_base: int = 0,
     return ov, oi
 
 
+def set_match_ring(mode: int) -> None:
+    """Test hook: ring-schedule distance kernel 0 = never, 1 = auto, 2 = whenever legal."""
+    _lib.load().oibl_debug_set_match_ring(int(mode))
+
+
+def sqdist_topk(x: torch.Tensor, y: torch.Tensor, k: int, index_base: int = 0, precision=F32,
+                exact: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """k nearest rows of y (squared L2) for every row of x, without materialising the matrix:
+    (values [m][k] ascending, indices [m][k] int32 = index_base + row of y).  Equals
+    row_topk(pairwise_sqdist(x, y), k).  The fused bf16 path reports candidate-list overflow through
+    a device flag; it is read here (one 4-byte copy) and the call repeated on the exact path."""
+    p = precision_code(precision)
+    dev = _need_cuda(x, y)
+    if x.dtype != torch.float32 or y.dtype != torch.float32 or x.dim() != 2 or y.dim() != 2:
+        raise ValueError("sqdist_topk expects float32 [m][d] and [n][d]")
+    m, d = map(int, x.shape)
+    n = int(y.shape[0])
+    if int(y.shape[1]) != d:
+        raise ValueError("sqdist_topk: dimension mismatch")
+    ov = torch.full((m, k), float("inf"), dtype=torch.float32, device=dev)
+    oi = torch.full((m, k), -1, dtype=torch.int32, device=dev)
+    if m == 0 or n == 0:
+        return ov, oi
+    lib = _lib.load()
+    x, y = x.contiguous(), y.contiguous()
+    ws_bytes = lib.oibl_sqdist_topk_workspace_bytes(m, n, d, k, p)
+    ws = workspace(ws_bytes, dev, "sqdist_topk")
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    for ex in ([1] if exact else [0, 1]):
+        _lib.check(lib.oibl_sqdist_topk(_ptr(x), m, _ptr(y), n, d, k, int(index_base), p, ex, _ptr(ov),
+                                        _ptr(oi), _ptr(flag), _ptr(ws), ws.numel(), _stream(dev)),
+                   "sqdist_topk")
+        if ex == 1 or int(flag.item()) == 0:
+            break
+    return ov, oi
+
+
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, regstage: bool = False) -> torch.Tensor:
     """Diagnostic: C = A . B^T on the MFMA core; A [M][K], B [N][K] both bf16 or both fp32."""
     dev = _need_cuda(a, b)

@@ -47,15 +47,7 @@ def hip_local_topk(q: torch.Tensor, g: torch.Tensor, k: int, index_base: int, pr
     if g.shape[0] == 0:
         return (torch.full((Q, k), float("inf"), device=q.device),
                 torch.full((Q, k), -1, dtype=torch.int32, device=q.device))
-    # bound the distance tile to 4 GiB (2^30 fp32 entries)
-    rows = max(1, min(Q, (1 << 30) // max(1, g.shape[0])))
-    vals, idxs = [], []
-    for s in range(0, Q, rows):
-        d = ops.pairwise_sqdist(q[s:s + rows].contiguous(), g, precision)
-        v, i = ops.row_topk(d, k, index_base=index_base)
-        vals.append(v)
-        idxs.append(i)
-    return torch.cat(vals), torch.cat(idxs)
+    return ops.sqdist_topk(q, g, k, index_base=index_base, precision=precision)
 
 
 def hip_merge_topk(vals: torch.Tensor, idx: torch.Tensor, k: int):

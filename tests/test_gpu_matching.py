@@ -133,3 +133,74 @@ def test_full_size_properties(dev):
     rb = recalls_from_topk(idxb.cpu().numpy(), gt)
     print("recalls fp32", r32, "bf16", rb)
     assert np.array_equal(r32, rb) and r32[0] > 0.95
+
+
+@pytest.mark.parametrize("m,n,d", [(300, 700, 256), (257, 1000, 512), (1000, 513, 4096), (64, 2500, 1024)])
+def test_pairwise_ring_equals_generic(dev, m, n, d):
+    """The ring-schedule distance kernel keeps the K order and the epilogue expression of the
+    generic kernel: identical bf16-mode matrices, ragged tiles included."""
+    g = torch.Generator().manual_seed(m + n + d)
+    x, y = torch.randn((m, d), generator=g).to(dev), torch.randn((n, d), generator=g).to(dev)
+    ops.set_match_ring(0)
+    try:
+        ref = ops.pairwise_sqdist(x, y, "bf16")
+        ops.set_match_ring(2)
+        big = torch.full((m, n + 37), -7.0, device=dev)
+        got = ops.pairwise_sqdist(x, y, "bf16", out=big[:, :n])
+    finally:
+        ops.set_match_ring(1)
+    assert torch.equal(got, ref)
+    assert (big[:, n:] == -7.0).all()
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("m,n,d,k", [(2100, 20000, 256, 10), (2049, 16500, 512, 25), (700, 9000, 128, 120),
+                                     (5, 300, 64, 10), (3, 7, 64, 10)])
+def test_sqdist_topk_equals_matrix_topk(dev, m, n, d, k, precision):
+    """Fused distance + top-k (threshold sample, filtered pass, candidate selection) == top-k of
+    the materialised matrix: same values, same indices, ties towards the lowest index."""
+    g = torch.Generator().manual_seed(m * 3 + n)
+    x, y = synth.descriptors(m, d, seed=m), synth.descriptors(n, d, seed=n + 1)
+    y[n // 2: n // 2 + min(m, 50)] = x[: min(m, 50)]              # exact matches
+    y[5] = y[n - 3]                                                 # a duplicate pair (tie)
+    x, y = x.to(dev), y.to(dev)
+    want_v, want_i = ops.row_topk(ops.pairwise_sqdist(x, y, precision), k, index_base=77)
+    got_v, got_i = ops.sqdist_topk(x, y, k, index_base=77, precision=precision)
+    assert torch.equal(got_i, want_i) and torch.equal(got_v, want_v)
+    ex_v, ex_i = ops.sqdist_topk(x, y, k, index_base=77, precision=precision, exact=True)
+    assert torch.equal(ex_i, want_i) and torch.equal(ex_v, want_v)
+
+
+def test_sqdist_topk_overflow_falls_back(dev):
+    """Thousands of identical gallery rows make every candidate list outgrow its capacity: the
+    overflow flag is raised and the wrapper repeats the call on the exact path."""
+    m, n, d, k = 2048, 16384, 256, 10
+    x = synth.descriptors(m, d, seed=3).to(dev)
+    y = synth.descriptors(1, d, seed=4).repeat(n, 1).contiguous().to(dev)
+    from openibl_amd import lib as _l
+    L = _l.load()
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    ov = torch.empty((m, k), device=dev)
+    oi = torch.empty((m, k), dtype=torch.int32, device=dev)
+    ws = torch.empty(L.oibl_sqdist_topk_workspace_bytes(m, n, d, k, 0), dtype=torch.uint8, device=dev)
+    rc = L.oibl_sqdist_topk(x.data_ptr(), m, y.data_ptr(), n, d, k, 0, 0, 0, ov.data_ptr(), oi.data_ptr(),
+                            flag.data_ptr(), ws.data_ptr(), ws.numel(), None)
+    assert rc == 0 and int(flag.item()) == 1
+    v, i = ops.sqdist_topk(x, y, k, precision="bf16")
+    assert torch.equal(i.cpu(), torch.arange(k, dtype=torch.int32).repeat(m, 1))
+
+
+def test_sqdist_topk_full_size_properties(dev):
+    """8192 x 81920 x 4096 (the benchmark's matching problem, bf16): planted duplicates come back
+    as nearest neighbour at distance ~0; a random row block agrees with the matrix path."""
+    Q, G = 8192, 81920
+    gq = torch.Generator(device=dev).manual_seed(7)
+    q = torch.nn.functional.normalize(torch.randn((Q, 4096), generator=gq, device=dev), dim=1)
+    g = torch.nn.functional.normalize(torch.randn((G, 4096), generator=gq, device=dev), dim=1)
+    g[G - 300:] = q[:300]
+    v, i = ops.sqdist_topk(q, g, 10, precision="bf16")
+    assert torch.equal(i[:300, 0].cpu(), torch.arange(G - 300, G, dtype=torch.int32))
+    assert v[:300, 0].abs().max().item() < 2e-2      # bf16 dot product of unit vectors
+    rows = slice(4000, 4512)
+    wv, wi = ops.row_topk(ops.pairwise_sqdist(q[rows].contiguous(), g, "bf16"), 10)
+    assert torch.equal(i[rows], wi) and torch.equal(v[rows], wv)
