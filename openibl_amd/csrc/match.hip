@@ -25,6 +25,31 @@ __global__ void row_sqnorm_kernel(const float* __restrict__ x, float* __restrict
   if (lane == 0) out[row] = s;
 }
 
+// the same reduction, and the bf16 copy of the row written on the way (bf16 mode reads the fp32
+// descriptors once instead of twice)
+__global__ void row_sqnorm_cast_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                       uint16_t* __restrict__ xb, int rows, int d) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * d;
+  uint16_t* br = xb + (size_t)row * d;
+  float s = 0.f;
+  for (int i = lane * 4; i < d; i += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + i);
+    s = fmaf(v.x, v.x, s);
+    s = fmaf(v.y, v.y, s);
+    s = fmaf(v.z, v.z, s);
+    s = fmaf(v.w, v.w, s);
+    uint2 b;
+    b.x = (uint32_t)f32_to_bf16_bits(v.x) | ((uint32_t)f32_to_bf16_bits(v.y) << 16);
+    b.y = (uint32_t)f32_to_bf16_bits(v.z) | ((uint32_t)f32_to_bf16_bits(v.w) << 16);
+    *reinterpret_cast<uint2*>(br + i) = b;
+  }
+  s = wave_sum(s);
+  if (lane == 0) out[row] = s;
+}
+
 struct PairParams {
   const void* x;  // [m][d] T
   const void* y;  // [n][d] T
@@ -186,6 +211,8 @@ __global__ __launch_bounds__(512) void pairwise_ring_kernel(PairRingParams p) {
           if (nok && ro < rows_left)
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dv), rs_d, (int)voff,
                                                   (int)((unsigned)ro * ldd4 + 128u * j), 0);
+          // keep the scalar row offsets from being computed (and spilled) for all 128 stores at once
+          if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
         }
     }
   } else {
@@ -310,9 +337,11 @@ __global__ __launch_bounds__(256) void row_topk_kernel(const float* __restrict__
     }
   }
   const int have = cnt;
-  for (int i = have + tid; i < TOPK_CAP; i += 256) cand[i] = TOPK_INF;
+  int span = 2;  // smallest power of two holding the survivors and the k outputs
+  while (span < have || span < k) span <<= 1;
+  for (int i = have + tid; i < span; i += 256) cand[i] = TOPK_INF;
   __syncthreads();
-  bitonic_sort_lds(cand, TOPK_CAP, tid, 256);
+  bitonic_sort_lds(cand, span, tid, 256);
   for (int i = tid; i < k; i += 256) {
     const unsigned long long key = cand[i];
     const bool valid = i < have;
@@ -385,21 +414,22 @@ static int pairwise_prepare(const float* x, int m, const float* y, int n, int d,
   hipStream_t st = (hipStream_t)stream;
   *xn = (float*)wsb;
   *yn = (float*)(wsb + pw_off_yn(m));
-  hipLaunchKernelGGL(row_sqnorm_kernel, dim3((m + 3) / 4), dim3(256), 0, st, x, *xn, m, d);
-  OIBL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(row_sqnorm_kernel, dim3((n + 3) / 4), dim3(256), 0, st, y, *yn, n, d);
-  OIBL_LAUNCH_CHECK();
   *xo = x;
   *yo = y;
   if (precision == OIBL_BF16) {
     uint16_t* xt = (uint16_t*)(wsb + pw_off_xt(m, n));
     uint16_t* yt = (uint16_t*)((char*)xt + align_up((size_t)m * d * 2, 256));
-    int rc = oibl_cast_f32_to_bf16(x, xt, (size_t)m * d, stream);
-    if (rc) return rc;
-    rc = oibl_cast_f32_to_bf16(y, yt, (size_t)n * d, stream);
-    if (rc) return rc;
+    hipLaunchKernelGGL(row_sqnorm_cast_kernel, dim3((m + 3) / 4), dim3(256), 0, st, x, *xn, xt, m, d);
+    OIBL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(row_sqnorm_cast_kernel, dim3((n + 3) / 4), dim3(256), 0, st, y, *yn, yt, n, d);
+    OIBL_LAUNCH_CHECK();
     *xo = xt;
     *yo = yt;
+  } else {
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((m + 3) / 4), dim3(256), 0, st, x, *xn, m, d);
+    OIBL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((n + 3) / 4), dim3(256), 0, st, y, *yn, n, d);
+    OIBL_LAUNCH_CHECK();
   }
   return OIBL_OK;
 }
