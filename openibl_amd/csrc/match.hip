@@ -132,6 +132,7 @@ struct PairRingParams {
   int32_t* cand_idx;
   int* cand_cnt;
   int cap, index_base, index_stride;  // global index of column c = index_base + c * index_stride
+  int group_m;                        // query tiles per ordering group (see above)
 };
 
 template <bool FILTER>
@@ -142,10 +143,11 @@ __global__ __launch_bounds__(512) void pairwise_ring_kernel(PairRingParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave / G::WN, wn = wave % G::WN;
   const unsigned id = xcd_remap(blockIdx.x, gridDim.x);
-  const unsigned width = 8u * (unsigned)p.tiles_n;
+  const unsigned gm = (unsigned)p.group_m;
+  const unsigned width = gm * (unsigned)p.tiles_n;
   const unsigned grp = id / width, in_grp = id - grp * width;
-  const unsigned first_m = grp * 8u;
-  const unsigned gsz = (unsigned)p.tiles_m - first_m < 8u ? (unsigned)p.tiles_m - first_m : 8u;
+  const unsigned first_m = grp * gm;
+  const unsigned gsz = (unsigned)p.tiles_m - first_m < gm ? (unsigned)p.tiles_m - first_m : gm;
   const int tm = (int)(first_m + in_grp % gsz), tn = (int)(in_grp / gsz);
   const int m0 = tm * G::BM, n0 = tn * G::BN;
 
@@ -216,7 +218,17 @@ __global__ __launch_bounds__(512) void pairwise_ring_kernel(PairRingParams p) {
         }
     }
   } else {
+    // Survivors are rare (about 1 % of the distances, ~1.3 per lane and tile) but a wave sees one
+    // in every second accumulator register, so nothing with a memory round trip may sit in this
+    // loop: each lane first collects its own survivors in a private LDS list (count in a
+    // register), then all lanes claim their slots with back-to-back atomics — one round trip per
+    // tile instead of one per register.  List layout [entry][thread]: conflict-free.
+    constexpr int LCAP = 8;
+    float* const l_val = reinterpret_cast<float*>(smem + 4096);
+    int* const l_idx = reinterpret_cast<int*>(smem + 4096 + LCAP * 512 * 4);
+    int* const l_row = reinterpret_cast<int*>(smem + 4096 + 2 * LCAP * 512 * 4);
     const int rows_left = p.m - m0 - row0;
+    int nl = 0;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int n = n0 + col0 + 32 * j;
@@ -230,14 +242,36 @@ __global__ __launch_bounds__(512) void pairwise_ring_kernel(PairRingParams p) {
           const float dv = fmaf(-2.0f, acc[i][j][r], xn_s[row0 + ro] + yn);
           if (nok && ro < rows_left && dv <= th_s[row0 + ro]) {
             const int m = m0 + row0 + ro;
-            const int pos = atomicAdd(p.cand_cnt + m, 1);
-            if (pos < p.cap) {
-              p.cand_val[(size_t)m * p.cap + pos] = dv;
-              p.cand_idx[(size_t)m * p.cap + pos] = p.index_base + n * p.index_stride;
+            if (nl < LCAP) {
+              l_val[nl * 512 + threadIdx.x] = dv;
+              l_idx[nl * 512 + threadIdx.x] = p.index_base + n * p.index_stride;
+              l_row[nl * 512 + threadIdx.x] = m;
+              ++nl;
+            } else {  // list full (practically never): claim the slot right away
+              const int pos = atomicAdd(p.cand_cnt + m, 1);
+              if (pos < p.cap) {
+                p.cand_val[(size_t)m * p.cap + pos] = dv;
+                p.cand_idx[(size_t)m * p.cap + pos] = p.index_base + n * p.index_stride;
+              }
             }
           }
         }
     }
+    int e_row[LCAP], e_pos[LCAP];
+#pragma unroll
+    for (int e = 0; e < LCAP; ++e) {
+      e_row[e] = e < nl ? l_row[e * 512 + threadIdx.x] : 0;
+      e_pos[e] = p.cap;
+    }
+#pragma unroll
+    for (int e = 0; e < LCAP; ++e)
+      if (e < nl) e_pos[e] = atomicAdd(p.cand_cnt + e_row[e], 1);
+#pragma unroll
+    for (int e = 0; e < LCAP; ++e)
+      if (e < nl && e_pos[e] < p.cap) {
+        p.cand_val[(size_t)e_row[e] * p.cap + e_pos[e]] = l_val[e * 512 + threadIdx.x];
+        p.cand_idx[(size_t)e_row[e] * p.cap + e_pos[e]] = l_idx[e * 512 + threadIdx.x];
+      }
   }
 }
 
@@ -357,6 +391,12 @@ using namespace oibl;
 extern "C" {
 
 static int g_match_ring = 1;  // test hook: 0 = never, 1 = auto, 2 = whenever legal
+static int g_match_group = 4;  // test hook: query tiles per ordering group of the ring kernel
+
+int oibl_debug_set_match_group(int g) {
+  g_match_group = g < 1 ? 1 : g;
+  return OIBL_OK;
+}
 
 int oibl_debug_set_match_ring(int mode) {
   g_match_ring = mode;
@@ -391,6 +431,7 @@ template <bool FILTER>
 static int launch_pairwise_ring(PairRingParams& p, hipStream_t st) {
   p.tiles_m = (p.m + 255) / 256;
   p.tiles_n = (p.n + 255) / 256;
+  p.group_m = g_match_group;
   const long grid = (long)p.tiles_m * p.tiles_n;
   OIBL_REQUIRE(grid > 0 && grid <= 0x7fffffffL, "pairwise: grid out of range");
   constexpr int lds = RingGeo<2>::MAIN_LDS;

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--only", default="")
+    ap.add_argument("--groups", default="")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     gen = torch.Generator(device=dev).manual_seed(1)
@@ -53,6 +54,13 @@ def main():
         t = timed(lambda: ops.pairwise_sqdist(q, g, "bf16", out=out), a.iters)
         ops.set_match_ring(1)
         rows.append(("pairwise_sqdist bf16 (generic 128x128 kernel)", t))
+    if a.groups:
+        from openibl_amd import lib as _l
+        for gm in [int(v) for v in a.groups.split(",")]:
+            _l.load().oibl_debug_set_match_group(gm)
+            t = timed(lambda: ops.pairwise_sqdist(q, g, "bf16", out=out), a.iters)
+            rows.append((f"pairwise ring, group_m={gm}", t))
+        _l.load().oibl_debug_set_match_group(8)
     for n, t in rows:
         print(f"  {n:48s} {t:8.3f} ms  {fl / t / 1e9:8.1f} TFLOP/s-equivalent  {a.q * a.g / t / 1e6:9.1f} Gpairs/s")
 
