@@ -138,6 +138,14 @@ int oibl_debug_set_regstage(int on) {
   return OIBL_OK;
 }
 
+// diagnostic (not in the public header): elapsed milliseconds between two recorded hipEvents, also
+// when they were recorded by event nodes of a replayed hipGraph (bench.py's kernel-span timing)
+int oibl_debug_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_host) {
+  OIBL_REQUIRE(ev_start && ev_stop && ms_host, "event_elapsed: null pointer");
+  OIBL_HIP_CHECK(hipEventElapsedTime(ms_host, (hipEvent_t)ev_start, (hipEvent_t)ev_stop));
+  return OIBL_OK;
+}
+
 int oibl_abi_version(void) { return 1; }
 const char* oibl_last_error(void) { return g_err; }
 const char* oibl_target_arch(void) { return "gfx950"; }

@@ -232,6 +232,52 @@ class EmbedNetPCA(_PrecisionMixin, nn.Module):
         w, b = self._pca_params()
         return ops.pca(vlad, w, b, l2norm=True)
 
+    def graphed(self, example: torch.Tensor) -> "GraphedDescriptor":
+        """hipGraph-replayed forward for a fixed batch shape (see GraphedDescriptor)."""
+        return GraphedDescriptor(self, example)
+
+
+class GraphedDescriptor:
+    """`EmbedNetPCA.forward` captured once into two hipGraphs and replayed: backbone (the 12
+    matrix-core launches) and head (NetVLAD + PCA, ~10 launches).  A forward then costs the host two
+    graph launches instead of ~30 kernel launches — on a shared host the eager path can become
+    launch-bound at ~5 ms per batch.  Shapes, precision and parameters are frozen at capture time;
+    the returned descriptor tensor is static and overwritten by the next call (clone it to keep it).
+
+        fwd = model.graphed(example_batch)        # example_batch: resident [N][3][H][W] fp32
+        desc = fwd(batch)                         # same shape; copied into the static input
+    `events`: optional (start, stop) torch.cuda.Event pair recorded on the launching stream right
+    around the backbone graph (bench.py's matrix-core span)."""
+
+    def __init__(self, model: "EmbedNetPCA", example: torch.Tensor):
+        if not example.is_cuda or example.dtype != torch.float32 or example.dim() != 4:
+            raise ValueError("graphed(): example must be a float32 CUDA tensor [N][3][H][W]")
+        self.static_in = example.contiguous()
+        with torch.no_grad():
+            model(self.static_in)               # packs weights, sizes every workspace, warms up
+            torch.cuda.synchronize(example.device)
+            self.g_backbone = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_backbone):
+                feat = model.base_model.features_nhwc(self.static_in)
+            self.g_head = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_head, pool=self.g_backbone.pool()):
+                _, vlad = model.net_vlad.aggregate_nhwc(feat, want_raw=False, want_norm=True)
+                w, b = model._pca_params()
+                self.out = ops.pca(vlad, w, b, l2norm=True)
+
+    def __call__(self, x: torch.Tensor = None, events=None) -> torch.Tensor:
+        if x is not None and x.data_ptr() != self.static_in.data_ptr():
+            if x.shape != self.static_in.shape:
+                raise ValueError(f"graphed forward was captured for {tuple(self.static_in.shape)}")
+            self.static_in.copy_(x, non_blocking=True)
+        if events is not None:
+            events[0].record()
+        self.g_backbone.replay()
+        if events is not None:
+            events[1].record()
+        self.g_head.replay()
+        return self.out
+
 
 class EmbedRegionNet(_PrecisionMixin, nn.Module):
     """ibl/models/netvlad.py:112-207.  Only the evaluation branch (:199-205, identical to

@@ -377,6 +377,15 @@ def row_topk(vals: torch.Tensor, k: int, index_base: int = 0,
     return ov, oi
 
 
+def event_elapsed_ms(start: "torch.cuda.Event", stop: "torch.cuda.Event") -> float:
+    """hipEventElapsedTime on the raw handles — works for events recorded by the event nodes of a
+    replayed hipGraph, which torch's own bookkeeping does not see."""
+    ms = C.c_float(0.0)
+    _lib.check(_lib.load().oibl_debug_event_elapsed_ms(int(start.cuda_event), int(stop.cuda_event),
+                                                       C.byref(ms)), "event_elapsed_ms")
+    return float(ms.value)
+
+
 def set_match_ring(mode: int) -> None:
     """Test hook: ring-schedule distance kernel 0 = never, 1 = auto, 2 = whenever legal."""
     _lib.load().oibl_debug_set_match_ring(int(mode))

@@ -113,3 +113,21 @@ def test_weight_update_invalidates_packed_cache(model, dev, state_dict):
     c = model(x).cpu()
     assert (a - b).norm() > 1e-4
     assert torch.equal(a, c)
+
+
+def test_graphed_forward_equals_eager(dev):
+    """model.graphed(x): the two captured hipGraphs reproduce model(x) bit for bit, on the example
+    batch and on a second batch copied into the static input."""
+    import hubconf
+    model = hubconf.vgg16_netvlad(pretrained=False)
+    model.load_state_dict(synth.embednetpca_state(0))
+    model = model.to(dev).eval().set_precision("bf16")
+    x1 = synth.images(2, 64, 96, seed=21).to(dev)
+    x2 = synth.images(2, 64, 96, seed=22).to(dev)
+    want1, want2 = model(x1).clone(), model(x2).clone()
+    fwd = model.graphed(x1)
+    assert torch.equal(fwd(), want1)
+    assert torch.equal(fwd(x2), want2)
+    assert torch.equal(fwd(x1), want1)
+    with pytest.raises(ValueError):
+        fwd(synth.images(1, 64, 96, seed=1).to(dev))
