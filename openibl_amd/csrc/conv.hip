@@ -347,13 +347,20 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void conv3x3_igemm_kernel(ConvParams
   la.init(c, p, m0, tap0);
   lb.init(c, p, n0, tap0);
 
+  // accumulators start at the bias (every kernel of this file orders the sum that way, so that
+  // all variants of a layer produce identical bits)
   f32x16_t acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int j = 0; j < TN; ++j) {
+    float b = p.bias[n0 + (c.wn * TN + j) * 32 + (c.lane & 31)];
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) {
+        asm volatile("" : "+v"(b));  // distinct registers, not aliases of one value
+        acc[i][j][r] = b;
+      }
+  }
 
   gemm_nt_mainloop<Cfg, GLDS>(acc, smem, c, la, lb, 9 * (p.cin / Cfg::BK));
   // (the main loop ends on a workgroup barrier: the staging LDS is free for the epilogue)
@@ -363,14 +370,13 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void conv3x3_igemm_kernel(ConvParams
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = (c.wn * TN + j) * 32 + (c.lane & 31);
-    const float b = p.bias[n0 + col];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       if constexpr (POOL) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           float v = fmaxf(fmaxf(acc[i][j][4 * g], acc[i][j][4 * g + 1]),
-                          fmaxf(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3])) + b;
+                          fmaxf(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]));
           if (p.relu) v = fmaxf(v, 0.f);
           const int row = (c.wm * TM + i) * 8 + 2 * g + (c.lane >> 5);
           Elem<T>::store(reinterpret_cast<T*>(smem + row * PITCH) + col, v);
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void conv3x3_igemm_kernel(ConvParams
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float v = acc[i][j][r] + b;
+          float v = acc[i][j][r];
           if (p.relu) v = fmaxf(v, 0.f);
           const int row = (c.wm * TM + i) * 32 + acc_row(r, c.lane);
           Elem<T>::store(reinterpret_cast<T*>(smem + row * PITCH) + col, v);
@@ -432,6 +438,8 @@ static int launch_conv_cfg(const ConvParams& p, hipStream_t st) {
                     : launch_conv_kernel<Cfg, POOL, true>(q, grid, st);
 }
 
+static unsigned long long* g_prof_buf = nullptr;  // test hook: phase profile of block 0
+
 // ring-schedule kernel (conv_ring.h): bf16, Cin % 64 == 0; WM = 2: 256 x 256 tile (Cout % 256 == 0),
 // WM = 4: 512 x 128 tile (Cout % 128 == 0)
 template <int WM, bool POOL, bool ODD>
@@ -453,6 +461,7 @@ static int launch_conv_ring_impl(const ConvParams& p, hipStream_t st) {
   q.out_rows = (int)p.out_rows;
   q.tiles_n = p.cout / G::BN;
   q.relu = p.relu;
+  q.prof = g_prof_buf;
   const long tiles_m = (p.m_total + G::BM - 1) / G::BM;
   const long grid = tiles_m * q.tiles_n;
   constexpr int lds = ring_lds_bytes<WM, POOL>();
@@ -571,7 +580,6 @@ struct C64Params {
   int ntiles;
   unsigned long long* prof;  // optional (test hook): per-phase shader-clock totals of block 0 wave 0
 };
-static unsigned long long* g_prof_buf = nullptr;
 
 __device__ static inline int c64_swz(int hy, int hx) { return ((hx >> 1) & 7) ^ ((hy & 1) << 2); }
 
@@ -666,13 +674,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(C64Params p) {
     if (nxt < p.ntiles) issue_halo(nxt, hb + ((it & 1) ^ 1) * C64_HALO_BYTES);
     C64_TICK(0)
 
-    f32x16_t acc[2][2];
+    f32x16_t acc[2][2];  // start at the bias, like every convolution kernel here
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][tn][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][tn][r] = bvals[tn];
 
     // 36 steps (tap-major, 4 k-steps per tap), fragment reads software-pipelined one step ahead:
     // with one wave per SIMD nothing else hides the LDS latency.
@@ -725,7 +733,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(C64Params p) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             float v = fmaxf(fmaxf(acc[i][tn][4 * g], acc[i][tn][4 * g + 1]),
-                            fmaxf(acc[i][tn][4 * g + 2], acc[i][tn][4 * g + 3])) + bvals[tn];
+                            fmaxf(acc[i][tn][4 * g + 2], acc[i][tn][4 * g + 3]));
             if (p.relu) v = fmaxf(v, 0.f);
             const int qx = 8 * i + 2 * g + half;
             *reinterpret_cast<uint16_t*>(st + qx * 144 + (tn * 32 + l31) * 2) = f32_to_bf16_bits(v);
@@ -749,7 +757,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(C64Params p) {
         for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            float v = acc[i][tn][r] + bvals[tn];
+            float v = acc[i][tn][r];
             if (p.relu) v = fmaxf(v, 0.f);
             const int prow = i * 32 + acc_row(r, lane);
             *reinterpret_cast<uint16_t*>(st + prow * 144 + (tn * 32 + l31) * 2) = f32_to_bf16_bits(v);
@@ -1087,13 +1095,13 @@ __global__ __launch_bounds__(512) void vgg_stem_kernel(StemParams p) {
     const unsigned long long c0 = cprof ? __builtin_amdgcn_s_memtime() : 0;
     const int tile = first + it * stride;
     const char* const cur = hb + (it & 1) * ST_HALO_BYTES;
-    f32x16_t acc[2][2];
+    f32x16_t acc[2][2];  // start at the bias, like every convolution kernel here
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][tn][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][tn][r] = bvals[tn];
     bf16x8_t fa[2][2], fb[2][2];
     auto load_step = [&](int sidx, bf16x8_t (&a)[2], bf16x8_t (&b)[2]) __attribute__((always_inline)) {
       const int tap = sidx >> 2, kk = sidx & 3;
@@ -1145,7 +1153,7 @@ __global__ __launch_bounds__(512) void vgg_stem_kernel(StemParams p) {
 #pragma unroll
           for (int tn = 0; tn < 2; ++tn) {
             const float v = fmaxf(fmaxf(acc[i][tn][4 * g], acc[i][tn][4 * g + 1]),
-                                  fmaxf(acc[i][tn][4 * g + 2], acc[i][tn][4 * g + 3])) + bvals[tn];
+                                  fmaxf(acc[i][tn][4 * g + 2], acc[i][tn][4 * g + 3]));
             o[tn * 32] = f32_to_bf16_bits(fmaxf(v, 0.f));
           }
         }

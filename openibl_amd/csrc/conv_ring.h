@@ -26,6 +26,7 @@ struct RingParams {
   int out_rows;  // rows of the output tensor
   int tiles_n;
   int relu;
+  unsigned long long* prof;  // optional (test hook): shader-clock stamps of block 0, wave 0
 };
 
 template <int WM, bool POOL>
@@ -142,6 +143,8 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave / G::WN, wn = wave % G::WN;
+  const bool prof = p.prof != nullptr && blockIdx.x == 0 && wave == 0;
+  const unsigned long long t_start = prof ? __builtin_amdgcn_s_memtime() : 0;
   const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
   const int m0 = tm * G::BM, n0 = tn * G::BN;
@@ -161,58 +164,125 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
   la.init(p, m0, rows_a, piece);
   lb.init(p, n0, rows_b, piece);
 
+  // The accumulators start at the bias (the fma chain of every output begins with it), laid out
+  // like the results: natural layout = one channel per lane and column tile, transposed layout
+  // (!POOL) = 4 consecutive channels per register quad.  Nothing is added in the epilogue, and the
+  // loads are long done when the loop ends.
   f32x16_t acc[4][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  ring_mainloop<WM, ODD>(acc, smem, wave, lane, la, lb, nsteps);
-  // (the main loop ends on a workgroup barrier: the staging LDS is free for the epilogue)
-
-  // ---- epilogue: bias (+ReLU) (+2x2 max-pool over register quads), transpose through LDS,
-  //      full-line NHWC stores
-  constexpr int PITCH = G::BN * 2 + 16;
-  constexpr int OUT_ROWS = POOL ? G::BM / 4 : G::BM;
-#pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int col = wn * 64 + j * 32 + (lane & 31);
-    const float b = p.bias[n0 + col];
+    if constexpr (POOL) {
+      float b = p.bias[n0 + wn * 64 + j * 32 + (lane & 31)];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if constexpr (POOL) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float v = fmaxf(fmaxf(acc[i][j][4 * g], acc[i][j][4 * g + 1]),
-                          fmaxf(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3])) + b;
-          if (p.relu) v = fmaxf(v, 0.f);
-          const int row = (wm * 4 + i) * 8 + 2 * g + (lane >> 5);
-          *reinterpret_cast<uint16_t*>(smem + row * PITCH + col * 2) = f32_to_bf16_bits(v);
-        }
-      } else {
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float v = acc[i][j][r] + b;
-          if (p.relu) v = fmaxf(v, 0.f);
-          const int row = (wm * 4 + i) * 32 + acc_row(r, lane);
-          *reinterpret_cast<uint16_t*>(smem + row * PITCH + col * 2) = f32_to_bf16_bits(v);
+          asm volatile("" : "+v"(b));  // 64 distinct registers, not 64 aliases of one value
+          acc[i][j][r] = b;
+        }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b =
+            *reinterpret_cast<const float4*>(p.bias + n0 + wn * 64 + j * 32 + 8 * g + 4 * (lane >> 5));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[i][j][4 * g] = b.x;
+          acc[i][j][4 * g + 1] = b.y;
+          acc[i][j][4 * g + 2] = b.z;
+          acc[i][j][4 * g + 3] = b.w;
         }
       }
     }
   }
+
+  const unsigned long long t_loop = prof ? __builtin_amdgcn_s_memtime() : 0;
+  ring_mainloop<WM, ODD, !POOL>(acc, smem, wave, lane, la, lb, nsteps);
+  // (the main loop ends on a workgroup barrier: the staging LDS is free for the epilogue)
+  const unsigned long long t_epi = prof ? __builtin_amdgcn_s_memtime() : 0;
+
+  // ---- epilogue: bias (+ReLU) (+2x2 max-pool over register quads), transpose through LDS,
+  //      full-line NHWC stores.
+  //      POOL : accumulators in the natural layout (lane = channel, registers = pixels): a pooling
+  //             window is one register quad -> three v_max, 2-byte LDS writes of the pooled values.
+  //      !POOL: accumulators transposed (lane = pixel, register quad = 4 consecutive channels):
+  //             one packed 8-byte LDS write per quad, a quarter of the write instructions.
+  constexpr int PITCH = G::BN * 2 + 16;
+  constexpr int OUT_ROWS = POOL ? G::BM / 4 : G::BM;
+  if constexpr (POOL) {
+    const float floor_v = p.relu ? 0.f : -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float v = fmaxf(fmaxf(fmaxf(acc[i][j][4 * g], acc[i][j][4 * g + 1]),
+                                      fmaxf(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3])), floor_v);
+          const int row = (wm * 4 + i) * 8 + 2 * g + (lane >> 5);
+          *reinterpret_cast<uint16_t*>(smem + row * PITCH + col * 2) = f32_to_bf16_bits(v);
+        }
+    }
+  } else {
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+    typedef __attribute__((ext_vector_type(2))) short s2;
+    // ReLU on the packed pair: as signed 16-bit integers every negative bf16 is < 0 (see conv.hip)
+    const short fl = p.relu ? (short)0 : (short)-32768;
+    const s2 floor2 = {fl, fl};
+    const int half = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = wn * 64 + j * 32 + 8 * g + 4 * half;  // first of this quad's 4 channels
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bf2 lo = __builtin_convertvector((f2){acc[i][j][4 * g], acc[i][j][4 * g + 1]}, bf2);
+          const bf2 hi = __builtin_convertvector((f2){acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]}, bf2);
+          uint2 pk;
+          pk.x = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s2, lo), floor2));
+          pk.y = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s2, hi), floor2));
+          const int row = wm * 128 + i * 32 + (lane & 31);
+          *reinterpret_cast<uint2*>(smem + row * PITCH + c0 * 2) = pk;
+        }
+      }
+  }
   __syncthreads();
+  const unsigned long long t_copy = prof ? __builtin_amdgcn_s_memtime() : 0;
   constexpr int CPR = G::BN * 2 / 16;  // 16-byte chunks per output row
+  constexpr int ITERS = OUT_ROWS * CPR / 512, BATCH = ITERS < 8 ? ITERS : 8;
+  static_assert(OUT_ROWS * CPR % 512 == 0 && ITERS % BATCH == 0, "copy-out shape");
   const long row0 = POOL ? (m0 >> 2) : m0;
   char* obase = reinterpret_cast<char*>(p.out) + (long)n0 * 2;
   const long orow_bytes = (long)p.cout * 2;
-  for (int idx = threadIdx.x; idx < OUT_ROWS * CPR; idx += 512) {
-    const int row = idx / CPR, ch = idx - row * CPR;
-    const long grow = row0 + row;
-    if (grow < p.out_rows)
-      *reinterpret_cast<uint4*>(obase + grow * orow_bytes + ch * 16) =
-          *reinterpret_cast<const uint4*>(smem + row * PITCH + ch * 16);
+  // LDS reads of a batch first, then its stores: the loads' latency is paid once per batch
+#pragma unroll
+  for (int it0 = 0; it0 < ITERS; it0 += BATCH) {
+    uint4 v[BATCH];
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int idx = (it0 + u) * 512 + (int)threadIdx.x;
+      v[u] = *reinterpret_cast<const uint4*>(smem + (idx / CPR) * PITCH + (idx % CPR) * 16);
+    }
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int idx = (it0 + u) * 512 + (int)threadIdx.x;
+      const long grow = row0 + idx / CPR;
+      if (grow < p.out_rows)
+        *reinterpret_cast<uint4*>(obase + grow * orow_bytes + (idx % CPR) * 16) = v[u];
+    }
+  }
+  if (prof) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+    if (lane == 0) {
+      p.prof[0] = t_loop - t_start;
+      p.prof[1] = t_epi - t_loop;
+      p.prof[2] = t_copy - t_epi;
+      p.prof[3] = t_end - t_copy;
+    }
   }
 }
 

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(512) void pairwise_ring_kernel(PairRingParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  ring_mainloop<2, false>(acc, smem, wave, lane, la, lb, p.d >> 6);
+  ring_mainloop<2, false, false>(acc, smem, wave, lane, la, lb, p.d >> 6);
 
   // norms (and thresholds) of the tile's rows / columns -> LDS; out-of-range rows/columns are
   // clamped here and masked at the store

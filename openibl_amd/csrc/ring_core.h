@@ -126,8 +126,13 @@ struct RingRowLoader {
 
 // The main loop.  acc[i][j]: 32x32 tile (row tile i of 4, column tile j of 2) of this wave's
 // 128 x 64 block, in the MFMA C/D layout.  nsteps >= 3; ODD = nsteps is odd.
+// SWAP = true feeds the B fragment as the MFMA's first operand: every accumulator tile is then
+// held TRANSPOSED (register index <-> column of the block, lane <-> row), i.e. a lane owns 4
+// consecutive columns of one row per register quad — what an epilogue that writes row-major
+// 16-bit outputs wants (8-byte stores instead of 2-byte ones).  Each output element is the same
+// k-ordered fma chain either way: identical bits.
 // On return every wave has passed a workgroup barrier: the staging LDS is free.
-template <int WM, bool ODD, typename LA, typename LB>
+template <int WM, bool ODD, bool SWAP, typename LA, typename LB>
 __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, int wave, int lane,
                                             LA& la, LB& lb, int nsteps) {
   using G = RingGeo<WM>;
@@ -179,7 +184,8 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
 #pragma unroll
       for (int i2 = 0; i2 < 2; ++i2)
         acc[2 * h + i2][j] =
-            __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i2][kk], fb[kk], acc[2 * h + i2][j], 0, 0, 0);
+            SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk], fa[i2][kk], acc[2 * h + i2][j], 0, 0, 0)
+                 : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i2][kk], fb[kk], acc[2 * h + i2][j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
   };

@@ -246,13 +246,14 @@ class GraphedDescriptor:
 
         fwd = model.graphed(example_batch)        # example_batch: resident [N][3][H][W] fp32
         desc = fwd(batch)                         # same shape; copied into the static input
+        desc = fwd()                              # again on the batch already in place
     `events`: optional (start, stop) torch.cuda.Event pair recorded on the launching stream right
     around the backbone graph (bench.py's matrix-core span)."""
 
     def __init__(self, model: "EmbedNetPCA", example: torch.Tensor):
         if not example.is_cuda or example.dtype != torch.float32 or example.dim() != 4:
             raise ValueError("graphed(): example must be a float32 CUDA tensor [N][3][H][W]")
-        self.static_in = example.contiguous()
+        self.static_in = example.clone(memory_format=torch.contiguous_format)   # private: never aliases a caller's tensor
         with torch.no_grad():
             model(self.static_in)               # packs weights, sizes every workspace, warms up
             torch.cuda.synchronize(example.device)
@@ -266,7 +267,7 @@ class GraphedDescriptor:
                 self.out = ops.pca(vlad, w, b, l2norm=True)
 
     def __call__(self, x: torch.Tensor = None, events=None) -> torch.Tensor:
-        if x is not None and x.data_ptr() != self.static_in.data_ptr():
+        if x is not None:                     # x=None: run again on the batch already in place
             if x.shape != self.static_in.shape:
                 raise ValueError(f"graphed forward was captured for {tuple(self.static_in.shape)}")
             self.static_in.copy_(x, non_blocking=True)
