@@ -150,9 +150,19 @@ def main():
     fl_igemm = (igemm_flops_per_image() + fl_conv11) * args.batch
     achieved = fl_igemm / (span_ms * 1e-3) / 1e12
     peak = BF16_MFMA_PEAK_TFLOPS if args.precision == "bf16" else F32_MFMA_PEAK_TFLOPS
+    # HBM bytes per launch come from the committed PMC passes of this same command (they cannot be
+    # collected inside the timed run): tools/prof_summary.py writes the digest next to the tables
+    traffic, traffic_src = None, None
+    tj = ROOT / "profiles" / "hbm_traffic_latest.json"
+    if args.precision == "bf16" and tj.exists():
+        try:
+            tdata = json.loads(tj.read_text())
+            traffic, traffic_src = round(float(tdata["bytes_per_launch"])), tdata["source"]
+        except Exception:
+            traffic = None
     roofline = {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-        "frac": round(achieved / peak, 4), "traffic": None,
+        "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
         "kernel": ("oibl::vgg_stem_kernel (conv1_1+conv1_2+pool) + oibl::conv3x3_ring_kernel "
                    "(conv2_1..conv5_3), 12 launches/step" if args.precision == "bf16" else
                    "oibl::conv3x3_igemm_kernel (conv1_2..conv5_3, 12 launches/step)"),

@@ -95,6 +95,22 @@ def main():
             lines.append(f"| `{short(k)}` | {n} | {f_raw:.1f} | {2 * f_raw:.1f} | {w_mb:.1f} | {us:.1f} | "
                          f"{(2 * f_raw + w_mb) / us * 1e3:.0f} |")
         (prof / f"{tag}_hbm_traffic.md").write_text("\n".join(lines) + "\n")
+        # machine-readable digest for bench.py's roofline.traffic: corrected HBM bytes of the
+        # matrix-core convolution launches, averaged per launch
+        import json
+        tot_b, tot_n = 0.0, 0
+        for k, (n, v, t) in fe.items():
+            if not any(tag_ in k for tag_ in ("conv3x3_ring_kernel", "vgg_stem_kernel", "conv3x3_igemm_kernel",
+                                              "conv3x3_c64_kernel")):
+                continue
+            w = wr.get(k, [1, 0.0, 1])
+            tot_b += 2 * v * 1024 + w[1] * 1024 * (n / max(w[0], 1))
+            tot_n += n
+        if tot_n:
+            (prof / "hbm_traffic_latest.json").write_text(json.dumps({
+                "source": f"profiles/{tag}_hbm_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                          "FETCH doubled per MI355X_MICROARCH.md; counts Infinity-Cache hits)",
+                "conv_launches": tot_n, "bytes_per_launch": tot_b / tot_n}, indent=1) + "\n")
     print("wrote", sorted(p.name for p in prof.glob(f"{tag}_*")))
 
 
