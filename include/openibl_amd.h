@@ -202,6 +202,20 @@ int oibl_sqdist_topk(const float* x, int m, const float* y, int n, int d, int k,
 int oibl_row_topk(const float* vals, const int32_t* idx_in, int m, int n, size_t ld, int k,
                   int index_base, float* out_val, int32_t* out_idx, void* stream);
 
+/* ---- recall counting ---------------------------------------------------------------- *
+ * Replaces the per-query Python loop of evaluate_all and spatial_nms
+ * (ibl/evaluators.py:132-140, 149-160).  For every query, the rank (0-based, inside the
+ * prediction list the reference builds) of the first prediction that is a ground-truth
+ * neighbour, -1 if there is none; Recall@N = #(0 <= rank < N) / m for any N.
+ *   topk_idx [m][k] int32 ranked gallery positions (-1 = padding), k <= 1024
+ *   gt_offsets [m+1], gt_values [gt_offsets[m]] int32: ground truth in CSR form
+ *   gallery_pids [n] int32 or NULL.  Non-NULL switches on spatial NMS: only the first
+ *   nms_window (= 12 * max(recall_topk) in the reference) predictions count and a prediction
+ *   whose pid occurred earlier in the list is dropped.                                        */
+int oibl_first_hit_rank(const int32_t* topk_idx, int m, int k, const int32_t* gt_offsets,
+                        const int32_t* gt_values, const int32_t* gallery_pids, int nms_window,
+                        int32_t* out_rank, void* stream);
+
 /* ---- diagnostics ------------------------------------------------------------------ */
 
 /* Plain C = A . B^T on the shared MFMA GEMM core (used by tests to validate the core and

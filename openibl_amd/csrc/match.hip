@@ -384,6 +384,70 @@ __global__ __launch_bounds__(256) void row_topk_kernel(const float* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Recall counting on the device (evaluate_all / spatial_nms, ibl/evaluators.py:132-160).
+// Per query: the rank, inside the prediction list the reference would build, of the first
+// prediction that is a ground-truth neighbour (-1: none).  Recall@N for every N follows on the
+// host from these m integers (query q counts for N iff 0 <= rank < N).
+//   topk [m][k]     ranked gallery positions (ascending distance), -1 = padding
+//   gt_off [m+1], gt_val [nnz]   ground truth as CSR (gallery positions per query)
+//   pids != NULL    spatial NMS: only the first nms_window predictions are considered and a
+//                   prediction whose pid already occurred earlier in the list is dropped
+//                   (evaluators.py:132-140 keeps the first occurrence); the rank is the position
+//                   among the kept ones.
+// One wave per query, 64 predictions per pass.
+// ---------------------------------------------------------------------------------------------
+constexpr int RANK_MAXK = 1024;
+__global__ __launch_bounds__(256) void first_hit_rank_kernel(const int32_t* __restrict__ topk, int m,
+                                                             int k, const int32_t* __restrict__ gt_off,
+                                                             const int32_t* __restrict__ gt_val,
+                                                             const int32_t* __restrict__ pids,
+                                                             int nms_window,
+                                                             int32_t* __restrict__ out_rank) {
+  __shared__ int32_t s_pid[4][RANK_MAXK];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int q = blockIdx.x * 4 + wv;
+  if (q >= m) return;
+  const int32_t* pred = topk + (size_t)q * k;
+  const int window = pids ? (k < nms_window ? k : nms_window) : k;
+  const int g0 = gt_off[q], g1 = gt_off[q + 1];
+  if (pids) {
+    for (int j = lane; j < window; j += 64) {
+      const int32_t id = pred[j];
+      s_pid[wv][j] = id >= 0 ? pids[id] : -1;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  int kept_before = 0, result = -1;
+  for (int j0 = 0; j0 < window && result < 0; j0 += 64) {
+    const int j = j0 + lane;
+    const int32_t id = j < window ? pred[j] : -1;
+    bool keep = id >= 0;
+    if (pids && keep) {
+      const int32_t mine = s_pid[wv][j];
+      for (int i = 0; i < j; ++i)
+        if (s_pid[wv][i] == mine && pred[i] >= 0) {
+          keep = false;
+          break;
+        }
+    }
+    bool hit = false;
+    if (keep)
+      for (int t = g0; t < g1; ++t)
+        if (gt_val[t] == id) {
+          hit = true;
+          break;
+        }
+    const unsigned long long keep_m = __ballot(keep), hit_m = __ballot(hit);
+    if (hit_m) {
+      const int first = __ffsll((long long)hit_m) - 1;
+      result = kept_before + __popcll(keep_m & ((1ull << first) - 1ull));
+    }
+    kept_before += __popcll(keep_m);
+  }
+  if (lane == 0) out_rank[q] = result;
+}
+
 }  // namespace oibl
 
 using namespace oibl;
@@ -691,6 +755,18 @@ int oibl_sqdist_topk(const float* x, int m, const float* y, int n, int d, int k,
                        out_idx + (size_t)r0 * k, (const int*)nullptr, (int*)nullptr);
     OIBL_LAUNCH_CHECK();
   }
+  return OIBL_OK;
+}
+
+int oibl_first_hit_rank(const int32_t* topk_idx, int m, int k, const int32_t* gt_offsets,
+                        const int32_t* gt_values, const int32_t* gallery_pids, int nms_window,
+                        int32_t* out_rank, void* stream) {
+  OIBL_REQUIRE(topk_idx && gt_offsets && gt_values && out_rank, "first_hit_rank: null pointer");
+  OIBL_REQUIRE(m > 0 && k >= 1 && k <= RANK_MAXK, "first_hit_rank: bad shape m=%d k=%d", m, k);
+  OIBL_REQUIRE(!gallery_pids || nms_window >= 1, "first_hit_rank: nms_window must be >= 1");
+  hipLaunchKernelGGL(first_hit_rank_kernel, dim3((m + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                     topk_idx, m, k, gt_offsets, gt_values, gallery_pids, nms_window, out_rank);
+  OIBL_LAUNCH_CHECK();
   return OIBL_OK;
 }
 

@@ -377,6 +377,26 @@ def row_topk(vals: torch.Tensor, k: int, index_base: int = 0,
     return ov, oi
 
 
+def first_hit_rank(topk_idx: torch.Tensor, gt_offsets: torch.Tensor, gt_values: torch.Tensor,
+                   gallery_pids: Optional[torch.Tensor] = None, nms_window: int = 120) -> torch.Tensor:
+    """Per query: rank of the first prediction that is a ground-truth neighbour (-1: none), with
+    the reference's spatial NMS when gallery_pids is given.  All tensors int32 on the device."""
+    dev = _need_cuda(topk_idx, gt_offsets, gt_values, gallery_pids)
+    for t in (topk_idx, gt_offsets, gt_values, gallery_pids):
+        if t is not None and t.dtype != torch.int32:
+            raise ValueError("first_hit_rank expects int32 tensors")
+    m, k = map(int, topk_idx.shape)
+    if int(gt_offsets.numel()) != m + 1:
+        raise ValueError("first_hit_rank: gt_offsets must have m + 1 entries")
+    out = torch.empty((m,), dtype=torch.int32, device=dev)
+    if m == 0:
+        return out
+    _lib.check(_lib.load().oibl_first_hit_rank(_ptr(topk_idx.contiguous()), m, k, _ptr(gt_offsets),
+                                               _ptr(gt_values), _ptr(gallery_pids), int(nms_window),
+                                               _ptr(out), _stream(dev)), "first_hit_rank")
+    return out
+
+
 def event_elapsed_ms(start: "torch.cuda.Event", stop: "torch.cuda.Event") -> float:
     """hipEventElapsedTime on the raw handles — works for events recorded by the event nodes of a
     replayed hipGraph, which torch's own bookkeeping does not see."""

@@ -204,3 +204,26 @@ def test_sqdist_topk_full_size_properties(dev):
     rows = slice(4000, 4512)
     wv, wi = ops.row_topk(ops.pairwise_sqdist(q[rows].contiguous(), g, "bf16"), 10)
     assert torch.equal(i[rows], wi) and torch.equal(v[rows], wv)
+
+
+@pytest.mark.parametrize("nms", [False, True])
+@pytest.mark.parametrize("m,n,k", [(37, 500, 10), (200, 3000, 120), (5, 40, 130), (64, 2000, 1024)])
+def test_first_hit_rank_equals_host_counting(dev, m, n, k, nms):
+    """Device recall counting == the reference's per-query loop (recalls_from_topk), with and
+    without spatial NMS, on random rankings with duplicate pids, padding and empty ground truth."""
+    from openibl_amd.evaluators import recalls_from_topk, recalls_from_topk_device
+    rng = np.random.default_rng(m + n + k)
+    kk = min(k, n)
+    idx = np.stack([rng.permutation(n)[:kk] for _ in range(m)]).astype(np.int32)
+    if k > n:
+        idx = np.concatenate([idx, -np.ones((m, k - n), np.int32)], 1)
+    pids = rng.integers(0, max(2, n // 12), size=n).tolist()       # ~12 views per place
+    gt = [rng.choice(n, size=rng.integers(0, 9), replace=False).tolist() for _ in range(m)]
+    for q in range(0, m, 3):                                        # make some queries easy
+        gt[q] = gt[q] + [int(idx[q, rng.integers(0, min(kk, 15))])]
+    for topk in ((1, 5, 10), (1, 5, 10, 20, 25)):
+        if nms and max(topk) * 12 > 1024:
+            continue
+        want = recalls_from_topk(idx, gt, pids, topk, nms)
+        got = recalls_from_topk_device(torch.from_numpy(idx).to(dev), gt, pids, topk, nms)
+        np.testing.assert_array_equal(got, want)
