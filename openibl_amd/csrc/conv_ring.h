@@ -97,9 +97,10 @@ struct ConvRingALoader {
     }
     soff = (unsigned)cc * 128u;
   }
-  __device__ inline void stage(int h, char* dst) const {
+  __device__ inline void stage(int h, char* dst, int i0 = 0, int i1 = NA) const {
 #pragma unroll
-    for (int i = 0; i < NA; ++i) buf_glds16(rsrc, cur[NA * h + i], soff, dst + i * 8192);
+    for (int i = 0; i < NA; ++i)
+      if (i >= i0 && i < i1) buf_glds16(rsrc, cur[NA * h + i], soff, dst + i * 8192);
   }
 };
 
@@ -129,9 +130,10 @@ struct ConvRingBLoader {
     }
     soff = (unsigned)tap * tap_stride + (unsigned)cc * 128u;
   }
-  __device__ inline void stage(int h, char* dst) const {
+  __device__ inline void stage(int h, char* dst, int i0 = 0, int i1 = NB) const {
 #pragma unroll
-    for (int i = 0; i < NB; ++i) buf_glds16(rsrc, off[NB * h + i], soff, dst + i * 8192);
+    for (int i = 0; i < NB; ++i)
+      if (i >= i0 && i < i1) buf_glds16(rsrc, off[NB * h + i], soff, dst + i * 8192);
   }
 };
 

@@ -41,8 +41,9 @@
 // Loader concept (one object per operand, each with its own K cursor):
 //   void begin_tile();                 advance the cursor to the next K-tile; called once per
 //                                      K-tile and operand, before the first stage() of that tile
-//   void stage(int h, char* dst);      issue the N LDS-DMA instructions of half h of the cursor's
-//                                      K-tile; instruction i fills dst + i * 8192 (wave-relative)
+//   void stage(int h, char* dst, int i0, int i1);   issue LDS-DMA instructions i0 <= i < i1 (of N)
+//                                      of half h of the cursor's K-tile; instruction i fills
+//                                      dst + i * 8192 (wave-relative)
 // Both operands are fetched with buffer_load_dwordx4 ... lds (16 B per lane); an offset beyond the
 // descriptor's num_records returns zeros, which is how the convolution pads.
 #pragma once
@@ -118,9 +119,10 @@ struct RingRowLoader {
     soff = 0u - 128u;
   }
   __device__ inline void begin_tile() { soff += 128u; }
-  __device__ inline void stage(int h, char* dst) const {
+  __device__ inline void stage(int h, char* dst, int i0 = 0, int i1 = N_INSTR) const {
 #pragma unroll
-    for (int i = 0; i < N_INSTR; ++i) buf_glds16(rsrc, voff[N_INSTR * h + i], soff, dst + i * 8192);
+    for (int i = 0; i < N_INSTR; ++i)
+      if (i >= i0 && i < i1) buf_glds16(rsrc, voff[N_INSTR * h + i], soff, dst + i * 8192);
   }
 };
 
@@ -143,8 +145,15 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
   const int group = wave >> 2;
 
   char* const st_base = smem + wave * 1024;
-  auto stage_a = [&](int buf, int h) __attribute__((always_inline)) {
-    la.stage(h, st_base + buf * G::TILE + (h ? OFF_A1 : OFF_A0));
+  // SPLIT (512 x 128 tile: an A unit is 4 instructions, a B unit 1): the A unit is issued in two
+  // halves, the second one phase later together with the B unit, so that every phase carries 2-3
+  // LDS-DMA instructions instead of 4, 1, 4, 1 — the LOAD segments of the A phases were longer
+  // than a COMPUTE segment.
+  constexpr bool SPLIT = NA >= 4 * NB;
+  auto stage_a = [&](int buf, int h, int part) __attribute__((always_inline)) {
+    char* d = st_base + buf * G::TILE + (h ? OFF_A1 : OFF_A0);
+    if constexpr (SPLIT) la.stage(h, d, part * (NA / 2), (part + 1) * (NA / 2));
+    else if (part == 0) la.stage(h, d, 0, NA);
   };
   auto stage_b = [&](int buf, int h) __attribute__((always_inline)) {
     lb.stage(h, st_base + buf * G::TILE + (h ? OFF_B1 : OFF_B0));
@@ -203,13 +212,16 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
   la.begin_tile();
   lb.begin_tile();
   stage_b(0, 0);
-  stage_a(0, 0);
+  stage_a(0, 0, 0);
+  stage_a(0, 0, 1);
   stage_b(0, 1);
-  stage_a(0, 1);
+  stage_a(0, 1, 0);
+  stage_a(0, 1, 1);
   lb.begin_tile();
   stage_b(1, 0);
   la.begin_tile();
-  stage_a(1, 0);
+  stage_a(1, 0, 0);
+  stage_a(1, 0, 1);
   stage_b(1, 1);
   wait_vmcnt<2 * NA + 3 * NB>();  // B0(0), A0(0) of this wave have landed
   bar();
@@ -219,8 +231,9 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
 
   // One K-tile = 4 phases.  PAR = tile parity (LDS buffer; which register set holds B0).
   // TAIL: 0 = steady state, 1 = tile nsteps-2, 2 = tile nsteps-1 (nothing left to stage).
-  // The counted waits leave exactly the five youngest units in flight (steady state); in the tail
-  // the units that are no longer issued are subtracted.
+  // The counted waits leave exactly the five youngest units in flight (steady state; with SPLIT the
+  // not-yet-issued second half of the phase's A unit is subtracted); in the tail the units that
+  // are no longer issued are subtracted.
   // Cursor discipline: A1(t+1) is staged (P0) before la moves on to t+2 (P2); B0(t+2) is the first
   // unit of tile t+2 (P1), so lb moves there.
   auto ktile = [&](auto par_c, auto tail_c) __attribute__((always_inline)) {
@@ -231,8 +244,8 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
     // P0: A0 x B0
     read_a(PAR, 0);
     if constexpr (TAIL <= 1) {
-      stage_a(PAR ^ 1, 1);  // A1(t+1)
-      wait_vmcnt<3 * NA + 2 * NB>();
+      stage_a(PAR ^ 1, 1, 0);  // A1(t+1) (SPLIT: its first half)
+      wait_vmcnt<3 * NA + 2 * NB - (SPLIT ? NA / 2 : 0)>();
     } else wait_vmcnt<NA>();
     bar();
     compute(I0{}, I0{}, b0);
@@ -240,11 +253,14 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
     // P1: A0 x B1
     read_b(PAR, 1, b1);
     if constexpr (TAIL == 0) {
+      stage_a(PAR ^ 1, 1, 1);  // SPLIT: second half of A1(t+1)
       lb.begin_tile();
       stage_b(PAR, 0);  // B0(t+2)
       wait_vmcnt<2 * NA + 3 * NB>();
-    } else if constexpr (TAIL == 1) wait_vmcnt<2 * NA + 2 * NB>();
-    else wait_vmcnt<0>();
+    } else if constexpr (TAIL == 1) {
+      stage_a(PAR ^ 1, 1, 1);
+      wait_vmcnt<2 * NA + 2 * NB>();
+    } else wait_vmcnt<0>();
     bar();
     compute(I0{}, I1{}, b1);
     bar();
@@ -252,8 +268,8 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
     read_a(PAR, 1);
     if constexpr (TAIL == 0) {
       la.begin_tile();
-      stage_a(PAR, 0);  // A0(t+2)
-      wait_vmcnt<3 * NA + 2 * NB>();
+      stage_a(PAR, 0, 0);  // A0(t+2) (SPLIT: its first half)
+      wait_vmcnt<3 * NA + 2 * NB - (SPLIT ? NA / 2 : 0)>();
     } else if constexpr (TAIL == 1) wait_vmcnt<2 * NA + NB>();
     bar();
     compute(I1{}, I1{}, b1);
@@ -261,7 +277,8 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
     // P3: A1 x B0   (B0 of the next tile goes into the register set B1 just vacated)
     if constexpr (TAIL <= 1) read_b(PAR ^ 1, 0, b1);
     if constexpr (TAIL == 0) {
-      stage_b(PAR, 1);  // B1(t+2)
+      stage_a(PAR, 0, 1);  // SPLIT: second half of A0(t+2)
+      stage_b(PAR, 1);     // B1(t+2)
       wait_vmcnt<2 * NA + 3 * NB>();
     } else if constexpr (TAIL == 1) wait_vmcnt<NA + NB>();
     bar();
