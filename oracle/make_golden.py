@@ -169,6 +169,20 @@ def main():
                             nms_rows=nms_arr, top20=order[:, :20])
         print(name, "recalls", rec, "nms", rec_nms)
 
+    def run_rerank(name, Q, G, seed, dim=256):
+        """ibl.utils.rerank.re_ranking (rerank.py:32-100) on the reference's own distance matrices."""
+        from ibl.utils.rerank import re_ranking
+        q, g, _, _ = synth.retrieval_problem(Q, G, dim=dim, seed=seed, views_per_place=4,
+                                             hard_fraction=0.5, hard_noise_mult=35.0)
+        d = lambda a, b: ((a * a).sum(1)[:, None] + (b * b).sum(1)[None] - 2 * a @ b.t()).numpy()
+        qg, qq, gg = d(q, g), d(q, q), d(g, g)
+        outs = {f"k{k1}_{k2}_{int(lam * 10)}": re_ranking(qg.copy(), qq.copy(), gg.copy(), k1=k1, k2=k2,
+                                                          lambda_value=lam)
+                for k1, k2, lam in ((20, 6, 0.3), (25, 1, 0.0), (10, 3, 0.5))}
+        np.savez_compressed(OUT / f"{name}.npz", Q=Q, G=G, dim=dim, seed=seed, **outs)
+        print(name, {k: v.shape for k, v in outs.items()})
+
+    run_rerank("rerank_small", 24, 90, seed=31)
     run_matching("match_small", 48, 300, seed=21, views_per_place=1)
     run_matching("match_nms", 40, 360, seed=22, views_per_place=12)
     # tiny-dimension case with many exact ties is deliberately absent: np.argsort's tie order is

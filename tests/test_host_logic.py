@@ -121,3 +121,21 @@ def test_init_dist_rejects_unknown_launcher():
     from ibl.utils.dist_utils import init_dist
     with pytest.raises(ValueError):
         init_dist("none", None)
+
+
+def test_re_ranking_matches_reference_golden():
+    """openibl_amd.rerank.re_ranking against outputs of the reference's ibl.utils.rerank.re_ranking
+    (tests/golden/rerank_small.npz, produced by oracle/make_golden.py)."""
+    import numpy as np
+    from conftest import load_golden
+    from openibl_amd import synth
+    from openibl_amd.rerank import re_ranking
+    g = load_golden("rerank_small")
+    q, gal, _, _ = synth.retrieval_problem(int(g["Q"]), int(g["G"]), dim=int(g["dim"]), seed=int(g["seed"]),
+                                           views_per_place=4, hard_fraction=0.5, hard_noise_mult=35.0)
+    d = lambda a, b: ((a * a).sum(1)[:, None] + (b * b).sum(1)[None] - 2 * a @ b.t()).numpy()
+    qg, qq, gg = d(q, gal), d(q, q), d(gal, gal)
+    for key, (k1, k2, lam) in {"k20_6_3": (20, 6, 0.3), "k25_1_0": (25, 1, 0.0), "k10_3_5": (10, 3, 0.5)}.items():
+        got = re_ranking(qg.copy(), qq.copy(), gg.copy(), k1=k1, k2=k2, lambda_value=lam)
+        assert got.shape == g[key].shape and got.dtype == np.float32
+        np.testing.assert_allclose(got, g[key], rtol=0, atol=2e-6)
