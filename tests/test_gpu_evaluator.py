@@ -67,3 +67,12 @@ def test_evaluator_flows_agree_with_oracle(group, state_dict, dev):
     assert np.array_equal(r_dev, want) and np.array_equal(r_host, want)
     assert np.array_equal(r_nms, want_nms)
     assert want[0] == 1.0     # the planted copies are found
+    # rerank=True takes the reference's host flow: k-reciprocal re-ranking of the three matrices
+    r_rr = ev.evaluate(loader(qset), query + gallery, query, gallery, gt, gallery_loader=loader(gset),
+                       rerank=True, rr_topk=6, lambda_value=0.3)
+    from openibl_amd.rerank import re_ranking
+    d_rr = re_ranking(d, om.pairwise_distance(desc[:nq], desc[:nq]).numpy(),
+                      om.pairwise_distance(desc[nq:], desc[nq:]).numpy(), k1=6, k2=1, lambda_value=0.3)
+    want_rr = om.evaluate_all(d_rr, gt, [g[1] for g in gallery])
+    print("re-ranked recalls", r_rr, want_rr)
+    assert np.array_equal(r_rr, want_rr)
