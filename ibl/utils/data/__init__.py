@@ -38,9 +38,10 @@ class _TestTransform(object):
     """Resize((h, w)) — or Resize(max(h, w)) on the shorter side for Tokyo queries — then
     ToTensor and Normalize."""
 
-    def __init__(self, height, width, keep_aspect=False):
+    def __init__(self, height, width, keep_aspect=False, as_uint8=False):
         self.size = (height, width)
         self.keep_aspect = keep_aspect
+        self.as_uint8 = as_uint8
         self.mean = torch.tensor(MEAN, dtype=torch.float32).view(3, 1, 1)
         self.std = torch.tensor(STD, dtype=torch.float32).view(3, 1, 1)
 
@@ -56,12 +57,16 @@ class _TestTransform(object):
         else:
             nh, nw = self.size
         img = img.resize((nw, nh), Image.BILINEAR)
+        if self.as_uint8:   # raw [H][W][3] bytes: the model normalises them inside its first kernel
+            return torch.from_numpy(np.asarray(img, dtype=np.uint8).copy())
         x = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float() / 255.0
         return (x - self.mean) / self.std
 
 
-def get_transformer_test(height, width, tokyo=False):
-    return _TestTransform(height, width, keep_aspect=tokyo)
+def get_transformer_test(height, width, tokyo=False, as_uint8=False):
+    """as_uint8=True (extension): skip ToTensor + Normalize and hand the decoded uint8 HWC image to
+    the model, which applies exactly that arithmetic on the GPU — same descriptors, 4x less PCIe."""
+    return _TestTransform(height, width, keep_aspect=tokyo, as_uint8=as_uint8)
 
 
 def get_transformer_train(height, width):

@@ -102,6 +102,22 @@ int oibl_nhwc_to_nchw_f32(const void* feat, int N, int P, int C, int precision, 
 int oibl_nchw_f32_to_nhwc(const float* x, int N, int C, int P, int precision, void* out,
                           void* stream);
 
+/* The same backbone fed with the loader's RAW image: x_nhwc [N][H][W][3] uint8 (what
+ * PIL / cv2 decode to), ToTensor + Normalize (ibl/utils/data/__init__.py:37-42:
+ * (u / 255 - mean) / std, fp32) folded into the first kernel.  mean3_host / std3_host: 3 floats
+ * each, HOST pointers.  Results are bit-identical to oibl_vgg16_conv5_forward on the normalised
+ * fp32 tensor; the host -> device copy shrinks 4x (0.9 MB instead of 3.7 MB per 480x640 image).
+ * OIBL_BF16: the fused stem looks the normalised bf16 operand up in a 3 x 257 table built with
+ * exactly that arithmetic; OIBL_F32 (and shapes the stem does not take): a normalising
+ * uint8 -> fp32 NCHW pass into the workspace, then the regular path.  ev_*: optional hipEvent_t
+ * recorded around the matrix-core launches (as oibl_vgg16_conv5_forward_ev), may be NULL.      */
+size_t oibl_vgg16_u8_workspace_bytes(int N, int H, int W, int precision);
+int oibl_vgg16_conv5_forward_u8(const uint8_t* x_nhwc, int N, int H, int W, const float* mean3_host,
+                                const float* std3_host, const void* const* packed_w_host,
+                                const float* const* bias_host, int precision, void* feat, void* ws,
+                                size_t ws_bytes, void* stream, void* ev_igemm_begin,
+                                void* ev_igemm_end);
+
 /* Fused VGG stem, bf16: conv1_1 + ReLU + conv1_2 + ReLU + 2x2/2 max-pool in one launch —
  * replaces modules 0-4 of VGG.base (ibl/models/vgg.py:40-42; forward :61-62):
  *   x_nchw [N][3][H][W] fp32 -> out [N][H/2][W/2][64] bf16 (NHWC).

@@ -847,12 +847,15 @@ static int launch_conv_c64(const void* in, int N, int H, int W, const void* w, c
 constexpr int ST_HALO_PX = 10 * C64_HW;              // 340
 constexpr int ST_HALO_BYTES = ST_HALO_PX * 128;      // 43520
 constexpr int ST_LDS_BYTES = C64_W_BYTES + 2 * ST_HALO_BYTES;
+constexpr int ST_LUT_ENTRIES = 3 * 257;              // uint8 input: per channel 256 values + "0.0"
+constexpr int ST_LDS_BYTES_U8 = ST_LDS_BYTES + 1552;
 constexpr int ST_BLOCKS = (ST_HALO_PX + 31) / 32;    // 11 blocks of 32 halo pixels
 constexpr unsigned ST_OOB = 0xF0000000u;
 static int g_stem_fused = 1;
 
 struct StemParams {
-  const float* x;
+  const void* x;     // U8 = false: [N][3][H][W] fp32 (normalised); U8 = true: [N][H][W][3] uint8
+  float mean[3], stdv[3];  // U8 only: the loader's Normalize constants
   const float* w1;   // conv1_1 [64][3][3][3] fp32
   const float* b1;
   const char* w2;    // conv1_2 packed [9][64][64] bf16
@@ -864,10 +867,17 @@ struct StemParams {
   unsigned long long* prof;  // optional (test hook): shader-clock totals of block 0, waves 0 and 4
 };
 
+// U8 = true: the input is the loader's raw uint8 NHWC image; ToTensor + Normalize
+// (ibl/utils/data/__init__.py:40-41: (u / 255 - mean) / std in fp32) followed by the bf16 rounding
+// of the operand is a pure function of (channel, byte), so the producers look it up in a 3 x 257
+// table built in LDS at kernel start with exactly that arithmetic (entry 256 = 0.0: conv1_1's
+// zero padding) — bit-identical to feeding the normalised fp32 tensor, a quarter of the bytes.
+template <bool U8>
 __global__ __launch_bounds__(512) void vgg_stem_kernel(StemParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const wl = smem;
   char* const hb = smem + C64_W_BYTES;
+  const uint16_t* const lut = reinterpret_cast<const uint16_t*>(smem + ST_LDS_BYTES);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = lane >> 5, l31 = lane & 31;
@@ -875,6 +885,15 @@ __global__ __launch_bounds__(512) void vgg_stem_kernel(StemParams p) {
   int niter = 0;
   if (first < p.ntiles) niter = (p.ntiles - first + stride - 1) / stride;
   const int Ho = p.H >> 1, Wo = p.W >> 1;
+  if constexpr (U8) {
+    uint16_t* lw = reinterpret_cast<uint16_t*>(smem + ST_LDS_BYTES);
+    for (int i = threadIdx.x; i < ST_LUT_ENTRIES; i += 512) {
+      const int c = i / 257, u = i - 257 * c;
+      const float q = (float)u / 255.0f;
+      lw[i] = u == 256 ? (uint16_t)0 : f32_to_bf16_bits((q - p.mean[c]) / p.stdv[c]);
+    }
+    __syncthreads();
+  }
 
   if (wave >= 4) {
     // ================================ producers ================================================
@@ -884,7 +903,7 @@ __global__ __launch_bounds__(512) void vgg_stem_kernel(StemParams p) {
     // issue once the consumer's loop has ended and the two roles serialise.  The priority is
     // raised around the MFMAs only; everything else in this role runs in the consumer's shadow.
     const __amdgpu_buffer_rsrc_t rs_x =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
     // conv1_1 weights as the A operand: wf[t][s] element e <-> cout = 32 t + l31, k = 16 s + 8 half + e
     bf16x8_t wf[2][2];
 #pragma unroll
@@ -919,7 +938,7 @@ __global__ __launch_bounds__(512) void vgg_stem_kernel(StemParams p) {
       g_hy[bi] = rc / C64_HW;
       g_hx[bi] = rc - g_hy[bi] * C64_HW;
       g_swz[bi] = c64_swz(g_hy[bi], g_hx[bi]);
-      g_rel[bi] = g_hy[bi] * p.W + g_hx[bi];
+      g_rel[bi] = (g_hy[bi] * p.W + g_hx[bi]) * (U8 ? 3 : 1);
       asm volatile("" : "+v"(g_rel[bi]));
     }
     int g_dk[16];
@@ -928,9 +947,15 @@ __global__ __launch_bounds__(512) void vgg_stem_kernel(StemParams p) {
       int k = 16 * (j >> 3) + 8 * half + (j & 7);
       if (k >= 27) k -= 8;
       const int c = k / 9, t = k - 9 * c;
-      g_dk[j] = c * plane + (t / 3 - 1) * p.W + (t % 3 - 1);
+      g_dk[j] = U8 ? ((t / 3 - 1) * p.W + (t % 3 - 1)) * 3 + c
+                   : c * plane + (t / 3 - 1) * p.W + (t % 3 - 1);
       asm volatile("" : "+v"(g_dk[j]));  // keep it in a register: re-deriving it costs a v_mul per load
     }
+    // U8: table row (channel) of slot j — two compile-time candidates selected by the lane half
+    auto lut_row = [&](int j) __attribute__((always_inline)) {
+      const int kA = 16 * (j >> 3) + (j & 7), kB = kA + 8 >= 27 ? kA : kA + 8;
+      return (half ? kB / 9 : kA / 9) * 257;
+    };
     auto tap_of = [&](int j) __attribute__((always_inline)) {  // border tiles only
       const int kA = 16 * (j >> 3) + (j & 7), kB = kA + 8 >= 27 ? kA : kA + 8;
       return half ? kB % 9 : kA % 9;
@@ -952,16 +977,22 @@ __global__ __launch_bounds__(512) void vgg_stem_kernel(StemParams p) {
       int n, ty, tx;
       decode(tile, n, ty, tx);
       const int y0 = ty * 8 - 1, x0 = tx * 32 - 1;
-      const int origin = ((n * 3) * p.H + y0) * p.W + x0;  // may be "negative" for border tiles
+      // element (fp32) / byte (uint8) offset of the halo origin; may be "negative" for border tiles
+      const int origin = U8 ? ((n * p.H + y0) * p.W + x0) * 3 : ((n * 3) * p.H + y0) * p.W + x0;
       if (is_interior(ty, tx)) {
 #pragma unroll
         for (int bi = 0; bi < 3; ++bi) {
           if (pw + 4 * bi >= ST_BLOCKS) continue;  // wave-uniform
           const int base = origin + g_rel[bi];
 #pragma unroll
-          for (int j = 0; j < 16; ++j)
-            xv[bi][j] = __builtin_bit_cast(
-                float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (base + g_dk[j]) * 4, 0, 0));
+          for (int j = 0; j < 16; ++j) {
+            if constexpr (U8)
+              xv[bi][j] = __builtin_bit_cast(
+                  float, (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_x, base + g_dk[j], 0, 0));
+            else
+              xv[bi][j] = __builtin_bit_cast(
+                  float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (base + g_dk[j]) * 4, 0, 0));
+          }
         }
       } else {
 #pragma unroll
@@ -977,9 +1008,17 @@ __global__ __launch_bounds__(512) void vgg_stem_kernel(StemParams p) {
           const int base = origin + g_rel[bi];
 #pragma unroll
           for (int j = 0; j < 16; ++j) {
-            const unsigned off = ((mk >> tap_of(j)) & 1u) ? (unsigned)(base + g_dk[j]) * 4u : ST_OOB;
-            xv[bi][j] = __builtin_bit_cast(float,
-                                           __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)off, 0, 0));
+            const bool ok = (mk >> tap_of(j)) & 1u;
+            if constexpr (U8) {
+              // an invalid tap must read as 0.0 AFTER normalisation: table entry 256
+              const unsigned off = ok ? (unsigned)(base + g_dk[j]) : ST_OOB;
+              const unsigned u = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_x, (int)off, 0, 0);
+              xv[bi][j] = __builtin_bit_cast(float, ok ? u : 256u);
+            } else {
+              const unsigned off = ok ? (unsigned)(base + g_dk[j]) * 4u : ST_OOB;
+              xv[bi][j] = __builtin_bit_cast(float,
+                                             __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)off, 0, 0));
+            }
           }
         }
       }
@@ -997,7 +1036,12 @@ __global__ __launch_bounds__(512) void vgg_stem_kernel(StemParams p) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) xf[s][e] = (short)f32_to_bf16_bits(xv[bi][8 * s + e]);
+          for (int e = 0; e < 8; ++e) {
+            if constexpr (U8)
+              xf[s][e] = (short)lut[lut_row(8 * s + e) + (int)__builtin_bit_cast(unsigned, xv[bi][8 * s + e])];
+            else
+              xf[s][e] = (short)f32_to_bf16_bits(xv[bi][8 * s + e]);
+          }
         f32x16_t acc[2];
         __builtin_amdgcn_s_setprio(3);
 #pragma unroll
@@ -1172,16 +1216,23 @@ __global__ __launch_bounds__(512) void vgg_stem_kernel(StemParams p) {
   }
 }
 
-static int launch_vgg_stem(const float* x, int N, int H, int W, const float* w1, const float* b1,
-                           const void* packed_w2, const float* b2, void* out, hipStream_t st) {
+// mean3 / std3: host pointers, used only when U8
+template <bool U8>
+static int launch_vgg_stem(const void* x, int N, int H, int W, const float* mean3, const float* std3,
+                           const float* w1, const float* b1, const void* packed_w2, const float* b2,
+                           void* out, hipStream_t st) {
   StemParams p;
   p.x = x;
+  for (int c = 0; c < 3; ++c) {
+    p.mean[c] = U8 ? mean3[c] : 0.f;
+    p.stdv[c] = U8 ? std3[c] : 1.f;
+  }
   p.w1 = w1;
   p.b1 = b1;
   p.w2 = (const char*)packed_w2;
   p.b2 = b2;
   p.out = (char*)out;
-  p.x_bytes = (unsigned)((size_t)N * 3 * H * W * 4);
+  p.x_bytes = (unsigned)((size_t)N * 3 * H * W * (U8 ? 1 : 4));
   p.N = N;
   p.H = H;
   p.W = W;
@@ -1193,15 +1244,34 @@ static int launch_vgg_stem(const float* x, int N, int H, int W, const float* w1,
   p.prof = g_prof_buf;
   int gx = 256;  // one persistent workgroup per CU
   if (gx > p.ntiles) gx = p.ntiles;
+  constexpr int lds = U8 ? ST_LDS_BYTES_U8 : ST_LDS_BYTES;
+  auto kern = vgg_stem_kernel<U8>;
   static bool attr_done = false;
   if (!attr_done) {
-    OIBL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(vgg_stem_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_BYTES));
+    OIBL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
-  hipLaunchKernelGGL(vgg_stem_kernel, dim3(gx), dim3(512), ST_LDS_BYTES, st, p);
+  hipLaunchKernelGGL(kern, dim3(gx), dim3(512), lds, st, p);
   OIBL_LAUNCH_CHECK();
   return OIBL_OK;
+}
+
+// uint8 NHWC -> normalised fp32 NCHW with the loader's arithmetic ((u / 255 - mean) / std, fp32,
+// correctly rounded divisions): the route of the uint8 entry point whenever the fused stem is not
+// used (fp32 precision, test hooks)
+__global__ void u8_nhwc_to_nchw_f32_kernel(const uint8_t* __restrict__ x, float* __restrict__ out,
+                                           long npix_total, long plane, float m0, float m1, float m2,
+                                           float s0, float s1, float s2) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix_total;
+       i += (long)gridDim.x * blockDim.x) {
+    const long n = i / plane, pix = i - n * plane;
+    const uint8_t* px = x + i * 3;
+    float* o = out + n * 3 * plane + pix;
+    o[0] = ((float)px[0] / 255.0f - m0) / s0;
+    o[plane] = ((float)px[1] / 255.0f - m1) / s1;
+    o[2 * plane] = ((float)px[2] / 255.0f - m2) / s2;
+  }
 }
 
 static bool stem_eligible(int N, int H, int W) {
@@ -1339,7 +1409,8 @@ int oibl_vgg16_stem_bf16(const float* x_nchw, int N, int H, int W, const float* 
   OIBL_REQUIRE(stem_eligible(N, H, W), "vgg16_stem: input of %d x 3 x %d x %d exceeds 3.5 GB", N, H, W);
   OIBL_REQUIRE((uintptr_t)packed_w2 % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)x_nchw % 4 == 0,
                "vgg16_stem: packed weights / output must be 16-byte aligned");
-  return launch_vgg_stem(x_nchw, N, H, W, w1_oihw, b1, packed_w2, b2, out, (hipStream_t)stream);
+  return launch_vgg_stem<false>(x_nchw, N, H, W, nullptr, nullptr, w1_oihw, b1, packed_w2, b2, out,
+                                (hipStream_t)stream);
 }
 
 int oibl_debug_set_conv_c64(int on) {  // 0 = off, 1 = auto, 2 = every Cin = 64 layer
@@ -1502,16 +1573,19 @@ int oibl_vgg16_conv5_forward(const float* x_nchw, int N, int H, int W,
                                      ws_bytes, stream, nullptr, nullptr);
 }
 
-int oibl_vgg16_conv5_forward_ev(const float* x_nchw, int N, int H, int W,
-                                const void* const* packed_w_host, const float* const* bias_host,
-                                int precision, void* feat, void* ws, size_t ws_bytes, void* stream,
-                                void* ev_igemm_begin, void* ev_igemm_end) {
-  OIBL_REQUIRE(x_nchw && packed_w_host && bias_host && feat && ws, "vgg16: null pointer");
+// x: fp32 NCHW (u8 = 0) or uint8 NHWC + Normalize constants (u8 = 1, host pointers mean3 / std3)
+static int vgg_forward_impl(const void* x, int u8, const float* mean3, const float* std3, int N, int H,
+                            int W, const void* const* packed_w_host, const float* const* bias_host,
+                            int precision, void* feat, void* ws, size_t ws_bytes, void* stream,
+                            void* ev_igemm_begin, void* ev_igemm_end) {
+  OIBL_REQUIRE(x && packed_w_host && bias_host && feat && ws, "vgg16: null pointer");
+  OIBL_REQUIRE(!u8 || (mean3 && std3), "vgg16: uint8 input needs the mean / std constants");
   OIBL_REQUIRE(precision == OIBL_BF16 || precision == OIBL_F32, "vgg16: bad precision %d",
                precision);
   OIBL_REQUIRE(N > 0 && H >= 16 && W >= 16, "vgg16: bad shape N=%d H=%d W=%d", N, H, W);
   OIBL_REQUIRE((uintptr_t)ws % 256 == 0, "vgg16: workspace must be 256-byte aligned");
-  const size_t need = oibl_vgg16_workspace_bytes(N, H, W, precision);
+  const size_t base_need = oibl_vgg16_workspace_bytes(N, H, W, precision);
+  const size_t need = u8 ? oibl_vgg16_u8_workspace_bytes(N, H, W, precision) : base_need;
   if (ws_bytes < need) {
     set_error("vgg16: workspace %zu < required %zu bytes", ws_bytes, need);
     return OIBL_E_WORKSPACE;
@@ -1521,31 +1595,45 @@ int oibl_vgg16_conv5_forward_ev(const float* x_nchw, int N, int H, int W,
   const size_t es = oibl_elem_size(precision);
   char* bufA = (char*)ws;
   char* bufB = bufA + align_up(ea * es, 256);
+  hipStream_t st = (hipStream_t)stream;
 
   int rc;
   int h = H, w = W, l0 = 1;
   const void* cur = bufA;
-  if (precision == OIBL_BF16 && g_stem_fused && stem_eligible(N, H, W) && !g_regstage &&
-      !g_conv_ablate) {
+  const bool fused = precision == OIBL_BF16 && g_stem_fused && stem_eligible(N, H, W) &&
+                     !g_regstage && !g_conv_ablate;
+  const float* x_f32 = (const float*)x;
+  if (u8 && !fused) {  // normalise into the fp32 staging area behind the activation buffers
+    float* stage = (float*)((char*)ws + base_need);
+    const long npix = (long)N * H * W;
+    hipLaunchKernelGGL(u8_nhwc_to_nchw_f32_kernel, dim3(2048), dim3(256), 0, st, (const uint8_t*)x,
+                       stage, npix, (long)H * W, mean3[0], mean3[1], mean3[2], std3[0], std3[1],
+                       std3[2]);
+    OIBL_LAUNCH_CHECK();
+    x_f32 = stage;
+  }
+  if (fused) {
     // conv1_1 + conv1_2 + pool in one launch (the matrix-core span then starts with it)
-    if (ev_igemm_begin) OIBL_HIP_CHECK(hipEventRecord((hipEvent_t)ev_igemm_begin, (hipStream_t)stream));
-    rc = launch_vgg_stem(x_nchw, N, H, W, (const float*)packed_w_host[0], bias_host[0],
-                         packed_w_host[1], bias_host[1], bufB, (hipStream_t)stream);
+    if (ev_igemm_begin) OIBL_HIP_CHECK(hipEventRecord((hipEvent_t)ev_igemm_begin, st));
+    rc = u8 ? launch_vgg_stem<true>(x, N, H, W, mean3, std3, (const float*)packed_w_host[0],
+                                    bias_host[0], packed_w_host[1], bias_host[1], bufB, st)
+            : launch_vgg_stem<false>(x, N, H, W, nullptr, nullptr, (const float*)packed_w_host[0],
+                                     bias_host[0], packed_w_host[1], bias_host[1], bufB, st);
     if (rc) return rc;
     h /= 2;
     w /= 2;
     cur = bufB;
     l0 = 2;
   } else {
-    rc = oibl_conv1_1_nchw(x_nchw, N, H, W, (const float*)packed_w_host[0], bias_host[0], precision,
+    rc = oibl_conv1_1_nchw(x_f32, N, H, W, (const float*)packed_w_host[0], bias_host[0], precision,
                            bufA, stream);
     if (rc) return rc;
-    if (ev_igemm_begin) OIBL_HIP_CHECK(hipEventRecord((hipEvent_t)ev_igemm_begin, (hipStream_t)stream));
+    if (ev_igemm_begin) OIBL_HIP_CHECK(hipEventRecord((hipEvent_t)ev_igemm_begin, st));
   }
   for (int l = l0; l < OIBL_VGG16_NUM_CONV; ++l) {
     void* dst = (l == OIBL_VGG16_NUM_CONV - 1) ? feat : (l % 2 == 0 ? (void*)bufA : (void*)bufB);
     rc = conv3x3_impl(cur, N, h, w, kVgg[l].cin, packed_w_host[l], bias_host[l], kVgg[l].cout,
-                      kVgg[l].relu, kVgg[l].pool, precision, dst, (hipStream_t)stream);
+                      kVgg[l].relu, kVgg[l].pool, precision, dst, st);
     if (rc) return rc;
     if (kVgg[l].pool) {
       h /= 2;
@@ -1553,8 +1641,30 @@ int oibl_vgg16_conv5_forward_ev(const float* x_nchw, int N, int H, int W,
     }
     cur = dst;
   }
-  if (ev_igemm_end) OIBL_HIP_CHECK(hipEventRecord((hipEvent_t)ev_igemm_end, (hipStream_t)stream));
+  if (ev_igemm_end) OIBL_HIP_CHECK(hipEventRecord((hipEvent_t)ev_igemm_end, st));
   return OIBL_OK;
+}
+
+int oibl_vgg16_conv5_forward_ev(const float* x_nchw, int N, int H, int W,
+                                const void* const* packed_w_host, const float* const* bias_host,
+                                int precision, void* feat, void* ws, size_t ws_bytes, void* stream,
+                                void* ev_igemm_begin, void* ev_igemm_end) {
+  return vgg_forward_impl(x_nchw, 0, nullptr, nullptr, N, H, W, packed_w_host, bias_host, precision,
+                          feat, ws, ws_bytes, stream, ev_igemm_begin, ev_igemm_end);
+}
+
+size_t oibl_vgg16_u8_workspace_bytes(int N, int H, int W, int precision) {
+  const size_t b = oibl_vgg16_workspace_bytes(N, H, W, precision);
+  return b ? b + align_up((size_t)N * 3 * H * W * sizeof(float), 256) : 0;
+}
+
+int oibl_vgg16_conv5_forward_u8(const uint8_t* x_nhwc, int N, int H, int W, const float* mean3_host,
+                                const float* std3_host, const void* const* packed_w_host,
+                                const float* const* bias_host, int precision, void* feat, void* ws,
+                                size_t ws_bytes, void* stream, void* ev_igemm_begin,
+                                void* ev_igemm_end) {
+  return vgg_forward_impl(x_nhwc, 1, mean3_host, std3_host, N, H, W, packed_w_host, bias_host,
+                          precision, feat, ws, ws_bytes, stream, ev_igemm_begin, ev_igemm_end);
 }
 
 }  // extern "C"

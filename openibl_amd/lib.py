@@ -39,6 +39,10 @@ SIGNATURES = {
     "oibl_vgg16_conv5_forward_ev": (c_int, [c_void_p, c_int, c_int, c_int, C.POINTER(c_void_p),
                                             C.POINTER(c_void_p), c_int, c_void_p, c_void_p,
                                             c_size_t, c_void_p, c_void_p, c_void_p]),
+    "oibl_vgg16_u8_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "oibl_vgg16_conv5_forward_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                            C.POINTER(c_void_p), C.POINTER(c_void_p), c_int, c_void_p,
+                                            c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "oibl_vgg16_stem_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p]),
     "oibl_netvlad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),

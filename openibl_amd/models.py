@@ -127,8 +127,10 @@ class VGG(_PrecisionMixin, nn.Module):
         return hit[1], hit[2]
 
     def features_nhwc(self, x: torch.Tensor) -> torch.Tensor:
-        """[N][3][H][W] fp32 -> conv5_3 map [N][h][w][512] in the precision's element type."""
-        if x.dtype != torch.float32:
+        """[N][3][H][W] fp32 (normalised) or [N][H][W][3] uint8 (raw image; the loader's
+        ToTensor + Normalize run inside the first kernel) -> conv5_3 map [N][h][w][512] in the
+        precision's element type."""
+        if x.dtype != torch.uint8 and x.dtype != torch.float32:
             x = x.float()
         x = x.contiguous()
         ws, bs = self._packed(x.device)
@@ -251,8 +253,9 @@ class GraphedDescriptor:
     around the backbone graph (bench.py's matrix-core span)."""
 
     def __init__(self, model: "EmbedNetPCA", example: torch.Tensor):
-        if not example.is_cuda or example.dtype != torch.float32 or example.dim() != 4:
-            raise ValueError("graphed(): example must be a float32 CUDA tensor [N][3][H][W]")
+        if not example.is_cuda or example.dtype not in (torch.float32, torch.uint8) or example.dim() != 4:
+            raise ValueError("graphed(): example must be a CUDA tensor, float32 [N][3][H][W] or "
+                             "uint8 [N][H][W][3]")
         self.static_in = example.clone(memory_format=torch.contiguous_format)   # private: never aliases a caller's tensor
         with torch.no_grad():
             model(self.static_in)               # packs weights, sizes every workspace, warms up

@@ -203,23 +203,39 @@ def vgg16_feature_hw(H: int, W: int) -> Tuple[int, int]:
     return H, W
 
 
+# Normalize constants of the reference's loader (ibl/utils/data/__init__.py:40-41): std = 1/255,
+# i.e. mean-subtracted 0..255 pixels
+REF_MEAN = (0.48501960784313836, 0.4579568627450961, 0.4076039215686255)
+REF_STD = (0.00392156862745098, 0.00392156862745098, 0.00392156862745098)
+
+
 def vgg16_conv5(x: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor],
-                precision, events=None) -> torch.Tensor:
-    """x [N][3][H][W] fp32 -> conv5_3 feature map [N][h][w][512] T (NHWC), h = H//16, w = W//16.
+                precision, events=None, mean=REF_MEAN, std=REF_STD) -> torch.Tensor:
+    """conv5_3 feature map [N][h][w][512] T (NHWC), h = H//16, w = W//16, of
+      x [N][3][H][W] float32, already normalised (what the reference's loader hands over), or
+      x [N][H][W][3] uint8, the raw decoded image: ToTensor + Normalize(mean, std) are folded into
+        the first kernel (bit-identical results, a quarter of the bytes over PCIe).
 
     weights[0] is the plain conv1_1 tensor, weights[1:] come from pack_conv3x3.
     `events`: optional pair of already-recorded torch.cuda.Event(enable_timing=True); they are
-    re-recorded right before / after the 12 implicit-GEMM convolutions (bench.py's roofline)."""
+    re-recorded right before / after the matrix-core convolutions (bench.py's roofline)."""
     p = precision_code(precision)
     dev = _need_cuda(x, *weights, *biases)
-    if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3:
-        raise ValueError("vgg16_conv5 expects a float32 [N][3][H][W] tensor")
+    u8 = x.dtype == torch.uint8
+    if u8:
+        if x.dim() != 4 or x.shape[3] != 3:
+            raise ValueError("vgg16_conv5: uint8 input must be [N][H][W][3]")
+        N, H, W, _ = map(int, x.shape)
+    else:
+        if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError("vgg16_conv5 expects a float32 [N][3][H][W] or uint8 [N][H][W][3] tensor")
+        N, _, H, W = map(int, x.shape)
     if len(weights) != 13 or len(biases) != 13:
         raise ValueError("vgg16_conv5 needs 13 weights and 13 biases")
-    N, _, H, W = map(int, x.shape)
+    x = x.contiguous()
     h, w = vgg16_feature_hw(H, W)
     lib = _lib.load()
-    ws_bytes = lib.oibl_vgg16_workspace_bytes(N, H, W, p)
+    ws_bytes = (lib.oibl_vgg16_u8_workspace_bytes if u8 else lib.oibl_vgg16_workspace_bytes)(N, H, W, p)
     if ws_bytes == 0:
         raise ValueError(f"vgg16_conv5: unsupported input shape {tuple(x.shape)}")
     ws = workspace(ws_bytes, dev, "vgg")
@@ -229,9 +245,16 @@ def vgg16_conv5(x: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequen
     ev0 = ev1 = None
     if events is not None:
         ev0, ev1 = int(events[0].cuda_event), int(events[1].cuda_event)
-    _lib.check(lib.oibl_vgg16_conv5_forward_ev(_ptr(x), N, H, W, wp, bp, p, _ptr(feat), _ptr(ws),
-                                               ws.numel(), _stream(dev), ev0, ev1),
-               "vgg16_conv5_forward")
+    if u8:
+        m3 = (C.c_float * 3)(*[float(v) for v in mean])
+        s3 = (C.c_float * 3)(*[float(v) for v in std])
+        _lib.check(lib.oibl_vgg16_conv5_forward_u8(_ptr(x), N, H, W, m3, s3, wp, bp, p, _ptr(feat),
+                                                   _ptr(ws), ws.numel(), _stream(dev), ev0, ev1),
+                   "vgg16_conv5_forward_u8")
+    else:
+        _lib.check(lib.oibl_vgg16_conv5_forward_ev(_ptr(x), N, H, W, wp, bp, p, _ptr(feat), _ptr(ws),
+                                                   ws.numel(), _stream(dev), ev0, ev1),
+                   "vgg16_conv5_forward")
     return feat
 
 

@@ -131,3 +131,25 @@ def test_graphed_forward_equals_eager(dev):
     assert torch.equal(fwd(x1), want1)
     with pytest.raises(ValueError):
         fwd(synth.images(1, 64, 96, seed=1).to(dev))
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("N,H,W", [(2, 64, 96), (1, 70, 90), (1, 480, 640)])
+def test_uint8_input_equals_normalised_input(dev, N, H, W, precision):
+    """Raw uint8 NHWC images (ToTensor + Normalize folded into the first kernel) give the same
+    descriptors, bit for bit, as the loader's normalised fp32 NCHW tensor."""
+    import hubconf
+    from ibl.utils.data import MEAN, STD
+    model = hubconf.vgg16_netvlad(pretrained=False)
+    model.load_state_dict(synth.embednetpca_state(0))
+    model = model.to(dev).eval().set_precision(precision)
+    g = torch.Generator().manual_seed(H + W)
+    u8 = torch.randint(0, 256, (N, H, W, 3), generator=g, dtype=torch.uint8)
+    u8[0, 0, :, :] = 0                      # a run of zeros on the border (padding vs value 0)
+    u8[0, -1, :, :] = 255
+    mean = torch.tensor(MEAN, dtype=torch.float32).view(1, 3, 1, 1)
+    std = torch.tensor(STD, dtype=torch.float32).view(1, 3, 1, 1)
+    x = (u8.permute(0, 3, 1, 2).float() / 255.0 - mean) / std       # the reference transform
+    want = model(x.to(dev))
+    got = model(u8.to(dev))
+    assert torch.equal(got, want)
