@@ -261,10 +261,13 @@ class GraphedDescriptor:
             model(self.static_in)               # packs weights, sizes every workspace, warms up
             torch.cuda.synchronize(example.device)
             self.g_backbone = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_backbone):
+            # thread_local: a communicator's watchdog thread (RCCL, one process per GPU) may touch
+            # the HIP runtime while this thread captures
+            with torch.cuda.graph(self.g_backbone, capture_error_mode="thread_local"):
                 feat = model.base_model.features_nhwc(self.static_in)
             self.g_head = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_head, pool=self.g_backbone.pool()):
+            with torch.cuda.graph(self.g_head, pool=self.g_backbone.pool(),
+                                  capture_error_mode="thread_local"):
                 _, vlad = model.net_vlad.aggregate_nhwc(feat, want_raw=False, want_norm=True)
                 w, b = model._pca_params()
                 self.out = ops.pca(vlad, w, b, l2norm=True)
