@@ -439,6 +439,7 @@ static int launch_conv_cfg(const ConvParams& p, hipStream_t st) {
 }
 
 static unsigned long long* g_prof_buf = nullptr;  // test hook: phase profile of block 0
+static int g_ring_ablate = 0;                     // test hook: see RingParams::ablate
 
 // ring-schedule kernel (conv_ring.h): bf16, Cin % 64 == 0; WM = 2: 256 x 256 tile (Cout % 256 == 0),
 // WM = 4: 512 x 128 tile (Cout % 128 == 0)
@@ -462,6 +463,7 @@ static int launch_conv_ring_impl(const ConvParams& p, hipStream_t st) {
   q.tiles_n = p.cout / G::BN;
   q.relu = p.relu;
   q.prof = g_prof_buf;
+  q.ablate = g_ring_ablate;
   const long tiles_m = (p.m_total + G::BM - 1) / G::BM;
   const long grid = tiles_m * q.tiles_n;
   constexpr int lds = ring_lds_bytes<WM, POOL>();
@@ -1420,6 +1422,11 @@ int oibl_debug_set_conv_c64(int on) {  // 0 = off, 1 = auto, 2 = every Cin = 64 
 
 int oibl_debug_set_conv_ablate(int mode) {
   g_conv_ablate = mode;
+  return OIBL_OK;
+}
+
+int oibl_debug_set_ring_ablate(int mode) {
+  g_ring_ablate = mode;
   return OIBL_OK;
 }
 

@@ -27,6 +27,8 @@ struct RingParams {
   int tiles_n;
   int relu;
   unsigned long long* prof;  // optional (test hook): shader-clock stamps of block 0, wave 0
+  int ablate;  // timing experiments only (WRONG results): 1 = pixel loads of taps != 0 all hit one
+               // line, 2 = weight loads after the first K-tile all hit one line, 3 = both
 };
 
 template <int WM, bool POOL>
@@ -44,8 +46,8 @@ template <int NA, bool POOL>
 struct ConvRingALoader {
   __amdgpu_buffer_rsrc_t rsrc;
   unsigned base[2 * NA], mask[2 * NA], cur[2 * NA];
-  unsigned soff;
-  int tap, cc, cchunks, W, pix_bytes;
+  unsigned soff, abl_piece;
+  int tap, cc, cchunks, W, pix_bytes, ablate;
   __device__ inline void init(const RingParams& p, int m0, const int (&tile_row)[2 * NA], int piece) {
     rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
     pix_bytes = p.cin * 2;
@@ -54,6 +56,8 @@ struct ConvRingALoader {
     tap = 0;
     cc = -1;
     soff = 0;
+    ablate = p.ablate & 1;
+    abl_piece = (unsigned)piece;
     const int Hq = POOL ? (p.H >> 1) : p.H, Wq = POOL ? (p.W >> 1) : p.W;
     const unsigned hw = (unsigned)Hq * (unsigned)Wq;
 #pragma unroll
@@ -94,6 +98,10 @@ struct ConvRingALoader {
 #pragma unroll
       for (int j = 0; j < 2 * NA; ++j)
         cur[j] = ((mask[j] >> tap) & 1u) ? base[j] + (unsigned)toff : RG_OOB;
+      if (ablate && tap != 0) {
+#pragma unroll
+        for (int j = 0; j < 2 * NA; ++j) cur[j] = abl_piece;
+      }
     }
     soff = (unsigned)cc * 128u;
   }
@@ -109,8 +117,8 @@ template <int NB>
 struct ConvRingBLoader {
   __amdgpu_buffer_rsrc_t rsrc;
   unsigned off[2 * NB];
-  unsigned soff, tap_stride;
-  int tap, cc, cchunks;
+  unsigned soff, tap_stride, abl_piece;
+  int tap, cc, cchunks, ablate;
   __device__ inline void init(const RingParams& p, int n0, const int (&tile_row)[2 * NB], int piece) {
     rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
     const unsigned pix_bytes = (unsigned)p.cin * 2u;
@@ -119,6 +127,8 @@ struct ConvRingBLoader {
     tap = 0;
     cc = -1;
     soff = 0;
+    ablate = p.ablate & 2;
+    abl_piece = (unsigned)piece;
 #pragma unroll
     for (int j = 0; j < 2 * NB; ++j) off[j] = (unsigned)(n0 + tile_row[j]) * pix_bytes + piece;
   }
@@ -129,6 +139,11 @@ struct ConvRingBLoader {
       ++tap;
     }
     soff = (unsigned)tap * tap_stride + (unsigned)cc * 128u;
+    if (ablate && (tap != 0 || cc != 0)) {
+      soff = 0;
+#pragma unroll
+      for (int j = 0; j < 2 * NB; ++j) off[j] = abl_piece;
+    }
   }
   __device__ inline void stage(int h, char* dst, int i0 = 0, int i1 = NB) const {
 #pragma unroll

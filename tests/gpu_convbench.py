@@ -27,8 +27,14 @@ def main():
     ap.add_argument("--modes", default="3,4")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=4)
+    ap.add_argument("--ablate", default="", help="timing experiment: comma list of ring ablate modes "
+                    "(1 = pixel loads, 2 = weight loads, 3 = both served from one line; results wrong)")
     a = ap.parse_args()
     modes = [int(m) for m in a.modes.split(",")]
+    from openibl_amd import lib as _l
+    abl = [int(v) for v in a.ablate.split(",")] if a.ablate else []
+    if abl:                       # pseudo-modes 100 + ablate code, all on the auto (ring) kernel
+        modes = [0] + [100 + v for v in abl]
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev).manual_seed(5)
     tot = {m: 0.0 for m in modes}
@@ -40,13 +46,16 @@ def main():
         b = torch.randn((cout,), generator=g, device=dev) * 0.1
         wp = ops.pack_conv3x3(w, "bf16")
         outs, times = {}, {m: [] for m in modes}
+        def select(m):
+            ops.set_conv_tile(0 if m >= 100 else m)
+            _l.load().oibl_debug_set_ring_ablate(m - 100 if m >= 100 else 0)
         for m in modes:
-            ops.set_conv_tile(m)
+            select(m)
             outs[m] = ops.conv3x3_nhwc(x, wp, b, bool(relu), bool(pool), "bf16")
         torch.cuda.synchronize()
         for _ in range(a.rounds):
             for m in modes:
-                ops.set_conv_tile(m)
+                select(m)
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
                 for _ in range(a.iters):
@@ -54,7 +63,7 @@ def main():
                 e.record()
                 torch.cuda.synchronize()
                 times[m].append(s.elapsed_time(e) / a.iters)
-        ops.set_conv_tile(0)
+        select(0)
         fl = 2.0 * N * H * W * cout * 9 * cin
         totfl += fl
         ref = outs[modes[0]]
