@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of a hipGraph replay")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="run NetVLAD+PCA of a step on the same stream instead of overlapping it with the next backbone")
     ap.add_argument("--skip-matching", action="store_true")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--queries", type=int, default=8192)
@@ -110,8 +112,10 @@ def main():
     # Timed steps replay the forward as two hipGraphs (backbone: the 12 matrix-core launches; head:
     # NetVLAD + PCA) — `model.graphed(x)`, the same kernels on the same data as `model(x)`, but two
     # graph launches per step instead of ~30 kernel launches, so that the number does not depend on
-    # how quickly a shared, possibly busy host core issues launches.  The span events are recorded
-    # on the launching stream around the backbone graph.  --eager times `model(x)` launch by launch.
+    # how quickly a shared, possibly busy host core issues launches.  The head of step i runs on a
+    # second stream while the backbone of step i+1 starts (--no-pipeline: one stream); every step's
+    # head has completed when the closing barrier returns.  The span events are recorded on the
+    # launching stream around the backbone graph.  --eager times `model(x)` launch by launch.
     launch_mode = "eager"
     fwd = None
     with torch.no_grad():
@@ -119,10 +123,14 @@ def main():
             model(x)
         if not args.eager:
             try:
-                fwd = model.graphed(x)
+                fwd = model.graphed(x, pipeline=not args.no_pipeline)
                 ref = model(x)
-                assert torch.equal(fwd(), ref), "graph replay differs from the eager forward"
-                launch_mode = "hipGraph x2 per step"
+                got = [fwd(), fwd()]    # both pipeline slots, in flight together
+                fwd.wait()
+                torch.cuda.synchronize(dev)
+                assert all(torch.equal(g_, ref) for g_ in got), "graph replay differs from the eager forward"
+                launch_mode = ("hipGraph x2 per step" if args.no_pipeline else
+                               "hipGraph x2 per step, head of step i overlapped with backbone of step i+1")
             except Exception as e:      # capture unsupported on this stack: time the eager launches
                 print(f"[bench] hipGraph capture failed ({e!r}); timing eager launches", file=sys.stderr)
                 fwd = None
@@ -142,6 +150,8 @@ def main():
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
     assert tuple(out.shape) == (args.batch, 4096) and bool(torch.isfinite(out).all())
+    with torch.no_grad():     # the timed steps produced the descriptors the eager forward produces
+        assert torch.equal(out, model(x)), "timed forward differs from model(x)"
 
     images = args.batch * args.steps * world
     value = images / elapsed

@@ -131,6 +131,20 @@ def test_graphed_forward_equals_eager(dev):
     assert torch.equal(fwd(x1), want1)
     with pytest.raises(ValueError):
         fwd(synth.images(1, 64, 96, seed=1).to(dev))
+    # pipelined: head of call i on a second stream, overlapped with the backbone of call i+1
+    pf = model.graphed(x1, pipeline=True)
+    outs = []
+    for x, want in ((x1, want1), (x2, want2), (x1, want1), (x2, want2), (x2, want2)):
+        o = pf(x)
+        pf.wait()
+        outs.append((o.clone(), want))
+    torch.cuda.synchronize()
+    for o, want in outs:
+        assert torch.equal(o, want)
+    a, b = pf(x1), pf(x2)          # two calls in flight: each slot keeps its own result
+    pf.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(a, want1) and torch.equal(b, want2)
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp32"])
