@@ -1135,6 +1135,20 @@ __global__ __launch_bounds__(512) void vgg_stem_kernel(StemParams p) {
 
   const bool cprof = p.prof != nullptr && blockIdx.x == 0 && wave == 0;
   unsigned long long ct[3] = {0, 0, 0};
+  // The pooled outputs of tile i are held back (8 packed registers) and stored one pixel at a time
+  // between the matrix steps of tile i+1, so the store issue hides in the MFMA shadow.
+  uint32_t pend[8];
+  uint32_t pmask = 0;  // bit e: pixel e = 4 i + g of the held tile is inside the image (per lane)
+  char* pbase = p.out;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) pend[e] = 0;
+  auto store_px = [&](int e) __attribute__((always_inline)) {
+    if ((pmask >> e) & 1) {
+      uint16_t* o = reinterpret_cast<uint16_t*>(pbase + (8 * (e >> 2) + 2 * (e & 3)) * 128);
+      o[0] = (uint16_t)pend[e];
+      o[32] = (uint16_t)(pend[e] >> 16);
+    }
+  };
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   for (int it = 0; it < niter; ++it) {
@@ -1173,36 +1187,35 @@ __global__ __launch_bounds__(512) void vgg_stem_kernel(StemParams p) {
         for (int tn = 0; tn < 2; ++tn)
           acc[i][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sidx & 1][i], fb[sidx & 1][tn],
                                                                acc[i][tn], 0, 0, 0);
+      if ((sidx & 3) == 1 && (sidx >> 2) < 8) store_px(sidx >> 2);
     }
     // all fragment reads of `cur` have been consumed by the MFMAs above: hand the buffer back
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const unsigned long long c1 = cprof ? __builtin_amdgcn_s_memtime() : 0;
     __builtin_amdgcn_s_barrier();
     const unsigned long long c2 = cprof ? __builtin_amdgcn_s_memtime() : 0;
-    // pooled epilogue straight from registers: lanes 0-31 / 32-63 each write the 32 channels of one
-    // pooled pixel (64 contiguous bytes); the two tn halves complete the 128-byte line
+    // pooled epilogue from registers: lanes 0-31 / 32-63 each hold the 32 channels of one pooled
+    // pixel (64 contiguous bytes); the two tn halves (low / high 16 bits) complete the 128-byte line
     const unsigned r2 = (unsigned)tile / (unsigned)p.tiles_x;
     const int tx = tile - (int)r2 * p.tiles_x;
     const int n = (int)(r2 / (unsigned)p.tiles_y), ty = (int)r2 - n * p.tiles_y;
     const int oy = ty * 4 + wave;
     // lane's first pooled pixel (i = g = 0) of this wave's pooled row; pixel (i, g) is 8 i + 2 g
     // pixels = (8 i + 2 g) * 128 bytes further: immediate offsets on one base address
-    char* const obase = p.out + ((((long)n * Ho + oy) * Wo + tx * 16 + half) * 64 + l31) * 2;
-    const bool full = oy < Ho && tx * 16 + 16 <= Wo;  // wave-uniform: no per-pixel predicate
+    pbase = p.out + ((((long)n * Ho + oy) * Wo + tx * 16 + half) * 64 + l31) * 2;
+    pmask = 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int ox = tx * 16 + 8 * i + 2 * g + half;
-        if (full || (oy < Ho && ox < Wo)) {
-          uint16_t* o = reinterpret_cast<uint16_t*>(obase + (8 * i + 2 * g) * 128);
+        pmask |= (oy < Ho && ox < Wo) ? (1u << (4 * i + g)) : 0u;
+        float v[2];
 #pragma unroll
-          for (int tn = 0; tn < 2; ++tn) {
-            const float v = fmaxf(fmaxf(acc[i][tn][4 * g], acc[i][tn][4 * g + 1]),
-                                  fmaxf(acc[i][tn][4 * g + 2], acc[i][tn][4 * g + 3]));
-            o[tn * 32] = f32_to_bf16_bits(fmaxf(v, 0.f));
-          }
-        }
+        for (int tn = 0; tn < 2; ++tn)
+          v[tn] = fmaxf(fmaxf(fmaxf(acc[i][tn][4 * g], acc[i][tn][4 * g + 1]),
+                              fmaxf(acc[i][tn][4 * g + 2], acc[i][tn][4 * g + 3])), 0.f);
+        pend[4 * i + g] = pack_bf16x2(v[0], v[1]);
       }
     if (cprof) {
       const unsigned long long c3 = __builtin_amdgcn_s_memtime();
@@ -1211,6 +1224,8 @@ __global__ __launch_bounds__(512) void vgg_stem_kernel(StemParams p) {
       ct[2] += c3 - c2;
     }
   }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) store_px(e);
   if (cprof && lane == 0) {
     p.prof[0] = ct[0];
     p.prof[1] = ct[1];
