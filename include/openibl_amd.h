@@ -43,6 +43,11 @@ extern "C" {
 #define OIBL_BF16 0
 #define OIBL_F32 1
 
+/* Storage type of a descriptor matrix handed to the *_st matching entry points. */
+#define OIBL_ST_F32 0
+#define OIBL_ST_F16 1  /* IEEE binary16 */
+#define OIBL_ST_BF16 2
+
 #define OIBL_VGG16_NUM_CONV 13
 
 /* ---- library ---------------------------------------------------------------------- */
@@ -62,6 +67,19 @@ size_t oibl_elem_size(int precision);
 int oibl_cast_f32_to_bf16(const float* src, uint16_t* dst, size_t n, void* stream);
 /* bf16 -> fp32, n elements. */
 int oibl_cast_bf16_to_f32(const uint16_t* src, float* dst, size_t n, void* stream);
+/* fp32 <-> IEEE binary16 (round-to-nearest-even), n elements: 16-bit descriptor storage
+ * (BASELINE.json configs[4], "fp16 descriptors"; no counterpart in the reference). */
+int oibl_cast_f32_to_f16(const float* src, uint16_t* dst, size_t n, void* stream);
+int oibl_cast_f16_to_f32(const uint16_t* src, float* dst, size_t n, void* stream);
+
+/* ---- bilinear resize --------------------------------------------------------------- *
+ * x [N][C][H][W] fp32 -> out [N][C][H2][W2] fp32 with the arithmetic of
+ * torch.nn.functional.interpolate(x, size=(H2, W2), mode="bilinear", align_corners=False)
+ * (source index (dst + 0.5) * in/out - 0.5 clamped at 0, no antialiasing).  Used by the
+ * multi-scale extraction of BASELINE.json configs[4]; the reference itself resizes PIL images in
+ * its loader (ibl/utils/data/__init__.py:37-42) and has no multi-scale path. */
+int oibl_resize_bilinear_nchw(const float* x, int N, int C, int H, int W, float* out, int H2, int W2,
+                              void* stream);
 
 /* ---- VGG16 conv1_1 .. conv5_3 backbone -------------------------------------------- *
  * Replaces VGG.forward's `self.base(x)`  (ibl/models/vgg.py:61-62; layer list built at
@@ -179,6 +197,10 @@ int oibl_pca_forward(const float* v, int N, int D, const void* w, const float* b
 /* Row-wise L2 normalisation x / max(|x|_2, 1e-12)  (F.normalize(dim=-1), e.g. the extra
  * one in extract_cnn_feature, ibl/evaluators.py:29-33).  In place allowed. */
 int oibl_l2_normalize_rows(const float* x, int N, int D, float* out, void* stream);
+/* out[i] = normalize(xs[0][i] + xs[1][i] + ... + xs[S-1][i]), xs [S][N][D] fp32 (summed in that
+ * order): fuses the per-scale descriptors of the multi-scale extraction (BASELINE.json configs[4];
+ * no counterpart in the reference) into one unit-norm descriptor. */
+int oibl_sum_l2_normalize(const float* xs, int S, int N, int D, float* out, void* stream);
 
 /* ---- query x gallery squared-L2 --------------------------------------------------- *
  * Replaces the arithmetic of pairwise_distance (ibl/evaluators.py:122-129):
@@ -189,6 +211,14 @@ size_t oibl_pairwise_workspace_bytes(int m, int n, int d, int precision);
 int oibl_pairwise_sqdist(const float* x, int m, const float* y, int n, int d,
                          int precision, float* dist, size_t ldd, void* ws, size_t ws_bytes,
                          void* stream);
+
+/* The same with descriptors stored as fp32, IEEE half or bf16 (OIBL_ST_*): the result is that of
+ * oibl_pairwise_sqdist on the stored values widened to fp32 (norms from the widened values; in
+ * OIBL_BF16 a bf16-stored operand is read in place, no copy).  x [m][d], y [n][d] of their types. */
+size_t oibl_pairwise_st_workspace_bytes(int m, int n, int d, int precision, int x_st, int y_st);
+int oibl_pairwise_sqdist_st(const void* x, int x_st, int m, const void* y, int y_st, int n, int d,
+                            int precision, float* dist, size_t ldd, void* ws, size_t ws_bytes,
+                            void* stream);
 
 /* Fused distance + top-k: the k nearest gallery rows of every query without materialising the
  * [m][n] matrix — what Evaluator.evaluate / evaluate_all need from pairwise_distance + argsort
@@ -206,6 +236,12 @@ size_t oibl_sqdist_topk_workspace_bytes(int m, int n, int d, int k, int precisio
 int oibl_sqdist_topk(const float* x, int m, const float* y, int n, int d, int k, int index_base,
                      int precision, int exact, float* out_val, int32_t* out_idx, int32_t* overflow,
                      void* ws, size_t ws_bytes, void* stream);
+/* Storage-typed variant (see oibl_pairwise_sqdist_st). */
+size_t oibl_sqdist_topk_st_workspace_bytes(int m, int n, int d, int k, int precision, int x_st,
+                                           int y_st);
+int oibl_sqdist_topk_st(const void* x, int x_st, int m, const void* y, int y_st, int n, int d, int k,
+                        int index_base, int precision, int exact, float* out_val, int32_t* out_idx,
+                        int32_t* overflow, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- top-k ------------------------------------------------------------------------ *
  * Replaces np.argsort(distmat, axis=1) (ibl/evaluators.py:143), of which evaluate_all only

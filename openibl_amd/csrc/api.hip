@@ -52,6 +52,47 @@ __global__ void cast_bf16_f32_kernel(const uint16_t* __restrict__ src, float* __
     dst[i] = bf16_bits_to_f32(src[i]);
 }
 
+__global__ void cast_f32_f16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst,
+                                    size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    dst[i] = f32_to_f16_bits(src[i]);
+}
+
+__global__ void cast_f16_f32_kernel(const uint16_t* __restrict__ src, float* __restrict__ dst,
+                                    size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    dst[i] = f16_bits_to_f32(src[i]);
+}
+
+// ---- bilinear resize (F.interpolate, align_corners=False) ------------------------------------
+// One thread per output pixel, consecutive threads along W2 (stores coalesce, the two source rows
+// are read as near-contiguous runs).  Arithmetic in the order ATen's upsample_bilinear2d uses:
+// src = scale * (dst + 0.5) - 0.5 clamped at 0; i1 = i0 + (i0 < in - 1); l1 = src - i0, l0 = 1 - l1;
+// out = l0y * (l0x * v00 + l1x * v01) + l1y * (l0x * v10 + l1x * v11).
+__global__ void resize_bilinear_kernel(const float* __restrict__ x, float* __restrict__ out, int H,
+                                       int W, int H2, int W2, float sy, float sx) {
+  const int ox = blockIdx.x * blockDim.x + threadIdx.x;
+  const int oy = blockIdx.y;
+  if (ox >= W2) return;
+  const size_t plane = blockIdx.z;
+  float fy = sy * ((float)oy + 0.5f) - 0.5f;
+  float fx = sx * ((float)ox + 0.5f) - 0.5f;
+  fy = fy < 0.f ? 0.f : fy;
+  fx = fx < 0.f ? 0.f : fx;
+  int y0 = (int)fy, x0 = (int)fx;
+  y0 = y0 > H - 1 ? H - 1 : y0;
+  x0 = x0 > W - 1 ? W - 1 : x0;
+  const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+  const float ly1 = fy - (float)y0, lx1 = fx - (float)x0;
+  const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+  const float* p = x + plane * H * W;
+  const float v00 = p[(size_t)y0 * W + x0], v01 = p[(size_t)y0 * W + x1];
+  const float v10 = p[(size_t)y1 * W + x0], v11 = p[(size_t)y1 * W + x1];
+  out[(plane * H2 + oy) * W2 + ox] = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+}
+
 // ---- row L2 normalise -------------------------------------------------------------------
 // one wave per row; x / max(||x||, 1e-12) as F.normalize does.
 __global__ void l2_normalize_rows_kernel(const float* __restrict__ x, float* __restrict__ out,
@@ -66,6 +107,27 @@ __global__ void l2_normalize_rows_kernel(const float* __restrict__ x, float* __r
   const float inv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
   float* orow = out + (size_t)row * D;
   for (int i = lane; i < D; i += 64) orow[i] = xr[i] * inv;
+}
+
+// out[row] = normalize(xs[0][row] + xs[1][row] + ... ) — descriptors of S scales fused into one
+__global__ void sum_l2_normalize_kernel(const float* __restrict__ xs, int S, int N, int D,
+                                        float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const size_t plane = (size_t)N * D;
+  const float* xr = xs + (size_t)row * D;
+  float* orow = out + (size_t)row * D;
+  float s = 0.f;
+  for (int i = lane; i < D; i += 64) {
+    float a = xr[i];
+    for (int k = 1; k < S; ++k) a += xr[i + k * plane];
+    orow[i] = a;
+    s += a * a;
+  }
+  s = wave_sum(s);
+  const float inv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+  for (int i = lane; i < D; i += 64) orow[i] *= inv;   // each lane re-reads its own writes
 }
 
 // ---- bare NT GEMM (diagnostic) ------------------------------------------------------------
@@ -178,12 +240,60 @@ int oibl_cast_bf16_to_f32(const uint16_t* src, float* dst, size_t n, void* strea
   return OIBL_OK;
 }
 
+int oibl_cast_f32_to_f16(const float* src, uint16_t* dst, size_t n, void* stream) {
+  OIBL_REQUIRE(src && dst, "cast_f32_to_f16: null pointer");
+  if (n == 0) return OIBL_OK;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(cast_f32_f16_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, src, dst, n);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
+
+int oibl_cast_f16_to_f32(const uint16_t* src, float* dst, size_t n, void* stream) {
+  OIBL_REQUIRE(src && dst, "cast_f16_to_f32: null pointer");
+  if (n == 0) return OIBL_OK;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(cast_f16_f32_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, src, dst, n);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
+
+int oibl_resize_bilinear_nchw(const float* x, int N, int C, int H, int W, float* out, int H2, int W2,
+                              void* stream) {
+  OIBL_REQUIRE(x && out, "resize_bilinear: null pointer");
+  OIBL_REQUIRE(N >= 0 && C > 0 && H > 0 && W > 0 && H2 > 0 && W2 > 0,
+               "resize_bilinear: bad shape N=%d C=%d %dx%d -> %dx%d", N, C, H, W, H2, W2);
+  OIBL_REQUIRE((long)N * C <= 65535 && H2 <= 65535, "resize_bilinear: N*C=%ld or H2=%d above 65535",
+               (long)N * C, H2);
+  if (N == 0) return OIBL_OK;
+  // ATen: scale = in / out in fp32 (area_pixel_compute_scale, align_corners = false)
+  const float sy = (float)H / (float)H2, sx = (float)W / (float)W2;
+  hipLaunchKernelGGL(resize_bilinear_kernel, dim3((W2 + 255) / 256, H2, N * C), dim3(256), 0,
+                     (hipStream_t)stream, x, out, H, W, H2, W2, sy, sx);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
+
 int oibl_l2_normalize_rows(const float* x, int N, int D, float* out, void* stream) {
   OIBL_REQUIRE(x && out, "l2_normalize_rows: null pointer");
   OIBL_REQUIRE(N >= 0 && D > 0, "l2_normalize_rows: bad shape N=%d D=%d", N, D);
   if (N == 0) return OIBL_OK;
   hipLaunchKernelGGL(l2_normalize_rows_kernel, dim3((N + 3) / 4), dim3(256), 0,
                      (hipStream_t)stream, x, out, N, D);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
+
+int oibl_sum_l2_normalize(const float* xs, int S, int N, int D, float* out, void* stream) {
+  OIBL_REQUIRE(xs && out, "sum_l2_normalize: null pointer");
+  OIBL_REQUIRE(S >= 1 && N >= 0 && D > 0, "sum_l2_normalize: bad shape S=%d N=%d D=%d", S, N, D);
+  if (N == 0) return OIBL_OK;
+  hipLaunchKernelGGL(sum_l2_normalize_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                     xs, S, N, D, out);
   OIBL_LAUNCH_CHECK();
   return OIBL_OK;
 }

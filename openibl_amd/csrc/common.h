@@ -69,6 +69,14 @@ __host__ __device__ static inline uint16_t f32_to_bf16_bits(float f) {
   return (uint16_t)(u >> 16);
 }
 
+// IEEE binary16 <-> fp32 (round-to-nearest-even; v_cvt_f16_f32 / v_cvt_f32_f16 on the device)
+__host__ __device__ static inline uint16_t f32_to_f16_bits(float f) {
+  return __builtin_bit_cast(uint16_t, (_Float16)f);
+}
+__host__ __device__ static inline float f16_bits_to_f32(uint16_t b) {
+  return (float)__builtin_bit_cast(_Float16, b);
+}
+
 __host__ __device__ static inline float bf16_bits_to_f32(uint16_t b) {
   union {
     float f;

@@ -25,26 +25,57 @@ __global__ void row_sqnorm_kernel(const float* __restrict__ x, float* __restrict
   if (lane == 0) out[row] = s;
 }
 
-// the same reduction, and the bf16 copy of the row written on the way (bf16 mode reads the fp32
-// descriptors once instead of twice)
-__global__ void row_sqnorm_cast_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                       uint16_t* __restrict__ xb, int rows, int d) {
+// Descriptor rows in their storage type (OIBL_ST_*), widened to fp32 four at a time.
+template <int ST>
+__device__ static inline float4 load4_widen(const void* row, int i) {
+  if constexpr (ST == OIBL_ST_F32) {
+    return *reinterpret_cast<const float4*>(static_cast<const float*>(row) + i);
+  } else {
+    const uint2 r = *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(row) + i);
+    float4 v;
+    if constexpr (ST == OIBL_ST_F16) {
+      v.x = f16_bits_to_f32((uint16_t)r.x);
+      v.y = f16_bits_to_f32((uint16_t)(r.x >> 16));
+      v.z = f16_bits_to_f32((uint16_t)r.y);
+      v.w = f16_bits_to_f32((uint16_t)(r.y >> 16));
+    } else {
+      v.x = __builtin_bit_cast(float, r.x << 16);
+      v.y = __builtin_bit_cast(float, r.x & 0xffff0000u);
+      v.z = __builtin_bit_cast(float, r.y << 16);
+      v.w = __builtin_bit_cast(float, r.y & 0xffff0000u);
+    }
+    return v;
+  }
+}
+
+// The same reduction over the widened row, with the operand copy the contraction reads written on
+// the way: OUT = 1 the bf16 rounding (bf16 mode; nothing to write for bf16 storage, xo == nullptr),
+// OUT = 2 the fp32 widening of a 16-bit row (fp32 mode).  The descriptors are read once.
+template <int ST, int OUT>
+__global__ void row_sqnorm_cast_kernel(const void* __restrict__ x, float* __restrict__ out,
+                                       void* __restrict__ xo, int rows, int d) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const float* xr = x + (size_t)row * d;
-  uint16_t* br = xb + (size_t)row * d;
+  const size_t es = ST == OIBL_ST_F32 ? 4 : 2;
+  const char* xr = static_cast<const char*>(x) + (size_t)row * d * es;
   float s = 0.f;
   for (int i = lane * 4; i < d; i += 256) {
-    const float4 v = *reinterpret_cast<const float4*>(xr + i);
+    const float4 v = load4_widen<ST>(xr, i);
     s = fmaf(v.x, v.x, s);
     s = fmaf(v.y, v.y, s);
     s = fmaf(v.z, v.z, s);
     s = fmaf(v.w, v.w, s);
-    uint2 b;
-    b.x = (uint32_t)f32_to_bf16_bits(v.x) | ((uint32_t)f32_to_bf16_bits(v.y) << 16);
-    b.y = (uint32_t)f32_to_bf16_bits(v.z) | ((uint32_t)f32_to_bf16_bits(v.w) << 16);
-    *reinterpret_cast<uint2*>(br + i) = b;
+    if constexpr (OUT == 1) {
+      if (ST != OIBL_ST_BF16) {
+        uint2 b;
+        b.x = (uint32_t)f32_to_bf16_bits(v.x) | ((uint32_t)f32_to_bf16_bits(v.y) << 16);
+        b.y = (uint32_t)f32_to_bf16_bits(v.z) | ((uint32_t)f32_to_bf16_bits(v.w) << 16);
+        *reinterpret_cast<uint2*>(static_cast<uint16_t*>(xo) + (size_t)row * d + i) = b;
+      }
+    } else if constexpr (OUT == 2) {
+      *reinterpret_cast<float4*>(static_cast<float*>(xo) + (size_t)row * d + i) = v;
+    }
   }
   s = wave_sum(s);
   if (lane == 0) out[row] = s;
@@ -470,12 +501,19 @@ int oibl_debug_set_match_ring(int mode) {
 static size_t pw_off_yn(int m) { return align_up((size_t)m * sizeof(float), 256); }
 static size_t pw_off_xt(int m, int n) { return pw_off_yn(m) + align_up((size_t)n * sizeof(float), 256); }
 
+static bool st_ok(int st) { return st == OIBL_ST_F32 || st == OIBL_ST_F16 || st == OIBL_ST_BF16; }
+// bytes of the operand copy the contraction reads instead of the stored rows (0: reads them as is)
+static size_t pw_copy_bytes(int rows, int d, int precision, int st) {
+  if (precision == OIBL_BF16) return st == OIBL_ST_BF16 ? 0 : align_up((size_t)rows * d * 2, 256);
+  return st == OIBL_ST_F32 ? 0 : align_up((size_t)rows * d * 4, 256);
+}
+
+size_t oibl_pairwise_st_workspace_bytes(int m, int n, int d, int precision, int x_st, int y_st) {
+  if (m <= 0 || n <= 0 || d <= 0 || !st_ok(x_st) || !st_ok(y_st)) return 0;
+  return pw_off_xt(m, n) + pw_copy_bytes(m, d, precision, x_st) + pw_copy_bytes(n, d, precision, y_st);
+}
 size_t oibl_pairwise_workspace_bytes(int m, int n, int d, int precision) {
-  if (m <= 0 || n <= 0 || d <= 0) return 0;
-  size_t b = pw_off_xt(m, n);
-  if (precision == OIBL_BF16)
-    b += align_up((size_t)m * d * 2, 256) + align_up((size_t)n * d * 2, 256);
-  return b;
+  return oibl_pairwise_st_workspace_bytes(m, n, d, precision, OIBL_ST_F32, OIBL_ST_F32);
 }
 
 // ring kernel legality: bf16, an even number (>= 4) of 64-element K-tiles, 32-bit buffer offsets
@@ -512,31 +550,46 @@ static int launch_pairwise_ring(PairRingParams& p, hipStream_t st) {
 }
 }  // extern "C++"
 
-// norms + (bf16) operand copies into the workspace; fills p.x / p.y / p.xn / p.yn
-static int pairwise_prepare(const float* x, int m, const float* y, int n, int d, int precision,
-                            char* wsb, const void** xo, const void** yo, float** xn, float** yn,
-                            void* stream) {
+// norms + operand copies of one descriptor matrix into the workspace
+extern "C++" {
+template <int ST>
+static int prepare_rows(const void* x, int rows, int d, int precision, float* norms, void* copy,
+                        const void** opnd, hipStream_t st) {
+  const dim3 grid((rows + 3) / 4), block(256);
+  if (precision == OIBL_BF16) {
+    hipLaunchKernelGGL((row_sqnorm_cast_kernel<ST, 1>), grid, block, 0, st, x, norms, copy, rows, d);
+    *opnd = ST == OIBL_ST_BF16 ? x : copy;
+  } else if (ST == OIBL_ST_F32) {
+    hipLaunchKernelGGL(row_sqnorm_kernel, grid, block, 0, st, (const float*)x, norms, rows, d);
+    *opnd = x;
+  } else {
+    hipLaunchKernelGGL((row_sqnorm_cast_kernel<ST, 2>), grid, block, 0, st, x, norms, copy, rows, d);
+    *opnd = copy;
+  }
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
+}  // extern "C++"
+static int prepare_rows_st(const void* x, int x_st, int rows, int d, int precision, float* norms,
+                           void* copy, const void** opnd, hipStream_t st) {
+  switch (x_st) {
+    case OIBL_ST_F32: return prepare_rows<OIBL_ST_F32>(x, rows, d, precision, norms, copy, opnd, st);
+    case OIBL_ST_F16: return prepare_rows<OIBL_ST_F16>(x, rows, d, precision, norms, copy, opnd, st);
+    default: return prepare_rows<OIBL_ST_BF16>(x, rows, d, precision, norms, copy, opnd, st);
+  }
+}
+// fills xo / yo (what the contraction reads) and xn / yn (fp32 squared norms)
+static int pairwise_prepare(const void* x, int x_st, int m, const void* y, int y_st, int n, int d,
+                            int precision, char* wsb, const void** xo, const void** yo, float** xn,
+                            float** yn, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   *xn = (float*)wsb;
   *yn = (float*)(wsb + pw_off_yn(m));
-  *xo = x;
-  *yo = y;
-  if (precision == OIBL_BF16) {
-    uint16_t* xt = (uint16_t*)(wsb + pw_off_xt(m, n));
-    uint16_t* yt = (uint16_t*)((char*)xt + align_up((size_t)m * d * 2, 256));
-    hipLaunchKernelGGL(row_sqnorm_cast_kernel, dim3((m + 3) / 4), dim3(256), 0, st, x, *xn, xt, m, d);
-    OIBL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(row_sqnorm_cast_kernel, dim3((n + 3) / 4), dim3(256), 0, st, y, *yn, yt, n, d);
-    OIBL_LAUNCH_CHECK();
-    *xo = xt;
-    *yo = yt;
-  } else {
-    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((m + 3) / 4), dim3(256), 0, st, x, *xn, m, d);
-    OIBL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((n + 3) / 4), dim3(256), 0, st, y, *yn, n, d);
-    OIBL_LAUNCH_CHECK();
-  }
-  return OIBL_OK;
+  char* xc = wsb + pw_off_xt(m, n);
+  char* yc = xc + pw_copy_bytes(m, d, precision, x_st);
+  int rc = prepare_rows_st(x, x_st, m, d, precision, *xn, xc, xo, st);
+  if (rc) return rc;
+  return prepare_rows_st(y, y_st, n, d, precision, *yn, yc, yo, st);
 }
 
 // dist[m rows starting at row0][ldd] from prepared operands
@@ -596,25 +649,32 @@ static int pairwise_launch(const void* xo, const void* yo, const float* xn, cons
   return OIBL_OK;
 }
 
-int oibl_pairwise_sqdist(const float* x, int m, const float* y, int n, int d, int precision,
-                         float* dist, size_t ldd, void* ws, size_t ws_bytes, void* stream) {
+int oibl_pairwise_sqdist_st(const void* x, int x_st, int m, const void* y, int y_st, int n, int d,
+                            int precision, float* dist, size_t ldd, void* ws, size_t ws_bytes,
+                            void* stream) {
   OIBL_REQUIRE(x && y && dist && ws, "pairwise: null pointer");
   OIBL_REQUIRE(precision == OIBL_BF16 || precision == OIBL_F32, "pairwise: bad precision %d",
                precision);
+  OIBL_REQUIRE(st_ok(x_st) && st_ok(y_st), "pairwise: bad storage type %d / %d", x_st, y_st);
   OIBL_REQUIRE(m > 0 && n > 0 && d > 0 && d % 64 == 0 && ldd >= (size_t)n,
                "pairwise: unsupported shape m=%d n=%d d=%d ldd=%zu", m, n, d, ldd);
   OIBL_REQUIRE((uintptr_t)ws % 256 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0,
                "pairwise: workspace must be 256-byte, x and y 16-byte aligned");
-  const size_t need = oibl_pairwise_workspace_bytes(m, n, d, precision);
+  const size_t need = oibl_pairwise_st_workspace_bytes(m, n, d, precision, x_st, y_st);
   if (ws_bytes < need) {
     set_error("pairwise: workspace %zu < required %zu bytes", ws_bytes, need);
     return OIBL_E_WORKSPACE;
   }
   const void *xo, *yo;
   float *xn, *yn;
-  int rc = pairwise_prepare(x, m, y, n, d, precision, (char*)ws, &xo, &yo, &xn, &yn, stream);
+  int rc = pairwise_prepare(x, x_st, m, y, y_st, n, d, precision, (char*)ws, &xo, &yo, &xn, &yn, stream);
   if (rc) return rc;
   return pairwise_launch(xo, yo, xn, yn, 0, m, m, n, d, precision, dist, ldd, (hipStream_t)stream);
+}
+int oibl_pairwise_sqdist(const float* x, int m, const float* y, int n, int d, int precision,
+                         float* dist, size_t ldd, void* ws, size_t ws_bytes, void* stream) {
+  return oibl_pairwise_sqdist_st(x, OIBL_ST_F32, m, y, OIBL_ST_F32, n, d, precision, dist, ldd, ws,
+                                 ws_bytes, stream);
 }
 
 // ---- fused distance + top-k -------------------------------------------------------------------
@@ -629,7 +689,7 @@ struct TopkPlan {
   int S, stride, cap, chunk;
   size_t off_prep, off_sample, off_sval, off_sidx, off_cnt, off_cval, off_cidx, off_chunk, total;
 };
-static TopkPlan topk_plan(int m, int n, int d, int k, int precision) {
+static TopkPlan topk_plan(int m, int n, int d, int k, int precision, int x_st, int y_st) {
   TopkPlan t = {};
   int S = 1024;
   while (S < 4 * k) S *= 2;
@@ -647,7 +707,7 @@ static TopkPlan topk_plan(int m, int n, int d, int k, int precision) {
   t.chunk = (int)chunk;
   size_t o = 0;
   t.off_prep = o;
-  o += align_up(oibl_pairwise_workspace_bytes(m, n, d, precision), 256);
+  o += align_up(oibl_pairwise_st_workspace_bytes(m, n, d, precision, x_st, y_st), 256);
   t.off_sample = o;
   o += align_up((size_t)m * S * sizeof(float), 256);
   t.off_sval = o;
@@ -666,24 +726,36 @@ static TopkPlan topk_plan(int m, int n, int d, int k, int precision) {
   return t;
 }
 
+size_t oibl_sqdist_topk_st_workspace_bytes(int m, int n, int d, int k, int precision, int x_st,
+                                           int y_st) {
+  if (m <= 0 || n <= 0 || d <= 0 || k <= 0 || !st_ok(x_st) || !st_ok(y_st)) return 0;
+  return topk_plan(m, n, d, k, precision, x_st, y_st).total;
+}
 size_t oibl_sqdist_topk_workspace_bytes(int m, int n, int d, int k, int precision) {
-  if (m <= 0 || n <= 0 || d <= 0 || k <= 0) return 0;
-  return topk_plan(m, n, d, k, precision).total;
+  return oibl_sqdist_topk_st_workspace_bytes(m, n, d, k, precision, OIBL_ST_F32, OIBL_ST_F32);
 }
 
 int oibl_sqdist_topk(const float* x, int m, const float* y, int n, int d, int k, int index_base,
                      int precision, int exact, float* out_val, int32_t* out_idx, int32_t* overflow,
                      void* ws, size_t ws_bytes, void* stream) {
+  return oibl_sqdist_topk_st(x, OIBL_ST_F32, m, y, OIBL_ST_F32, n, d, k, index_base, precision, exact,
+                             out_val, out_idx, overflow, ws, ws_bytes, stream);
+}
+
+int oibl_sqdist_topk_st(const void* x, int x_st, int m, const void* y, int y_st, int n, int d, int k,
+                        int index_base, int precision, int exact, float* out_val, int32_t* out_idx,
+                        int32_t* overflow, void* ws, size_t ws_bytes, void* stream) {
   OIBL_REQUIRE(x && y && out_val && out_idx && ws, "sqdist_topk: null pointer");
   OIBL_REQUIRE(precision == OIBL_BF16 || precision == OIBL_F32, "sqdist_topk: bad precision %d",
                precision);
+  OIBL_REQUIRE(st_ok(x_st) && st_ok(y_st), "sqdist_topk: bad storage type %d / %d", x_st, y_st);
   OIBL_REQUIRE(m > 0 && n > 0 && d > 0 && d % 64 == 0, "sqdist_topk: unsupported shape m=%d n=%d d=%d",
                m, n, d);
   OIBL_REQUIRE(k >= 1 && k <= 1024, "sqdist_topk: k=%d outside [1, 1024]", k);
   OIBL_REQUIRE((long)index_base + n <= 0x7fffffffL, "sqdist_topk: index_base + n overflows int32");
   OIBL_REQUIRE((uintptr_t)ws % 256 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0,
                "sqdist_topk: workspace must be 256-byte, x and y 16-byte aligned");
-  const TopkPlan t = topk_plan(m, n, d, k, precision);
+  const TopkPlan t = topk_plan(m, n, d, k, precision, x_st, y_st);
   if (ws_bytes < t.total) {
     set_error("sqdist_topk: workspace %zu < required %zu bytes", ws_bytes, t.total);
     return OIBL_E_WORKSPACE;
@@ -693,7 +765,8 @@ int oibl_sqdist_topk(const float* x, int m, const float* y, int n, int d, int k,
   if (overflow) OIBL_HIP_CHECK(hipMemsetAsync(overflow, 0, sizeof(int32_t), st));
   const void *xo, *yo;
   float *xn, *yn;
-  int rc = pairwise_prepare(x, m, y, n, d, precision, wsb + t.off_prep, &xo, &yo, &xn, &yn, stream);
+  int rc = pairwise_prepare(x, x_st, m, y, y_st, n, d, precision, wsb + t.off_prep, &xo, &yo, &xn, &yn,
+                            stream);
   if (rc) return rc;
 
   if (t.fused && !exact) {

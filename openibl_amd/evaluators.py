@@ -58,10 +58,14 @@ class _Meter:
         return self.sum / max(self.count, 1)
 
 
-def extract_cnn_feature(model, inputs, vlad=True, gpu=None):
-    """Forward one batch and L2-normalise the selected output (evaluators.py:22-34)."""
+def extract_cnn_feature(model, inputs, vlad=True, gpu=None, scales=None):
+    """Forward one batch and L2-normalise the selected output (evaluators.py:22-34).
+    `scales` (extension, BASELINE.json configs[4]): multi-scale extraction, see multiscale.py."""
     model.eval()
     x = _to_tensor(inputs).to(_device(gpu), non_blocking=True)
+    if scales is not None:
+        from .multiscale import extract_multiscale
+        return extract_multiscale(model, x, scales, vlad)
     out = model(x)
     if isinstance(out, (list, tuple)):
         pool_x, vlad_x = out
@@ -69,8 +73,9 @@ def extract_cnn_feature(model, inputs, vlad=True, gpu=None):
     return ops.l2_normalize(out.float().contiguous())
 
 
-def _extract_local(model, data_loader, vlad, pca, gpu, print_freq, rank):
-    """Run the loader of this rank; returns the [n_local][d] descriptor matrix ON DEVICE."""
+def _extract_local(model, data_loader, vlad, pca, gpu, print_freq, rank, scales=None, store_dtype=None):
+    """Run the loader of this rank; returns the [n_local][d] descriptor matrix ON DEVICE, in
+    `store_dtype` (None = float32; float16 / bfloat16 = 16-bit descriptor storage)."""
     model.eval()
     if pca is not None:
         pca.load(gpu=gpu)
@@ -81,10 +86,10 @@ def _extract_local(model, data_loader, vlad, pca, gpu, print_freq, rank):
         for i, batch in enumerate(data_loader):
             imgs = batch[0]
             data_t.update(time.time() - end)
-            out = extract_cnn_feature(model, imgs, vlad, gpu=gpu)
+            out = extract_cnn_feature(model, imgs, vlad, gpu=gpu, scales=scales)
             if pca is not None:
                 out = pca.infer(out)
-            chunks.append(out)
+            chunks.append(ops.store_descriptors(out, store_dtype))
             batch_t.update(time.time() - end)
             end = time.time()
             if (i + 1) % print_freq == 0 and rank == 0:
@@ -98,9 +103,9 @@ def _extract_local(model, data_loader, vlad, pca, gpu, print_freq, rank):
 def _gather_all(local: torch.Tensor, sync_gather: bool, rank: int, world: int) -> torch.Tensor:
     """Every rank's [per][d] block -> [world * per][d] on the host, rank-major."""
     if world == 1:
-        return local.cpu()
+        return local.cpu().float()
     if sync_gather:  # one all_gather (evaluators.py:76-88)
-        return sharded.all_gather_rows(local).cpu()
+        return sharded.all_gather_rows(local).cpu().float()
     parts = []  # rank-by-rank broadcast, one block resident at a time (evaluators.py:89-101)
     buf = torch.empty_like(local)
     for k in range(world):
@@ -110,17 +115,17 @@ def _gather_all(local: torch.Tensor, sync_gather: bool, rank: int, world: int) -
             print("gathering features from rank no.{}".format(k))
         dist.broadcast(buf, k)
         parts.append(buf.to("cpu", copy=True))   # the buffer is reused for the next rank
-    return torch.cat(parts)
+    return torch.cat(parts).float()
 
 
 def extract_features(model, data_loader, dataset, print_freq=10, vlad=True, pca=None, gpu=None,
-                     sync_gather=False):
+                     sync_gather=False, scales=None, store_dtype=None):
     """OrderedDict fname -> CPU descriptor for every item of `dataset` (evaluators.py:36-103).
 
     Each rank extracts the slice its DistributedSliceSampler yields; slices are gathered
     rank-major and truncated to len(dataset) (the wrap-around padding of the last slices)."""
     rank, world = _rank_world()
-    local = _extract_local(model, data_loader, vlad, pca, gpu, print_freq, rank)
+    local = _extract_local(model, data_loader, vlad, pca, gpu, print_freq, rank, scales, store_dtype)
     allf = _gather_all(local, sync_gather, rank, world)[: len(dataset)]
     features = OrderedDict()
     for item, row in zip(dataset, allf):
@@ -252,23 +257,28 @@ def evaluate_all(distmat, gt, gallery, recall_topk=[1, 5, 10], nms=False):
 
 
 class Evaluator(object):
-    def __init__(self, model, precision: Optional[str] = None):
+    def __init__(self, model, precision: Optional[str] = None, scales=None, descriptor_dtype=None):
+        """`scales` / `descriptor_dtype` are the BASELINE.json configs[4] extensions (multi-scale
+        extraction, 16-bit descriptor storage); the defaults reproduce the reference."""
         super(Evaluator, self).__init__()
         self.model = model
         self.rank = _rank_world()[0]
         self.precision = precision
+        self.scales = scales
+        self.descriptor_dtype = descriptor_dtype
 
     # -- reference flow: fname dict on the host, full distance matrix ----------------------------
     def _evaluate_host(self, query_loader, dataset, query, gallery, ground_truth, gallery_loader,
                        vlad, pca, rerank, gpu, sync_gather, nms, rr_topk, lambda_value):
         if gallery_loader is not None:
-            features = extract_features(self.model, query_loader, query, vlad=vlad, pca=pca,
-                                        gpu=gpu, sync_gather=sync_gather)
-            features.update(extract_features(self.model, gallery_loader, gallery, vlad=vlad,
-                                             pca=pca, gpu=gpu, sync_gather=sync_gather))
+            ext = dict(vlad=vlad, pca=pca, gpu=gpu, sync_gather=sync_gather, scales=self.scales,
+                       store_dtype=self.descriptor_dtype)
+            features = extract_features(self.model, query_loader, query, **ext)
+            features.update(extract_features(self.model, gallery_loader, gallery, **ext))
         else:
             features = extract_features(self.model, query_loader, dataset, vlad=vlad, pca=pca,
-                                        gpu=gpu, sync_gather=sync_gather)
+                                        gpu=gpu, sync_gather=sync_gather, scales=self.scales,
+                                        store_dtype=self.descriptor_dtype)
         distmat, _, _ = pairwise_distance(features, query, gallery, precision=self.precision)
         recalls = evaluate_all(distmat, ground_truth, gallery, nms=nms)
         if not rerank:
@@ -287,8 +297,10 @@ class Evaluator(object):
                          pca, gpu, nms, recall_topk=(1, 5, 10)):
         rank, world = _rank_world()
         prec = self.precision or default_precision()
-        q_local = _extract_local(self.model, query_loader, vlad, pca, gpu, 10, rank)
-        g_local = _extract_local(self.model, gallery_loader, vlad, pca, gpu, 10, rank)
+        q_local = _extract_local(self.model, query_loader, vlad, pca, gpu, 10, rank, self.scales,
+                                 self.descriptor_dtype)
+        g_local = _extract_local(self.model, gallery_loader, vlad, pca, gpu, 10, rank, self.scales,
+                                 self.descriptor_dtype)
         q_all = sharded.all_gather_rows(q_local)[: len(query)].contiguous()
         start, _, n_valid = sharded.slice_bounds(len(gallery), rank, world)
         g_local = g_local[:n_valid].contiguous()

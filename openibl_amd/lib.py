@@ -53,12 +53,24 @@ SIGNATURES = {
     "oibl_pca_forward": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                                  c_void_p, c_void_p, c_size_t, c_void_p]),
     "oibl_l2_normalize_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "oibl_sum_l2_normalize": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "oibl_pairwise_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "oibl_pairwise_sqdist": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
                                      c_size_t, c_void_p, c_size_t, c_void_p]),
     "oibl_sqdist_topk_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "oibl_sqdist_topk": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "oibl_pairwise_st_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "oibl_pairwise_sqdist_st": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                        c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
+    "oibl_sqdist_topk_st_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "oibl_sqdist_topk_st": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                    c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                    c_void_p]),
+    "oibl_cast_f32_to_f16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "oibl_cast_f16_to_f32": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "oibl_resize_bilinear_nchw": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int,
+                                          c_void_p]),
     "oibl_row_topk": (c_int, [c_void_p, c_void_p, c_int, c_int, c_size_t, c_int, c_int, c_void_p,
                               c_void_p, c_void_p]),
     "oibl_first_hit_rank": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,

@@ -354,17 +354,85 @@ def l2_normalize(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+# ---- 16-bit descriptor storage (BASELINE.json configs[4]; no counterpart in the reference) ----------
+ST_F32, ST_F16, ST_BF16 = 0, 1, 2
+_ST_OF = {torch.float32: ST_F32, torch.float16: ST_F16, torch.bfloat16: ST_BF16}
+
+
+def storage_code(t: torch.Tensor) -> int:
+    try:
+        return _ST_OF[t.dtype]
+    except KeyError:
+        raise ValueError("descriptors must be float32, float16 or bfloat16, not %s" % t.dtype)
+
+
+def store_descriptors(x: torch.Tensor, dtype: Optional[torch.dtype]) -> torch.Tensor:
+    """float32 descriptors -> their storage type (round-to-nearest-even), through the HIP casts."""
+    if dtype is None or dtype == torch.float32:
+        return x
+    dev = _need_cuda(x)
+    if x.dtype != torch.float32:
+        raise ValueError("store_descriptors expects float32 input")
+    if dtype == torch.bfloat16:
+        return cast(x, BF16)
+    if dtype != torch.float16:
+        raise ValueError("descriptor storage must be float32, float16 or bfloat16")
+    out = torch.empty(x.shape, dtype=torch.float16, device=dev)
+    _lib.check(_lib.load().oibl_cast_f32_to_f16(_ptr(x), _ptr(out), x.numel(), _stream(dev)),
+               "cast_f32_to_f16")
+    return out
+
+
+def load_descriptors(x: torch.Tensor) -> torch.Tensor:
+    """Stored descriptors widened to float32 (exact)."""
+    if x.dtype != torch.float16:
+        return to_f32(x)
+    dev = _need_cuda(x)
+    out = torch.empty(x.shape, dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().oibl_cast_f16_to_f32(_ptr(x), _ptr(out), x.numel(), _stream(dev)),
+               "cast_f16_to_f32")
+    return out
+
+
+def sum_l2_normalize(xs: torch.Tensor) -> torch.Tensor:
+    """float32 [S][N][D] -> [N][D]: rows of xs[0] + xs[1] + ... L2-normalised."""
+    dev = _need_cuda(xs)
+    if xs.dtype != torch.float32 or xs.dim() != 3:
+        raise ValueError("sum_l2_normalize expects a float32 [S][N][D] tensor")
+    S, N, D = map(int, xs.shape)
+    out = torch.empty((N, D), dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().oibl_sum_l2_normalize(_ptr(xs), S, N, D, _ptr(out), _stream(dev)),
+               "sum_l2_normalize")
+    return out
+
+
+def resize_bilinear(x: torch.Tensor, size: Tuple[int, int]) -> torch.Tensor:
+    """float32 [N][C][H][W] -> [N][C][H2][W2] with the arithmetic of
+    F.interpolate(x, size=size, mode="bilinear", align_corners=False)."""
+    dev = _need_cuda(x)
+    if x.dtype != torch.float32 or x.dim() != 4:
+        raise ValueError("resize_bilinear expects a float32 [N][C][H][W] tensor")
+    N, Cc, H, W = map(int, x.shape)
+    H2, W2 = int(size[0]), int(size[1])
+    out = torch.empty((N, Cc, H2, W2), dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().oibl_resize_bilinear_nchw(_ptr(x), N, Cc, H, W, _ptr(out), H2, W2,
+                                                     _stream(dev)), "resize_bilinear")
+    return out
+
+
 # ---- matching ---------------------------------------------------------------------------------
 def pairwise_sqdist(x: torch.Tensor, y: torch.Tensor, precision=F32,
                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """dist[i][j] = |x_i|^2 + |y_j|^2 - 2 x_i.y_j for float32 x [m][d], y [n][d]."""
+    """dist[i][j] = |x_i|^2 + |y_j|^2 - 2 x_i.y_j for x [m][d], y [n][d] stored as float32, float16
+    or bfloat16 (16-bit rows are widened exactly; see oibl_pairwise_sqdist_st)."""
     p = precision_code(precision)
     dev = _need_cuda(x, y)
     if out is not None and (not out.is_cuda or out.dtype != torch.float32 or out.dim() != 2
                             or out.stride(1) != 1 or out.device != dev):
         raise ValueError("pairwise_sqdist: `out` must be a float32 CUDA matrix with unit column stride")
-    if x.dtype != torch.float32 or y.dtype != torch.float32 or x.dim() != 2 or y.dim() != 2:
-        raise ValueError("pairwise_sqdist expects float32 [m][d] and [n][d]")
+    if x.dim() != 2 or y.dim() != 2:
+        raise ValueError("pairwise_sqdist expects [m][d] and [n][d]")
+    xs, ys = storage_code(x), storage_code(y)
     m, d = map(int, x.shape)
     n = int(y.shape[0])
     if int(y.shape[1]) != d:
@@ -374,10 +442,11 @@ def pairwise_sqdist(x: torch.Tensor, y: torch.Tensor, precision=F32,
     if m == 0 or n == 0:
         return out
     lib = _lib.load()
-    ws_bytes = lib.oibl_pairwise_workspace_bytes(m, n, d, p)
+    ws_bytes = lib.oibl_pairwise_st_workspace_bytes(m, n, d, p, xs, ys)
     ws = workspace(ws_bytes, dev, "pairwise")
-    _lib.check(lib.oibl_pairwise_sqdist(_ptr(x), m, _ptr(y), n, d, p, _ptr(out), int(out.stride(0)),
-                                        _ptr(ws), ws.numel(), _stream(dev)), "pairwise_sqdist")
+    _lib.check(lib.oibl_pairwise_sqdist_st(_ptr(x), xs, m, _ptr(y), ys, n, d, p, _ptr(out),
+                                           int(out.stride(0)), _ptr(ws), ws.numel(), _stream(dev)),
+               "pairwise_sqdist")
     return out
 
 
@@ -442,8 +511,9 @@ def sqdist_topk(x: torch.Tensor, y: torch.Tensor, k: int, index_base: int = 0, p
     a device flag; it is read here (one 4-byte copy) and the call repeated on the exact path."""
     p = precision_code(precision)
     dev = _need_cuda(x, y)
-    if x.dtype != torch.float32 or y.dtype != torch.float32 or x.dim() != 2 or y.dim() != 2:
-        raise ValueError("sqdist_topk expects float32 [m][d] and [n][d]")
+    if x.dim() != 2 or y.dim() != 2:
+        raise ValueError("sqdist_topk expects [m][d] and [n][d]")
+    xs, ys = storage_code(x), storage_code(y)
     m, d = map(int, x.shape)
     n = int(y.shape[0])
     if int(y.shape[1]) != d:
@@ -454,13 +524,13 @@ def sqdist_topk(x: torch.Tensor, y: torch.Tensor, k: int, index_base: int = 0, p
         return ov, oi
     lib = _lib.load()
     x, y = x.contiguous(), y.contiguous()
-    ws_bytes = lib.oibl_sqdist_topk_workspace_bytes(m, n, d, k, p)
+    ws_bytes = lib.oibl_sqdist_topk_st_workspace_bytes(m, n, d, k, p, xs, ys)
     ws = workspace(ws_bytes, dev, "sqdist_topk")
     flag = torch.zeros(1, dtype=torch.int32, device=dev)
     for ex in ([1] if exact else [0, 1]):
-        _lib.check(lib.oibl_sqdist_topk(_ptr(x), m, _ptr(y), n, d, k, int(index_base), p, ex, _ptr(ov),
-                                        _ptr(oi), _ptr(flag), _ptr(ws), ws.numel(), _stream(dev)),
-                   "sqdist_topk")
+        _lib.check(lib.oibl_sqdist_topk_st(_ptr(x), xs, m, _ptr(y), ys, n, d, k, int(index_base), p, ex,
+                                           _ptr(ov), _ptr(oi), _ptr(flag), _ptr(ws), ws.numel(),
+                                           _stream(dev)), "sqdist_topk")
         if ex == 1 or int(flag.item()) == 0:
             break
     return ov, oi

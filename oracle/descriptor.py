@@ -110,3 +110,21 @@ def extract_cnn_feature(x, sd, vlad=True, dtype=torch.float32, with_pca=True):
         return F.normalize(embednetpca(x, sd, dtype), p=2, dim=-1)
     pool_x, vl = embednet(x, sd, dtype)
     return F.normalize(vl if vlad else pool_x, p=2, dim=-1)
+
+
+def scaled_size(H: int, W: int, s: float):
+    return max(16, int(round(H * s))), max(16, int(round(W * s)))
+
+
+def multiscale_descriptor(x, sd, scales=(1.0, 2.0 ** -0.5, 0.5), dtype=torch.float32, with_pca=True):
+    """Definition of the multi-scale extension (BASELINE.json configs[4]; NOT in the reference, see
+    openibl_amd/multiscale.py): per scale F.interpolate(bilinear, align_corners=False) ->
+    extract_cnn_feature, then the L2-normalised sum over scales."""
+    H, W = int(x.shape[2]), int(x.shape[3])
+    acc = None
+    for s in scales:
+        size = scaled_size(H, W, float(s))
+        xs = x if size == (H, W) else F.interpolate(x, size=size, mode="bilinear", align_corners=False)
+        d = extract_cnn_feature(xs, sd, dtype=dtype, with_pca=with_pca)
+        acc = d if acc is None else acc + d
+    return F.normalize(acc, p=2, dim=-1)

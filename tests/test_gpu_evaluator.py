@@ -76,3 +76,46 @@ def test_evaluator_flows_agree_with_oracle(group, state_dict, dev):
     want_rr = om.evaluate_all(d_rr, gt, [g[1] for g in gallery])
     print("re-ranked recalls", r_rr, want_rr)
     assert np.array_equal(r_rr, want_rr)
+
+
+def test_evaluator_extensions_16bit_storage_and_multiscale(group, state_dict, dev):
+    """BASELINE.json configs[4] extensions through the Evaluator: descriptors stored in 16 bits
+    (device-resident and host flows agree with each other and with the oracle on the widened
+    values), and multi-scale extraction against the oracle's definition."""
+    import hubconf
+    from ibl.evaluators import Evaluator
+    from ibl.utils.data.sampler import DistributedSliceSampler
+    model = hubconf.vgg16_netvlad()
+    model.load_state_dict(state_dict)
+    model = model.to(dev).eval()
+    nq, ng = 4, 11
+    imgs = synth.images(nq + ng, 64, 96, seed=43)
+    for i in range(nq):
+        imgs[i] = imgs[nq + 2 * i + 1] + 2.0 * torch.randn_like(imgs[i])
+    query = [(f"q{i}.png", 1000 + i, 0.0, 0.0) for i in range(nq)]
+    gallery = [(f"g{j}.png", j // 3, 0.0, 0.0) for j in range(ng)]
+    gt = [[2 * i + 1] for i in range(nq)]
+    qset, gset = _Records(imgs[:nq], query), _Records(imgs[nq:], gallery)
+
+    def loader(ds):
+        return torch.utils.data.DataLoader(ds, batch_size=3, num_workers=0, shuffle=False,
+                                           sampler=DistributedSliceSampler(ds))
+
+    pids = [g[1] for g in gallery]
+    with torch.no_grad():
+        desc = od.extract_cnn_feature(imgs, state_dict)
+        desc_ms = od.multiscale_descriptor(imgs, state_dict, (1.0, 0.5))
+    for dt in (torch.float16, torch.bfloat16):
+        ev = Evaluator(model, descriptor_dtype=dt)
+        r_dev = ev.evaluate(loader(qset), query + gallery, query, gallery, gt, gallery_loader=loader(gset))
+        r_host = ev.evaluate(loader(qset), query + gallery, query, gallery, gt,
+                             gallery_loader=loader(gset), device_resident=False)
+        w = desc.to(dt).float()
+        want = om.evaluate_all(om.pairwise_distance(w[:nq], w[nq:]).numpy(), gt, pids)
+        print(dt, "recalls", r_dev, r_host, want)
+        assert np.array_equal(r_dev, want) and np.array_equal(r_host, want)
+    ev = Evaluator(model, scales=(1.0, 0.5))
+    r_ms = ev.evaluate(loader(qset), query + gallery, query, gallery, gt, gallery_loader=loader(gset))
+    want_ms = om.evaluate_all(om.pairwise_distance(desc_ms[:nq], desc_ms[nq:]).numpy(), gt, pids)
+    print("multi-scale recalls", r_ms, want_ms)
+    assert np.array_equal(r_ms, want_ms)

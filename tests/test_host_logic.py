@@ -139,3 +139,25 @@ def test_re_ranking_matches_reference_golden():
         got = re_ranking(qg.copy(), qq.copy(), gg.copy(), k1=k1, k2=k2, lambda_value=lam)
         assert got.shape == g[key].shape and got.dtype == np.float32
         np.testing.assert_allclose(got, g[key], rtol=0, atol=2e-6)
+
+
+def test_multiscale_definition_host_side(state_dict):
+    """configs[4] extension: product and oracle agree on the scaled sizes; the oracle definition
+    with the single scale 1.0 is the plain descriptor; the fused descriptor is unit-norm; and the
+    product refuses to run without the HIP extension's device (no CPU fallback)."""
+    from openibl_amd import multiscale
+    from openibl_amd.lib import OpenIBLAmdError
+    from oracle import descriptor as od
+    for H, W in [(480, 640), (33, 47), (16, 16), (20, 700)]:
+        for s in multiscale.DEFAULT_SCALES + (0.01, 1.5):
+            assert multiscale.scaled_size(H, W, s) == od.scaled_size(H, W, s)
+    assert multiscale.scaled_size(480, 640, 2.0 ** -0.5) == (339, 453)
+    x = synth.images(1, 32, 48, seed=4)
+    with torch.no_grad():
+        one = od.multiscale_descriptor(x, state_dict, (1.0,))
+        ref = od.extract_cnn_feature(x, state_dict)
+        three = od.multiscale_descriptor(x, state_dict)
+    assert torch.allclose(one, ref, atol=1e-7)
+    assert abs(float(three.norm()) - 1.0) < 1e-5
+    with pytest.raises((OpenIBLAmdError, ValueError)):
+        multiscale.extract_multiscale(lambda t: t, x)      # CPU tensor: must not silently compute
