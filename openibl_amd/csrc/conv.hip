@@ -464,6 +464,11 @@ static int launch_conv_ring_impl(const ConvParams& p, hipStream_t st) {
   q.relu = p.relu;
   q.prof = g_prof_buf;
   q.ablate = g_ring_ablate;
+  {
+    const unsigned hq = POOL ? p.H >> 1 : p.H, wq = POOL ? p.W >> 1 : p.W;
+    ring_magic_u31(hq * wq ? hq * wq : 1u, &q.hw_mul, &q.hw_sh);
+    ring_magic_u31(wq ? wq : 1u, &q.w_mul, &q.w_sh);
+  }
   const long tiles_m = (p.m_total + G::BM - 1) / G::BM;
   const long grid = tiles_m * q.tiles_n;
   constexpr int lds = ring_lds_bytes<WM, POOL>();

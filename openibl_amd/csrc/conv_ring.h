@@ -27,9 +27,25 @@ struct RingParams {
   int tiles_n;
   int relu;
   unsigned long long* prof;  // optional (test hook): shader-clock stamps of block 0, wave 0
+  // floor(m / d) for m < 2^31 as (m * mul) >> sh (ring_magic_u31): d = pixels (pooled: quads) per
+  // image, and per image row.  An emulated 32-bit divide costs ~25 instructions, and every lane
+  // decomposes 8-16 GEMM rows before the first load can be issued.
+  unsigned hw_mul, hw_sh, w_mul, w_sh;
   int ablate;  // timing experiments only (WRONG results): 1 = pixel loads of taps != 0 all hit one
                // line, 2 = weight loads after the first K-tile all hit one line, 3 = both
 };
+
+// mul, sh with floor(m / d) == (m * mul) >> sh for every m < 2^31 (d >= 1):  sh = 31 + ceil(log2 d),
+// mul = ceil(2^sh / d) < 2^32; the rounding error (mul d - 2^sh) m / (d 2^sh) < m / 2^31 / d < 1 / d.
+static inline void ring_magic_u31(unsigned d, unsigned* mul, unsigned* sh) {
+  unsigned s = 0;
+  while (((unsigned long long)1 << s) < d) ++s;
+  *sh = 31 + s;
+  *mul = (unsigned)((((unsigned long long)1 << (31 + s)) + d - 1) / d);
+}
+__device__ static inline unsigned ring_div_u31(unsigned m, unsigned mul, unsigned sh) {
+  return (unsigned)(((unsigned long long)m * mul) >> sh);
+}
 
 template <int WM, bool POOL>
 constexpr int ring_lds_bytes() {
@@ -68,9 +84,9 @@ struct ConvRingALoader {
       if (m < (unsigned)p.m_total) {
         const unsigned q = POOL ? (m >> 2) : m;
         const unsigned sub = POOL ? (m & 3u) : 0u;
-        const unsigned n = q / hw;
+        const unsigned n = ring_div_u31(q, p.hw_mul, p.hw_sh);
         const unsigned rem = q - n * hw;
-        const unsigned yq = rem / (unsigned)Wq;
+        const unsigned yq = ring_div_u31(rem, p.w_mul, p.w_sh);
         int y = (int)yq, x = (int)(rem - yq * (unsigned)Wq);
         if (POOL) {
           y = 2 * y + (int)(sub >> 1);
