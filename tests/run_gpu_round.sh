@@ -17,6 +17,9 @@ if [ -z "$QUICK" ]; then
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke exit $?" | tee -a $OUT/smoke.log
 fi
 timeout 900 python bench.py --steps 20 --warmup 3 2> $OUT/bench_err.log | tee $OUT/bench.json
+# the launch line the driver uses for N > 1, with one rank: RCCL init / barrier / all-reduce path
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 \
+  bench.py --gpus 1 --steps 10 --warmup 2 --skip-cpu-baseline 2> $OUT/bench_torchrun_err.log | tee $OUT/bench_torchrun.json
 timeout 600 python tests/gpu_timing.py --batch 32 --precision bf16 2>&1 | grep -v amdgpu.ids | tee $OUT/timing_bf16.log
 if [ -z "$QUICK" ]; then
   timeout 600 python tests/gpu_timing.py --batch 8 --precision fp32 2>&1 | grep -v amdgpu.ids | tee $OUT/timing_fp32.log
