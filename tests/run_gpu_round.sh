@@ -27,7 +27,8 @@ if [ -z "$QUICK" ]; then
 fi
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 5 --warmup 2 --skip-matching --skip-cpu-baseline"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o bench -- python $R/bench.py $ARGS > $OUT/prof_stats.log 2>&1
+# kernel stats over a run long enough that steady-state launches dominate the averages
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o bench -- python $R/bench.py --steps 40 --warmup 5 --skip-matching --skip-cpu-baseline > $OUT/prof_stats.log 2>&1
 if [ -z "$QUICK" ]; then
   timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch -o bench -- python $R/bench.py $ARGS > $OUT/prof_fetch.log 2>&1
   timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write -o bench -- python $R/bench.py $ARGS > $OUT/prof_write.log 2>&1

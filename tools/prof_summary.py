@@ -67,7 +67,7 @@ def main():
         if (d / "smoke.log").exists():
             f.write("==== smoke\n" + "\n".join((d / "smoke.log").read_text().splitlines()[-2:]) + "\n")
     for sub, title in (
-            ("prof_stats", "python bench.py --steps 5 --warmup 2 --skip-matching --skip-cpu-baseline"),
+            ("prof_stats", "python bench.py --steps 40 --warmup 5 --skip-matching --skip-cpu-baseline"),
             ("prof_match", "python bench.py --steps 2 --warmup 1 --skip-cpu-baseline (with matching)")):
         p = d / sub / "bench_kernel_stats.csv"
         if p.exists():
