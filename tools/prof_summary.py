@@ -58,6 +58,11 @@ def main():
     if (d / "bench.json").exists():
         shutil.copy(d / "bench.json", prof / f"{tag}_bench.json")
     with open(prof / f"{tag}_timing.txt", "w") as f:
+        if (d / "bench_torchrun.json").exists():
+            f.write("==== python -m torch.distributed.run --nproc-per-node 1 ... bench.py --gpus 1 "
+                    "--steps 10 --warmup 2 (RCCL group with one rank)\n"
+                    + "\n".join(l for l in (d / "bench_torchrun.json").read_text().splitlines()
+                                if l.startswith("{")) + "\n\n")
         for n in ("gpu.txt", "timing_bf16.log", "timing_fp32.log", "pcie.log", "convbench.log"):
             if (d / n).exists():
                 f.write(f"==== {n}\n" + (d / n).read_text() + "\n")
