@@ -100,12 +100,20 @@ def _extract_local(model, data_loader, vlad, pca, gpu, print_freq, rank, scales=
     return torch.cat(chunks)
 
 
+def _host_f32(t: torch.Tensor) -> torch.Tensor:
+    """Device descriptors (any storage type) -> float32 on the host; 16-bit rows are widened by the
+    HIP cast before they leave the device."""
+    if t.is_cuda and t.dtype != torch.float32 and t.numel():
+        t = ops.load_descriptors(t.contiguous())
+    return t.to("cpu", copy=True).float()
+
+
 def _gather_all(local: torch.Tensor, sync_gather: bool, rank: int, world: int) -> torch.Tensor:
     """Every rank's [per][d] block -> [world * per][d] on the host, rank-major."""
     if world == 1:
-        return local.cpu().float()
+        return _host_f32(local)
     if sync_gather:  # one all_gather (evaluators.py:76-88)
-        return sharded.all_gather_rows(local).cpu().float()
+        return _host_f32(sharded.all_gather_rows(local))
     parts = []  # rank-by-rank broadcast, one block resident at a time (evaluators.py:89-101)
     buf = torch.empty_like(local)
     for k in range(world):
@@ -114,8 +122,8 @@ def _gather_all(local: torch.Tensor, sync_gather: bool, rank: int, world: int) -
         if rank == 0:
             print("gathering features from rank no.{}".format(k))
         dist.broadcast(buf, k)
-        parts.append(buf.to("cpu", copy=True))   # the buffer is reused for the next rank
-    return torch.cat(parts).float()
+        parts.append(_host_f32(buf))   # (a copy: the buffer is reused for the next rank)
+    return torch.cat(parts)
 
 
 def extract_features(model, data_loader, dataset, print_freq=10, vlad=True, pca=None, gpu=None,
