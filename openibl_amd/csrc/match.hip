@@ -347,6 +347,44 @@ __device__ static inline void bitonic_sort_lds(unsigned long long* buf, int n_po
   }
 }
 
+// Short rows and small k (the two calls of the fused distance + top-k: 1024 sample distances, ~1000
+// candidates; k = 10): no LDS candidate buffer and no 55-stage bitonic sort — every lane keeps up
+// to 8 keys in registers, each wave extracts its k smallest by k rounds of (lane minimum, wave
+// minimum, the owning lane retires that key), and wave 0 repeats the same over the 4 k survivors.
+// Keys are unique except for (+inf, -1) paddings, so exactly one copy is retired per round and the
+// result is the sorted prefix the bitonic path produces.
+constexpr int SEL_MAX_K = 32, SEL_MAX_N = 2048;
+
+__device__ static inline unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned lo = __shfl_xor((unsigned)v, o, 64), hi = __shfl_xor((unsigned)(v >> 32), o, 64);
+    const unsigned long long w = ((unsigned long long)hi << 32) | lo;
+    v = w < v ? w : v;
+  }
+  return v;
+}
+
+// one selection round over NQ register keys per lane: returns the wave's smallest key and retires it
+template <int NQ>
+__device__ static inline unsigned long long wave_extract_min(unsigned long long (&mine)[NQ], int lane) {
+  unsigned long long m = mine[0];
+#pragma unroll
+  for (int q = 1; q < NQ; ++q) m = mine[q] < m ? mine[q] : m;
+  const unsigned long long w = wave_min_u64(m);
+  const unsigned long long owners = __ballot(m == w);
+  if (lane == __ffsll((long long)owners) - 1) {
+    bool done = false;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      if (!done && mine[q] == w) {
+        mine[q] = TOPK_INF;
+        done = true;
+      }
+  }
+  return w;
+}
+
 // row_n (optional): per-row element count (clamped to n); a count above n raises *overflow.
 __global__ __launch_bounds__(256) void row_topk_kernel(const float* __restrict__ vals,
                                                        const int32_t* __restrict__ idx_in, int n,
@@ -365,6 +403,44 @@ __global__ __launch_bounds__(256) void row_topk_kernel(const float* __restrict__
     const int have_n = row_n[row];
     if (have_n > n && tid == 0 && overflow) atomicOr(overflow, 1);
     n = have_n < n ? have_n : n;
+  }
+  if (k <= SEL_MAX_K && n <= SEL_MAX_N) {  // workgroup-uniform
+    unsigned long long* const wsel = cand;  // [4][SEL_MAX_K]
+    const int lane = tid & 63, wave = tid >> 6;
+    unsigned long long mine[SEL_MAX_N / 256];
+#pragma unroll
+    for (int q = 0; q < SEL_MAX_N / 256; ++q) {
+      const int j = tid + 256 * q;
+      mine[q] = TOPK_INF;
+      if (j < n) {
+        const uint32_t id = ir ? (uint32_t)ir[j] : (uint32_t)(index_base + j);
+        mine[q] = ((unsigned long long)ordered_bits(vr[j]) << 32) | id;
+      }
+    }
+    for (int r = 0; r < k; ++r) {
+      const unsigned long long w = wave_extract_min(mine, lane);
+      if (lane == 0) wsel[wave * SEL_MAX_K + r] = w;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      unsigned long long two[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int e = lane + 64 * h;  // survivor e = wave (e / k), rank (e % k)
+        two[h] = e < 4 * k ? wsel[(e / k) * SEL_MAX_K + (e % k)] : TOPK_INF;
+      }
+      unsigned long long res = TOPK_INF;
+      for (int r = 0; r < k; ++r) {
+        const unsigned long long w = wave_extract_min(two, lane);
+        if (lane == r) res = w;
+      }
+      if (lane < k) {
+        const bool valid = lane < n;
+        out_val[(size_t)row * k + lane] = valid ? from_ordered_bits((uint32_t)(res >> 32)) : INFINITY;
+        out_idx[(size_t)row * k + lane] = valid ? (int32_t)(uint32_t)(res & 0xffffffffu) : -1;
+      }
+    }
+    return;
   }
   if (tid == 0) {
     cnt = 0;
