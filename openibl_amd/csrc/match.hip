@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void row_topk_kernel(const float* __restrict__
                                                        float* __restrict__ out_val,
                                                        int32_t* __restrict__ out_idx,
                                                        const int* __restrict__ row_n,
-                                                       int* __restrict__ overflow) {
+                                                       int* __restrict__ overflow, int skip_le) {
   __shared__ unsigned long long cand[TOPK_CAP];
   __shared__ int cnt;
   __shared__ unsigned long long thr;
@@ -404,6 +404,7 @@ __global__ __launch_bounds__(256) void row_topk_kernel(const float* __restrict__
     if (have_n > n && tid == 0 && overflow) atomicOr(overflow, 1);
     n = have_n < n ? have_n : n;
   }
+  if (n <= skip_le) return;  // row_select_wave_kernel owns the short rows of this launch pair
   if (k <= SEL_MAX_K && n <= SEL_MAX_N) {  // workgroup-uniform
     unsigned long long* const wsel = cand;  // [4][SEL_MAX_K]
     const int lane = tid & 63, wave = tid >> 6;
@@ -489,6 +490,72 @@ __global__ __launch_bounds__(256) void row_topk_kernel(const float* __restrict__
     out_val[(size_t)row * k + i] = valid ? from_ordered_bits((uint32_t)(key >> 32)) : INFINITY;
     out_idx[(size_t)row * k + i] = valid ? (int32_t)(uint32_t)(key & 0xffffffffu) : -1;
   }
+}
+
+// Short rows (<= 1024 elements, k <= 32: the distance sample, the merge of the per-shard lists, and
+// nearly every candidate list): one WAVE per row, four rows per workgroup — the selection rounds
+// above without the second stage, the LDS hand-over or a barrier.  With row_n, rows longer than
+// 64 NQ are left to row_topk_kernel (launched right after with skip_le = 64 NQ).
+template <int NQ>
+__global__ __launch_bounds__(256) void row_select_wave_kernel(const float* __restrict__ vals,
+                                                              const int32_t* __restrict__ idx_in,
+                                                              int m, int n, size_t ld, int k,
+                                                              int index_base,
+                                                              float* __restrict__ out_val,
+                                                              int32_t* __restrict__ out_idx,
+                                                              const int* __restrict__ row_n) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= m) return;  // wave-uniform
+  if (row_n) {
+    const int have_n = row_n[row];
+    n = have_n < n ? have_n : n;
+    if (n > 64 * NQ) return;
+  }
+  const float* vr = vals + (size_t)row * ld;
+  const int32_t* ir = idx_in ? idx_in + (size_t)row * ld : nullptr;
+  unsigned long long mine[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int j = lane + 64 * q;
+    mine[q] = TOPK_INF;
+    if (j < n) {
+      const uint32_t id = ir ? (uint32_t)ir[j] : (uint32_t)(index_base + j);
+      mine[q] = ((unsigned long long)ordered_bits(vr[j]) << 32) | id;
+    }
+  }
+  unsigned long long res = TOPK_INF;
+  for (int r = 0; r < k; ++r) {
+    const unsigned long long w = wave_extract_min(mine, lane);
+    if (lane == r) res = w;
+  }
+  if (lane < k) {
+    const bool valid = lane < n;
+    out_val[(size_t)row * k + lane] = valid ? from_ordered_bits((uint32_t)(res >> 32)) : INFINITY;
+    out_idx[(size_t)row * k + lane] = valid ? (int32_t)(uint32_t)(res & 0xffffffffu) : -1;
+  }
+}
+
+// dispatch: wave-per-row selection for short rows, one workgroup per row for the rest
+static void launch_row_topk(const float* vals, const int32_t* idx_in, int m, int n, size_t ld, int k,
+                            int index_base, float* out_val, int32_t* out_idx, const int* row_n,
+                            int* overflow, hipStream_t st) {
+  const dim3 wgrid((m + 3) / 4), block(256);
+  int skip_le = -1;
+  if (k <= SEL_MAX_K && !row_n && n <= 512) {
+    hipLaunchKernelGGL(row_select_wave_kernel<8>, wgrid, block, 0, st, vals, idx_in, m, n, ld, k,
+                       index_base, out_val, out_idx, row_n);
+    return;
+  }
+  if (k <= SEL_MAX_K && (row_n || n <= 1024)) {
+    hipLaunchKernelGGL(row_select_wave_kernel<16>, wgrid, block, 0, st, vals, idx_in, m, n, ld, k,
+                       index_base, out_val, out_idx, row_n);
+    if (!row_n) return;
+    skip_le = 1024;  // per-row lengths: the workgroup kernel takes the rows above 1024 (and raises
+                     // the overflow flag for rows beyond the capacity)
+  }
+  hipLaunchKernelGGL(row_topk_kernel, dim3(m), block, 0, st, vals, idx_in, n, ld, k, index_base,
+                     out_val, out_idx, row_n, overflow, skip_le);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -767,8 +834,14 @@ struct TopkPlan {
 };
 static TopkPlan topk_plan(int m, int n, int d, int k, int precision, int x_st, int y_st) {
   TopkPlan t = {};
+  // Sample size: the k-th smallest of S sampled distances lets ~ k n / S gallery rows through the
+  // filter.  1024 rows keep the survivor density near 1 % of a tile (the filter epilogue's per-lane
+  // lists are sized for that; a 256-row sample on a 10k-row shard — 4 % — slowed the contraction
+  // from 1.2 to 0.93 PFLOP/s and saved nothing: the sample pass costs the latency of one 256 x 256
+  // tile over K = 4096 whatever S is); galleries beyond 82k rows sample 2048 so that the candidate
+  // lists stay on the register selection path of row_topk.
   int S = 1024;
-  while (S < 4 * k) S *= 2;
+  while ((S < 4 * k || (long)S * 800 < (long)k * n) && S < SEL_MAX_N) S *= 2;
   t.fused = precision == OIBL_BF16 && g_match_ring && pair_ring_legal(m, n, d) && n >= 8 * S &&
             (long)((m + 255) / 256) * ((n + 255) / 256) >= 64;
   t.S = S;
@@ -866,9 +939,7 @@ int oibl_sqdist_topk_st(const void* x, int x_st, int m, const void* y, int y_st,
     q.d = d;
     rc = launch_pairwise_ring<false>(q, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(row_topk_kernel, dim3(m), dim3(256), 0, st, (const float*)sample,
-                       (const int32_t*)nullptr, t.S, (size_t)t.S, k, 0, sval, sidx,
-                       (const int*)nullptr, (int*)nullptr);
+    launch_row_topk(sample, nullptr, m, t.S, (size_t)t.S, k, 0, sval, sidx, nullptr, nullptr, st);
     OIBL_LAUNCH_CHECK();
     // 2. the full contraction, keeping only distances <= threshold
     int* cnt = (int*)(wsb + t.off_cnt);
@@ -888,9 +959,8 @@ int oibl_sqdist_topk_st(const void* x, int x_st, int m, const void* y, int y_st,
     rc = launch_pairwise_ring<true>(q, st);
     if (rc) return rc;
     // 3. exact top-k of every candidate list ((value, index) keys: independent of append order)
-    hipLaunchKernelGGL(row_topk_kernel, dim3(m), dim3(256), 0, st, (const float*)q.cand_val,
-                       (const int32_t*)q.cand_idx, t.cap, (size_t)t.cap, k, 0, out_val, out_idx,
-                       (const int*)cnt, (int*)overflow);
+    launch_row_topk(q.cand_val, q.cand_idx, m, t.cap, (size_t)t.cap, k, 0, out_val, out_idx, cnt,
+                    (int*)overflow, st);
     OIBL_LAUNCH_CHECK();
     return OIBL_OK;
   }
@@ -899,9 +969,8 @@ int oibl_sqdist_topk_st(const void* x, int x_st, int m, const void* y, int y_st,
     const int rows = m - r0 < t.chunk ? m - r0 : t.chunk;
     rc = pairwise_launch(xo, yo, xn, yn, r0, rows, m, n, d, precision, tile, (size_t)n, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(row_topk_kernel, dim3(rows), dim3(256), 0, st, (const float*)tile,
-                       (const int32_t*)nullptr, n, (size_t)n, k, index_base, out_val + (size_t)r0 * k,
-                       out_idx + (size_t)r0 * k, (const int*)nullptr, (int*)nullptr);
+    launch_row_topk(tile, nullptr, rows, n, (size_t)n, k, index_base, out_val + (size_t)r0 * k,
+                    out_idx + (size_t)r0 * k, nullptr, nullptr, st);
     OIBL_LAUNCH_CHECK();
   }
   return OIBL_OK;
@@ -924,8 +993,8 @@ int oibl_row_topk(const float* vals, const int32_t* idx_in, int m, int n, size_t
   OIBL_REQUIRE(vals && out_val && out_idx, "row_topk: null pointer");
   OIBL_REQUIRE(m > 0 && n > 0 && ld >= (size_t)n, "row_topk: bad shape m=%d n=%d ld=%zu", m, n, ld);
   OIBL_REQUIRE(k >= 1 && k <= 1024, "row_topk: k=%d outside [1, 1024]", k);
-  hipLaunchKernelGGL(row_topk_kernel, dim3(m), dim3(256), 0, (hipStream_t)stream, vals, idx_in, n,
-                     ld, k, index_base, out_val, out_idx, (const int*)nullptr, (int*)nullptr);
+  launch_row_topk(vals, idx_in, m, n, ld, k, index_base, out_val, out_idx, nullptr, nullptr,
+                  (hipStream_t)stream);
   OIBL_LAUNCH_CHECK();
   return OIBL_OK;
 }

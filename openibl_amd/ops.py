@@ -504,11 +504,14 @@ def set_match_ring(mode: int) -> None:
 
 
 def sqdist_topk(x: torch.Tensor, y: torch.Tensor, k: int, index_base: int = 0, precision=F32,
-                exact: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+                exact: bool = False, defer_check: bool = False):
     """k nearest rows of y (squared L2) for every row of x, without materialising the matrix:
     (values [m][k] ascending, indices [m][k] int32 = index_base + row of y).  Equals
     row_topk(pairwise_sqdist(x, y), k).  The fused bf16 path reports candidate-list overflow through
-    a device flag; it is read here (one 4-byte copy) and the call repeated on the exact path."""
+    a device flag; it is read here (one 4-byte copy) and the call repeated on the exact path.
+    defer_check=True skips that host synchronisation and returns (values, indices, flag) with the
+    int32 device flag: the caller reads it when it synchronises anyway and repeats with exact=True
+    if it is set (sharded.sharded_topk ships it with the per-shard lists)."""
     p = precision_code(precision)
     dev = _need_cuda(x, y)
     if x.dim() != 2 or y.dim() != 2:
@@ -520,17 +523,24 @@ def sqdist_topk(x: torch.Tensor, y: torch.Tensor, k: int, index_base: int = 0, p
         raise ValueError("sqdist_topk: dimension mismatch")
     ov = torch.full((m, k), float("inf"), dtype=torch.float32, device=dev)
     oi = torch.full((m, k), -1, dtype=torch.int32, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
     if m == 0 or n == 0:
-        return ov, oi
+        return (ov, oi, flag) if defer_check else (ov, oi)
     lib = _lib.load()
     x, y = x.contiguous(), y.contiguous()
     ws_bytes = lib.oibl_sqdist_topk_st_workspace_bytes(m, n, d, k, p, xs, ys)
     ws = workspace(ws_bytes, dev, "sqdist_topk")
-    flag = torch.zeros(1, dtype=torch.int32, device=dev)
-    for ex in ([1] if exact else [0, 1]):
+
+    def run(ex: int) -> None:
         _lib.check(lib.oibl_sqdist_topk_st(_ptr(x), xs, m, _ptr(y), ys, n, d, k, int(index_base), p, ex,
                                            _ptr(ov), _ptr(oi), _ptr(flag), _ptr(ws), ws.numel(),
                                            _stream(dev)), "sqdist_topk")
+
+    if defer_check:
+        run(1 if exact else 0)
+        return ov, oi, flag
+    for ex in ([1] if exact else [0, 1]):
+        run(ex)
         if ex == 1 or int(flag.item()) == 0:
             break
     return ov, oi

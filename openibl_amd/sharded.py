@@ -40,14 +40,18 @@ def slice_bounds(length: int, rank: int, world_size: int) -> Tuple[int, int, int
     return start, per, n_valid
 
 
-def hip_local_topk(q: torch.Tensor, g: torch.Tensor, k: int, index_base: int, precision
-                   ) -> Tuple[torch.Tensor, torch.Tensor]:
-    """[Q][d] x [n][d] -> k nearest of the local slice per query (HIP kernels)."""
+def hip_local_topk(q: torch.Tensor, g: torch.Tensor, k: int, index_base: int, precision,
+                   exact: bool = False):
+    """[Q][d] x [n][d] -> k nearest of the local slice per query (HIP kernels), plus the device
+    flag of the fused path (candidate-list overflow: the lists are then undefined and the call must
+    be repeated with exact=True).  Nothing here synchronises with the host."""
     Q = q.shape[0]
     if g.shape[0] == 0:
         return (torch.full((Q, k), float("inf"), device=q.device),
-                torch.full((Q, k), -1, dtype=torch.int32, device=q.device))
-    return ops.sqdist_topk(q, g, k, index_base=index_base, precision=precision)
+                torch.full((Q, k), -1, dtype=torch.int32, device=q.device),
+                torch.zeros(1, dtype=torch.int32, device=q.device))
+    return ops.sqdist_topk(q, g, k, index_base=index_base, precision=precision, exact=exact,
+                           defer_check=True)
 
 
 def hip_merge_topk(vals: torch.Tensor, idx: torch.Tensor, k: int):
@@ -79,11 +83,36 @@ def sharded_topk(q_all: torch.Tensor, g_local: torch.Tensor, k: int, index_base:
     local_topk_fn = local_topk_fn or hip_local_topk
     merge_fn = merge_fn or hip_merge_topk
     rank, world = _world(group)
-    v, i = local_topk_fn(q_all, g_local, k, index_base, precision)
-    if world == 1:
-        return v, i
-    vs = [torch.empty_like(v) for _ in range(world)]
-    is_ = [torch.empty_like(i) for _ in range(world)]
-    dist.all_gather(vs, v.contiguous(), group=group)
-    dist.all_gather(is_, i.contiguous(), group=group)
-    return merge_fn(torch.cat(vs, dim=1), torch.cat(is_, dim=1), k)
+
+    def local(exact: bool):
+        res = local_topk_fn(q_all, g_local, k, index_base, precision, exact) if exact else \
+            local_topk_fn(q_all, g_local, k, index_base, precision)
+        if len(res) == 3:
+            return res
+        v_, i_ = res                      # an exact implementation (tests): no overflow flag
+        return v_, i_, torch.zeros(1, dtype=torch.int32, device=v_.device)
+
+    def gather_and_merge(v, i, flag):
+        if world == 1:
+            return v, i, flag
+        # one collective for everything: the int32 indices travel as the bit pattern of a float32
+        # next to the values, the overflow flag as one more row ([Q + 1][2k] per rank; nothing
+        # computes on them in transit), so every rank sees every rank's flag
+        Q = v.shape[0]
+        row = flag.view(torch.float32).expand(1, 2 * k)
+        packed = torch.cat([torch.cat([v, i.view(torch.float32)], dim=1), row]).contiguous()
+        gathered = torch.empty((world * (Q + 1), 2 * k), dtype=torch.float32, device=packed.device)
+        dist.all_gather_into_tensor(gathered, packed, group=group)   # rank-major concatenation
+        gathered = gathered.view(world, Q + 1, 2 * k)
+        flags = gathered[:, Q, 0].contiguous().view(torch.int32)
+        lists = gathered[:, :Q, :].permute(1, 0, 2)                   # [Q][world][2k]
+        vs = lists[:, :, :k].reshape(Q, world * k)
+        is_ = lists[:, :, k:].reshape(Q, world * k).view(torch.int32)
+        mv, mi = merge_fn(vs, is_, k)
+        return mv, mi, flags
+
+    v, i, flags = gather_and_merge(*local(False))
+    # the only host synchronisation, after everything has been enqueued; identical on every rank
+    if bool(flags.any().item()):
+        v, i, _ = gather_and_merge(*local(True))
+    return v, i

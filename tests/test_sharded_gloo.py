@@ -24,6 +24,20 @@ def _oracle_local_topk(q, g, k, index_base, precision):
     return vals, idx
 
 
+def _overflowing_local_topk(q, g, k, index_base, precision, exact=False):
+    """Stand-in for the fused GPU path: rank 1's first (non-exact) attempt overflows and returns
+    garbage lists with the flag raised; the exact repeat is correct on every rank."""
+    v, i = _oracle_local_topk(q, g, k, index_base, precision)
+    flag = torch.zeros(1, dtype=torch.int32)
+    if not exact and dist.get_rank() == 1:
+        v, i, flag = torch.zeros_like(v), torch.zeros_like(i), torch.ones(1, dtype=torch.int32)
+    _overflowing_local_topk.calls.append(bool(exact))
+    return v, i, flag
+
+
+_overflowing_local_topk.calls = []
+
+
 def _oracle_merge(vals, idx, k):
     key = np.lexsort((idx.numpy().astype(np.int64) & 0xFFFFFFFF, vals.numpy()), axis=1)[:, :k]
     return (torch.from_numpy(np.take_along_axis(vals.numpy(), key, 1)),
@@ -44,6 +58,12 @@ def _worker(rank, world, port, G, ret):
         d = om.pairwise_distance(q, g).numpy()
         wv, wi = om.topk(d, 10)
         ok_topk = bool(np.array_equal(idx.numpy(), wi) and np.allclose(vals.numpy(), wv))
+        # one rank's candidate lists overflow: EVERY rank must repeat on the exact path (the flag
+        # travels with the gathered lists), and the result is the correct one
+        v2, i2 = sharded.sharded_topk(q, g[start:start + n_valid], 10, start,
+                                      local_topk_fn=_overflowing_local_topk, merge_fn=_oracle_merge)
+        ok_topk = ok_topk and _overflowing_local_topk.calls == [False, True] and \
+            bool(np.array_equal(i2.numpy(), wi) and np.allclose(v2.numpy(), wv))
         rec = evaluators.recalls_from_topk(idx.numpy(), gt)
         ok_rec = bool(np.array_equal(rec, om.evaluate_all(d, gt, pids)))
 
