@@ -24,6 +24,7 @@ timeout 600 python tests/gpu_timing.py --batch 32 --precision bf16 2>&1 | grep -
 if [ -z "$QUICK" ]; then
   timeout 600 python tests/gpu_timing.py --batch 8 --precision fp32 2>&1 | grep -v amdgpu.ids | tee $OUT/timing_fp32.log
   timeout 300 python tests/gpu_pcie_rate.py 2>&1 | grep -v amdgpu.ids | tee $OUT/pcie.log
+  timeout 300 python tests/gpu_shardbench.py 2>&1 | grep -v amdgpu.ids | tee $OUT/shardbench.log
 fi
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 5 --warmup 2 --skip-matching --skip-cpu-baseline"

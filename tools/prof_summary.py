@@ -63,7 +63,7 @@ def main():
                     "--steps 10 --warmup 2 (RCCL group with one rank)\n"
                     + "\n".join(l for l in (d / "bench_torchrun.json").read_text().splitlines()
                                 if l.startswith("{")) + "\n\n")
-        for n in ("gpu.txt", "timing_bf16.log", "timing_fp32.log", "pcie.log", "convbench.log"):
+        for n in ("gpu.txt", "timing_bf16.log", "timing_fp32.log", "pcie.log", "convbench.log", "shardbench.log"):
             if (d / n).exists():
                 f.write(f"==== {n}\n" + (d / n).read_text() + "\n")
         if (d / "pytest_gpu.log").exists():
