@@ -72,11 +72,17 @@ def test_pairwise_strided_output(dev):
 
 
 @pytest.mark.parametrize("m,n,k", [(5, 3000, 10), (3, 5000, 120), (2, 7, 10), (4, 1024, 1024),
-                                   (1, 100000, 25), (6, 2049, 1)])
+                                   (1, 100000, 25), (6, 2049, 1),
+                                   # the selection paths: wave per row (<= 512, <= 1024 elements),
+                                   # workgroup selection (<= 2048), and their k = 32 / 33 boundary
+                                   (130, 300, 5), (7, 512, 31), (9, 513, 10), (9, 1024, 32),
+                                   (5, 1500, 7), (5, 2048, 32), (3, 2048, 33), (3, 1025, 33),
+                                   (1, 1, 1), (6, 40, 32)])
 def test_row_topk_vs_stable_argsort(dev, m, n, k):
     g = torch.Generator().manual_seed(n + k)
     v = torch.randn((m, n), generator=g)
-    v[:, ::7] = v[:, 1::7][:, : v[:, ::7].shape[1]]       # plant exact ties
+    w = min(v[:, ::7].shape[1], v[:, 1::7].shape[1])
+    v[:, ::7][:, :w] = v[:, 1::7][:, :w]                    # plant exact ties
     v[0, : min(n, 50)] = -3.0                               # a run of equal minima
     vals, idx = ops.row_topk(v.to(dev), k, index_base=1000)
     order = om.ranking(v.numpy())
