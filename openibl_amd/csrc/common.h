@@ -31,6 +31,24 @@ void set_error(const char* fmt, ...);
     }                                                                                 \
   } while (0)
 
+// hipFuncSetAttribute applies to the CURRENT device: bit d of a per-kernel mask remembers that the
+// kernel's dynamic-LDS limit has been raised on device d (a process may drive several devices).
+static inline bool oibl_first_use_on_device(unsigned long long* mask) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return true;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (*mask & bit) return false;
+  *mask |= bit;
+  return true;
+}
+#define OIBL_SET_MAX_LDS(kern, lds)                                                              \
+  do {                                                                                           \
+    static unsigned long long seen_ = 0;                                                         \
+    if (oibl_first_use_on_device(&seen_))                                                        \
+      OIBL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                    \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (lds)));    \
+  } while (0)
+
 #define OIBL_LAUNCH_CHECK()                                                          \
   do {                                                                               \
     hipError_t _e = hipGetLastError();                                               \

@@ -411,14 +411,7 @@ template <typename Cfg, bool POOL, bool GLDS>
 static int launch_conv_kernel(const ConvParams& q, long grid, hipStream_t st) {
   constexpr int lds = conv_lds_bytes<Cfg, POOL>();
   auto kern = conv3x3_igemm_kernel<Cfg, POOL, GLDS>;
-  if (lds > 64 * 1024) {  // opt in to more than 64 KiB of dynamic LDS once per kernel
-    static bool done = false;
-    if (!done) {
-      OIBL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-      done = true;
-    }
-  }
+  if (lds > 64 * 1024) OIBL_SET_MAX_LDS(kern, lds);  // opt in to more than 64 KiB of dynamic LDS
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::NTHREADS), lds, st, q);
   OIBL_LAUNCH_CHECK();
   return OIBL_OK;
@@ -473,12 +466,7 @@ static int launch_conv_ring_impl(const ConvParams& p, hipStream_t st) {
   const long grid = tiles_m * q.tiles_n;
   constexpr int lds = ring_lds_bytes<WM, POOL>();
   auto kern = conv3x3_ring_kernel<WM, POOL, ODD>;
-  static bool done = false;
-  if (!done) {
-    OIBL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    done = true;
-  }
+  OIBL_SET_MAX_LDS(kern, lds);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, q);
   OIBL_LAUNCH_CHECK();
   return OIBL_OK;
@@ -818,13 +806,11 @@ static int launch_conv_c64(const void* in, int N, int H, int W, const void* w, c
   int gx = 256 / slices;  // one resident workgroup per CU
   if (gx < 1) gx = 1;
   if (gx > p.ntiles) gx = p.ntiles;
-  static bool attr_done[2] = {false, false};
   auto kern = pool ? conv3x3_c64_kernel<true> : conv3x3_c64_kernel<false>;
-  if (!attr_done[pool ? 1 : 0]) {
-    OIBL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS_BYTES));
-    attr_done[pool ? 1 : 0] = true;
-  }
+  if (pool)
+    OIBL_SET_MAX_LDS(conv3x3_c64_kernel<true>, C64_LDS_BYTES);
+  else
+    OIBL_SET_MAX_LDS(conv3x3_c64_kernel<false>, C64_LDS_BYTES);
   hipLaunchKernelGGL(kern, dim3(gx, slices), dim3(256), C64_LDS_BYTES, st, p);
   OIBL_LAUNCH_CHECK();
   return OIBL_OK;
@@ -1268,12 +1254,7 @@ static int launch_vgg_stem(const void* x, int N, int H, int W, const float* mean
   if (gx > p.ntiles) gx = p.ntiles;
   constexpr int lds = U8 ? ST_LDS_BYTES_U8 : ST_LDS_BYTES;
   auto kern = vgg_stem_kernel<U8>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    OIBL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_done = true;
-  }
+  OIBL_SET_MAX_LDS(kern, lds);
   hipLaunchKernelGGL(kern, dim3(gx), dim3(512), lds, st, p);
   OIBL_LAUNCH_CHECK();
   return OIBL_OK;

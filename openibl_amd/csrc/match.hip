@@ -681,12 +681,7 @@ static int launch_pairwise_ring(PairRingParams& p, hipStream_t st) {
   OIBL_REQUIRE(grid > 0 && grid <= 0x7fffffffL, "pairwise: grid out of range");
   constexpr int lds = RingGeo<2>::MAIN_LDS;
   auto kern = pairwise_ring_kernel<FILTER>;
-  static bool done = false;
-  if (!done) {
-    OIBL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    done = true;
-  }
+  OIBL_SET_MAX_LDS(kern, lds);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, p);
   OIBL_LAUNCH_CHECK();
   return OIBL_OK;
