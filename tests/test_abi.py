@@ -64,6 +64,51 @@ def test_argument_validation_reports_errors():
     assert h.oibl_vgg16_workspace_bytes(32, 480, 640, 0) >= 2 * 32 * 480 * 640 * 64
 
 
+def test_workspace_queries_and_storage_types_host_side():
+    """Host-only parts of the matching ABI: workspace sizes (pure arithmetic) and the validation of
+    storage-type codes, which returns before any HIP call."""
+    from openibl_amd import lib
+    h = lib.load()
+    BF16, F32 = 0, 1
+    ST_F32, ST_F16, ST_BF16 = 0, 1, 2
+    m, n, d, k = 8192, 81920, 4096, 10
+    # the untyped entry points are the typed ones on float32 storage
+    for prec in (BF16, F32):
+        assert h.oibl_pairwise_workspace_bytes(m, n, d, prec) == \
+            h.oibl_pairwise_st_workspace_bytes(m, n, d, prec, ST_F32, ST_F32)
+        assert h.oibl_sqdist_topk_workspace_bytes(m, n, d, k, prec) == \
+            h.oibl_sqdist_topk_st_workspace_bytes(m, n, d, k, prec, ST_F32, ST_F32)
+    # bf16 mode: a bf16-stored operand is read in place (no operand copy), fp16 needs the bf16 copy
+    w32 = h.oibl_pairwise_st_workspace_bytes(m, n, d, BF16, ST_F32, ST_F32)
+    w16 = h.oibl_pairwise_st_workspace_bytes(m, n, d, BF16, ST_F16, ST_F16)
+    wbf = h.oibl_pairwise_st_workspace_bytes(m, n, d, BF16, ST_BF16, ST_BF16)
+    assert w32 == w16 and w32 - wbf >= (m + n) * d * 2 and wbf < 4 * (m + n) * 2
+    # fp32 mode: 16-bit rows are widened into the workspace, float32 rows are read in place
+    f32 = h.oibl_pairwise_st_workspace_bytes(m, n, d, F32, ST_F32, ST_F32)
+    f16 = h.oibl_pairwise_st_workspace_bytes(m, n, d, F32, ST_F16, ST_BF16)
+    assert f16 - f32 >= (m + n) * d * 4
+    # the fused top-k never reserves the [m][n] matrix, the exact path is bounded by 1 GiB tiles
+    assert h.oibl_sqdist_topk_st_workspace_bytes(m, n, d, k, BF16, ST_F32, ST_F32) < m * n * 4
+    # unknown codes / empty problems
+    assert h.oibl_pairwise_st_workspace_bytes(m, n, d, BF16, 3, ST_F32) == 0
+    assert h.oibl_sqdist_topk_st_workspace_bytes(m, n, d, k, BF16, ST_F32, -1) == 0
+    assert h.oibl_sqdist_topk_st_workspace_bytes(0, n, d, k, BF16, ST_F32, ST_F32) == 0
+    buf = ctypes.create_string_buffer(64)      # never dereferenced: validation fails first
+    ptr = ctypes.addressof(buf)
+    rc = h.oibl_sqdist_topk_st(ptr, 5, 1, ptr, 0, 1, 64, 1, 0, BF16, 0, ptr, ptr, None, ptr, 0, None)
+    assert rc == -1 and b"storage type" in h.oibl_last_error()
+    rc = h.oibl_pairwise_sqdist_st(ptr, 0, 1, ptr, 9, 1, 64, BF16, ptr, 1, ptr, 0, None)
+    assert rc == -1 and b"storage type" in h.oibl_last_error()
+    rc = h.oibl_resize_bilinear_nchw(None, 1, 3, 8, 8, None, 4, 4, None)
+    assert rc == -1 and b"null" in h.oibl_last_error()
+    rc = h.oibl_resize_bilinear_nchw(ptr, 1, 3, 8, 8, ptr, 0, 4, None)
+    assert rc == -1 and b"bad shape" in h.oibl_last_error()
+    rc = h.oibl_sum_l2_normalize(ptr, 0, 4, 64, ptr, None)
+    assert rc == -1 and b"bad shape" in h.oibl_last_error()
+    rc = h.oibl_cast_f32_to_f16(None, None, 8, None)
+    assert rc == -1
+
+
 def test_product_has_no_cpu_fallback():
     """Forward on a CPU tensor fails loudly instead of silently computing somewhere else."""
     import torch
