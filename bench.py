@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "fp32"])
     ap.add_argument("--eager", action="store_true", help="time eager launches instead of a hipGraph replay")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run NetVLAD+PCA of a step on the same stream instead of overlapping it with the next backbone")
@@ -172,7 +172,7 @@ def main():
     fl_conv11 = 2.0 * HEIGHT * WIDTH * 64 * 27 if args.precision == "bf16" else 0.0   # inside the stem
     fl_igemm = (igemm_flops_per_image() + fl_conv11) * args.batch
     achieved = fl_igemm / (span_ms * 1e-3) / 1e12
-    peak = BF16_MFMA_PEAK_TFLOPS if args.precision == "bf16" else F32_MFMA_PEAK_TFLOPS
+    peak = F32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else BF16_MFMA_PEAK_TFLOPS
     # HBM bytes per launch come from the committed PMC passes of this same command (they cannot be
     # collected inside the timed run): tools/prof_summary.py writes the digest next to the tables
     traffic, traffic_src = None, None

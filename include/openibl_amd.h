@@ -21,8 +21,13 @@
  *   - `precision` selects the arithmetic of the contraction:
  *       OIBL_BF16 : bf16 operands, fp32 accumulate on v_mfma_f32_32x32x16_bf16
  *       OIBL_F32  : exact fp32 on v_mfma_f32_32x32x2_f32 (parity mode)
+ *       OIBL_BF16X3 : "split bf16" — every operand travels as hi = bf16(v), lo = bf16(v - hi) and a
+ *                   product is hi.hi + hi.lo + lo.hi on the bf16 matrix cores, fp32 accumulate
+ *                   (~2^-17 relative per product: fp32-class descriptors at 3x the bf16 MFMA work
+ *                   instead of 16x).  Element = 4 bytes; a row of C elements (C % 32 == 0) is stored
+ *                   as C/32 groups of [32 x hi | 32 x lo] (128 bytes), see oibl_x3_split_rows.
  *     and with it the element type of activation / packed-weight buffers ("T" below:
- *     uint16 bf16 bits or float).
+ *     uint16 bf16 bits, float, or the 4-byte split pair).
  */
 #ifndef OPENIBL_AMD_H
 #define OPENIBL_AMD_H
@@ -42,6 +47,7 @@ extern "C" {
 
 #define OIBL_BF16 0
 #define OIBL_F32 1
+#define OIBL_BF16X3 2
 
 /* Storage type of a descriptor matrix handed to the *_st matching entry points. */
 #define OIBL_ST_F32 0
@@ -71,6 +77,11 @@ int oibl_cast_bf16_to_f32(const uint16_t* src, float* dst, size_t n, void* strea
  * (BASELINE.json configs[4], "fp16 descriptors"; no counterpart in the reference). */
 int oibl_cast_f32_to_f16(const float* src, uint16_t* dst, size_t n, void* stream);
 int oibl_cast_f16_to_f32(const uint16_t* src, float* dst, size_t n, void* stream);
+
+/* fp32 rows [rows][C] <-> OIBL_BF16X3 rows (C/32 groups of [32 hi | 32 lo] per row; C % 32 == 0):
+ * the activation / operand layout of the OIBL_BF16X3 kernels.  join returns hi + lo (exact). */
+int oibl_x3_split_rows(const float* src, void* dst, size_t rows, int C, void* stream);
+int oibl_x3_join_rows(const void* src, float* dst, size_t rows, int C, void* stream);
 
 /* ---- bilinear resize --------------------------------------------------------------- *
  * x [N][C][H][W] fp32 -> out [N][C][H2][W2] fp32 with the arithmetic of

@@ -62,11 +62,28 @@ def is_current() -> bool:
 
 
 def build(force: bool = False, verbose: bool = True) -> Path:
-    """Compile every HIP source for gfx950 and link libopenibl_amd.so.  Returns its path."""
+    """Compile every HIP source for gfx950 and link libopenibl_amd.so.  Returns its path.
+
+    One process per GPU means several ranks may arrive here at once: the build is serialised with
+    an exclusive file lock (the ranks that waited find the stamp current and return), and the
+    library is linked to a temporary name and renamed into place, so no rank ever maps a
+    half-written file."""
     if not force and is_current():
         return LIB_PATH
-    hipcc = _hipcc()
     BUILD_DIR.mkdir(parents=True, exist_ok=True)
+    import fcntl
+    with open(BUILD_DIR / "lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and is_current():
+                return LIB_PATH
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose: bool) -> Path:
+    hipcc = _hipcc()
     srcs = sources()
     objs = [BUILD_DIR / (s.stem + ".o") for s in srcs]
 
@@ -83,11 +100,14 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         list(ex.map(compile_one, zip(srcs, objs)))
 
+    tmp = LIB_PATH.with_name(LIB_PATH.name + f".tmp{os.getpid()}")
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fno-gpu-rdc",
-           *map(str, objs), "-o", str(LIB_PATH)]
+           *map(str, objs), "-o", str(tmp)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
+        tmp.unlink(missing_ok=True)
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    os.replace(tmp, LIB_PATH)
     (BUILD_DIR / "stamp").write_text(_digest())
     if verbose:
         print(f"[openibl_amd.build] linked {LIB_PATH}", file=sys.stderr)

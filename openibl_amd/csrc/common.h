@@ -3,6 +3,8 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -33,20 +35,22 @@ void set_error(const char* fmt, ...);
 
 // hipFuncSetAttribute applies to the CURRENT device: bit d of a per-kernel mask remembers that the
 // kernel's dynamic-LDS limit has been raised on device d (a process may drive several devices).
-static inline bool oibl_first_use_on_device(unsigned long long* mask) {
+// The bit is set only after the attribute call succeeded (a transient failure is retried by the
+// next launch) and atomically (two host threads may launch the same kernel).
+static inline unsigned long long oibl_device_bit() {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return true;
-  const unsigned long long bit = 1ull << (dev & 63);
-  if (*mask & bit) return false;
-  *mask |= bit;
-  return true;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  return 1ull << (dev & 63);
 }
 #define OIBL_SET_MAX_LDS(kern, lds)                                                              \
   do {                                                                                           \
-    static unsigned long long seen_ = 0;                                                         \
-    if (oibl_first_use_on_device(&seen_))                                                        \
+    static std::atomic<unsigned long long> seen_{0};                                             \
+    const unsigned long long bit_ = ::oibl::oibl_device_bit();                                   \
+    if (!(seen_.load(std::memory_order_relaxed) & bit_)) {                                       \
       OIBL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                    \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (lds)));    \
+      seen_.fetch_or(bit_, std::memory_order_relaxed);                                           \
+    }                                                                                            \
   } while (0)
 
 #define OIBL_LAUNCH_CHECK()                                                          \
@@ -102,6 +106,34 @@ __host__ __device__ static inline float bf16_bits_to_f32(uint16_t b) {
   } v;
   v.u = ((uint32_t)b) << 16;
   return v.f;
+}
+
+// bf16x3 ("split bf16", OIBL_BF16X3): a value v travels as the pair hi = bf16(v), lo = bf16(v - hi)
+// (v - hi is exact in fp32; hi + lo carries 16 significant bits), and a product is evaluated as
+// a_hi b_hi + a_hi b_lo + a_lo b_hi on the bf16 matrix cores with fp32 accumulation (the dropped
+// a_lo b_lo term is ~2^-18 relative).  Storage: rows of elements in groups of 32 —
+// [32 x hi | 32 x lo] = one 128-byte line per group, i.e. exactly one K-step of the GEMM cores, whose
+// four 16-byte k-chunks per lane half are then hi[0:16], hi[16:32], lo[0:16], lo[16:32].
+// The struct is only a tag (sizeof = 4 bytes per element); data is addressed through x3_off().
+struct bf16x3_t {
+  uint16_t hi, lo;
+};
+// byte offset of element c's hi half inside a row of x3 elements (its lo half sits 64 bytes further)
+__host__ __device__ static inline size_t x3_off(size_t c) { return (c >> 5) * 128 + (c & 31) * 2; }
+__device__ static inline void x3_split(float v, uint16_t& hi, uint16_t& lo) {
+  hi = f32_to_bf16_bits(v);
+  lo = f32_to_bf16_bits(v - bf16_bits_to_f32(hi));
+}
+__device__ static inline void x3_store(void* row, size_t c, float v) {
+  uint16_t hi, lo;
+  x3_split(v, hi, lo);
+  uint16_t* p = reinterpret_cast<uint16_t*>(static_cast<char*>(row) + x3_off(c));
+  p[0] = hi;
+  p[32] = lo;
+}
+__device__ static inline float x3_load(const void* row, size_t c) {
+  const uint16_t* p = reinterpret_cast<const uint16_t*>(static_cast<const char*>(row) + x3_off(c));
+  return bf16_bits_to_f32(p[0]) + bf16_bits_to_f32(p[32]);
 }
 
 template <typename T>

@@ -19,7 +19,29 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__
     const size_t t = i / cin;
     const int co = (int)(t % cout);
     const int tap = (int)(t / cout);
-    Elem<T>::store(packed + i, w[((size_t)co * cin + ci) * 9 + tap]);
+    const float v = w[((size_t)co * cin + ci) * 9 + tap];
+    if constexpr (std::is_same<T, bf16x3_t>::value)
+      x3_store(reinterpret_cast<char*>(packed) + (i - ci) * 4, ci, v);  // row (tap, co): cin x 4 bytes
+    else
+      Elem<T>::store(packed + i, v);
+  }
+}
+
+// fp32 rows <-> bf16x3 rows (groups of [32 hi | 32 lo]); C % 32 == 0
+__global__ void x3_split_rows_kernel(const float* __restrict__ src, char* __restrict__ dst, size_t n,
+                                     int C) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = i / C, c = i - row * C;
+    x3_store(dst + row * C * 4, c, src[i]);
+  }
+}
+__global__ void x3_join_rows_kernel(const char* __restrict__ src, float* __restrict__ dst, size_t n,
+                                    int C) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = i / C, c = i - row * C;
+    dst[i] = x3_load(src + row * C * 4, c);
   }
 }
 
@@ -112,19 +134,23 @@ __device__ static inline uint32_t relu_bf16x2(uint32_t packed) {
   return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, packed), z));
 }
 
+// X3 = bf16x3: weights and pixels are split into (hi, lo) fragments, 3 MFMAs per k-step, and the
+// output is written as groups of [32 hi | 32 lo] (256 B per pixel).
+template <bool X3>
 __global__ __launch_bounds__(256) void conv1_1_mfma_kernel(const float* __restrict__ x,
                                                            const float* __restrict__ w,
                                                            const float* __restrict__ bias,
-                                                           bf16_t* __restrict__ out, int N, int H,
+                                                           char* __restrict__ out, int N, int H,
                                                            int W, int tiles_per_row, long ntiles) {
+  constexpr int PX_BYTES = X3 ? 256 : 128, OPITCH = PX_BYTES + 16;
   __shared__ __attribute__((aligned(16))) float patch[9 * C11_PITCH + 4];
-  __shared__ __attribute__((aligned(16))) uint4 ostage[4][32 * 9];  // per wave: 32 px x 144 B
+  __shared__ __attribute__((aligned(16))) char ostage_all[4 * 32 * OPITCH];  // per wave: 32 px
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = lane >> 5, l31 = lane & 31;
 
   // A operand: weights.  wf[t][s] element e  <->  cout = 32 t + l31,  k = 16 s + 8 half + e
-  bf16x8_t wf[2][2];
+  bf16x8_t wf[2][2], wl[2][2];
   int koff[2][8];  // LDS float offset of input element k (relative to the pixel's column)
 #pragma unroll
   for (int s = 0; s < 2; ++s)
@@ -135,7 +161,10 @@ __global__ __launch_bounds__(256) void conv1_1_mfma_kernel(const float* __restri
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const float v = k < 27 ? w[(32 * t + l31) * 27 + k] : 0.f;
-        wf[t][s][e] = (short)f32_to_bf16_bits(v);
+        uint16_t hi, lo;
+        x3_split(v, hi, lo);
+        wf[t][s][e] = (short)hi;
+        wl[t][s][e] = (short)lo;
       }
     }
   float bb[2][16];
@@ -162,13 +191,16 @@ __global__ __launch_bounds__(256) void conv1_1_mfma_kernel(const float* __restri
     __syncthreads();
 
     const int px = wave * 32 + l31;  // pixel column inside the tile
-    bf16x8_t xf[2];
+    bf16x8_t xf[2], xl[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float v = koff[s][e] >= 0 ? patch[koff[s][e] + px] : 0.f;
-        xf[s][e] = (short)f32_to_bf16_bits(v);
+        uint16_t hi, lo;
+        x3_split(v, hi, lo);
+        xf[s][e] = (short)hi;
+        xl[s][e] = (short)lo;
       }
     f32x16_t acc[2];
 #pragma unroll
@@ -176,28 +208,43 @@ __global__ __launch_bounds__(256) void conv1_1_mfma_kernel(const float* __restri
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = bb[t][r];
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
+      for (int s = 0; s < 2; ++s) {
+        if constexpr (X3) {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[t][s], xf[s], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][s], xl[s], acc[t], 0, 0, 0);
+        }
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][s], xf[s], acc[t], 0, 0, 0);
+      }
     }
     // D[row = cout][col = pixel]: registers 4g..4g+3 = couts 32t + 8g + 4*half + 0..3 of pixel l31
-    char* ost = reinterpret_cast<char*>(&ostage[wave][0]);
+    char* ost = ostage_all + wave * 32 * OPITCH;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        uint2 v;
-        v.x = relu_bf16x2(pack_bf16x2(acc[t][4 * g], acc[t][4 * g + 1]));
-        v.y = relu_bf16x2(pack_bf16x2(acc[t][4 * g + 2], acc[t][4 * g + 3]));
-        *reinterpret_cast<uint2*>(ost + l31 * 144 + (32 * t + 8 * g + 4 * half) * 2) = v;
+        if constexpr (X3) {
+          uint2 hi, lo;
+          ring_split4(fmaxf(acc[t][4 * g], 0.f), fmaxf(acc[t][4 * g + 1], 0.f),
+                      fmaxf(acc[t][4 * g + 2], 0.f), fmaxf(acc[t][4 * g + 3], 0.f), hi, lo);
+          char* q = ost + l31 * OPITCH + t * 128 + (8 * g + 4 * half) * 2;
+          *reinterpret_cast<uint2*>(q) = hi;
+          *reinterpret_cast<uint2*>(q + 64) = lo;
+        } else {
+          uint2 v;
+          v.x = relu_bf16x2(pack_bf16x2(acc[t][4 * g], acc[t][4 * g + 1]));
+          v.y = relu_bf16x2(pack_bf16x2(acc[t][4 * g + 2], acc[t][4 * g + 3]));
+          *reinterpret_cast<uint2*>(ost + l31 * OPITCH + (32 * t + 8 * g + 4 * half) * 2) = v;
+        }
       }
     __builtin_amdgcn_wave_barrier();  // same-wave exchange through LDS: DS ops retire in order
-    bf16_t* orow = out + (((size_t)n * H + y) * W + x0 + wave * 32) * 64;
+    char* orow = out + (((size_t)n * H + y) * W + x0 + wave * 32) * PX_BYTES;
+    constexpr int PARTS = PX_BYTES / 16;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int idx = it * 64 + lane, p = idx >> 3, part = idx & 7;
-      const uint4 v = *reinterpret_cast<const uint4*>(ost + p * 144 + part * 16);
+    for (int it = 0; it < 32 * PARTS / 64; ++it) {
+      const int idx = it * 64 + lane, p = idx / PARTS, part = idx % PARTS;
+      const uint4 v = *reinterpret_cast<const uint4*>(ost + p * OPITCH + part * 16);
       if (x0 + wave * 32 + p < W)
-        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(orow) + (size_t)p * 128 + part * 16) = v;
+        *reinterpret_cast<uint4*>(orow + (size_t)p * PX_BYTES + part * 16) = v;
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -226,7 +273,21 @@ struct ConvParams {
   int relu;
   int ablate;  // timing experiments only (wrong results): 1 = A loads only at tap 0, 2 = B loads
                // only at the first step, 3 = both
+  int out_f32;  // bf16x3 only: the output is written as plain fp32 NHWC (the layer feeding the head)
 };
+
+// one output element into the staged tile row (row-major [BN] of T; bf16x3: (hi, lo) groups or fp32)
+template <typename T>
+__device__ static inline void conv_stage_store(char* row, int col, float v, int out_f32) {
+  if constexpr (std::is_same<T, bf16x3_t>::value) {
+    if (out_f32)
+      reinterpret_cast<float*>(row)[col] = v;
+    else
+      x3_store(row, col, v);
+  } else {
+    Elem<T>::store(reinterpret_cast<T*>(row) + col, v);
+  }
+}
 
 template <typename Cfg, bool POOL>
 struct ConvALoader {
@@ -379,7 +440,7 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void conv3x3_igemm_kernel(ConvParams
                           fmaxf(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]));
           if (p.relu) v = fmaxf(v, 0.f);
           const int row = (c.wm * TM + i) * 8 + 2 * g + (c.lane >> 5);
-          Elem<T>::store(reinterpret_cast<T*>(smem + row * PITCH) + col, v);
+          conv_stage_store<T>(smem + row * PITCH, col, v, p.out_f32);
         }
       } else {
 #pragma unroll
@@ -387,7 +448,7 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void conv3x3_igemm_kernel(ConvParams
           float v = acc[i][j][r];
           if (p.relu) v = fmaxf(v, 0.f);
           const int row = (c.wm * TM + i) * 32 + acc_row(r, c.lane);
-          Elem<T>::store(reinterpret_cast<T*>(smem + row * PITCH) + col, v);
+          conv_stage_store<T>(smem + row * PITCH, col, v, p.out_f32);
         }
       }
     }
@@ -436,7 +497,7 @@ static int g_ring_ablate = 0;                     // test hook: see RingParams::
 
 // ring-schedule kernel (conv_ring.h): bf16, Cin % 64 == 0; WM = 2: 256 x 256 tile (Cout % 256 == 0),
 // WM = 4: 512 x 128 tile (Cout % 128 == 0)
-template <int WM, bool POOL, bool ODD>
+template <int WM, bool POOL, bool ODD, bool X3 = false>
 static int launch_conv_ring_impl(const ConvParams& p, hipStream_t st) {
   using G = RingGeo<WM>;
   RingParams q;
@@ -444,8 +505,9 @@ static int launch_conv_ring_impl(const ConvParams& p, hipStream_t st) {
   q.w = p.w;
   q.bias = p.bias;
   q.out = p.out;
-  q.in_bytes = (unsigned)((size_t)p.N * p.H * p.W * p.cin * 2);
-  q.w_bytes = (unsigned)((size_t)9 * p.cout * p.cin * 2);
+  q.in_bytes = (unsigned)((size_t)p.N * p.H * p.W * p.cin * (X3 ? 4 : 2));
+  q.w_bytes = (unsigned)((size_t)9 * p.cout * p.cin * (X3 ? 4 : 2));
+  q.out_f32 = X3 ? p.out_f32 : 0;
   q.N = p.N;
   q.H = p.H;
   q.W = p.W;
@@ -464,26 +526,27 @@ static int launch_conv_ring_impl(const ConvParams& p, hipStream_t st) {
   }
   const long tiles_m = (p.m_total + G::BM - 1) / G::BM;
   const long grid = tiles_m * q.tiles_n;
-  constexpr int lds = ring_lds_bytes<WM, POOL>();
-  auto kern = conv3x3_ring_kernel<WM, POOL, ODD>;
+  constexpr int lds = ring_lds_bytes<WM, POOL, X3>();
+  auto kern = conv3x3_ring_kernel<WM, POOL, ODD, X3>;
   OIBL_SET_MAX_LDS(kern, lds);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, q);
   OIBL_LAUNCH_CHECK();
   return OIBL_OK;
 }
 
-template <int WM, bool POOL>
+template <int WM, bool POOL, bool X3 = false>
 static int launch_conv_ring(const ConvParams& p, hipStream_t st) {
-  // an odd number of K-tiles happens only for Cin = 64, which only the 512 x 128 variant serves
-  if constexpr (WM == 4) {
+  // an odd number of K-tiles happens only for Cin = 64 in bf16 (bf16x3 has twice the K-tiles),
+  // which only the 512 x 128 variant serves
+  if constexpr (WM == 4 && !X3) {
     if ((9 * (p.cin / 64)) & 1) return launch_conv_ring_impl<WM, POOL, true>(p, st);
   }
-  return launch_conv_ring_impl<WM, POOL, false>(p, st);
+  return launch_conv_ring_impl<WM, POOL, false, X3>(p, st);
 }
 
-// 0 = not eligible, else the wave-row count of the instantiation to use
-static int ring_variant(const ConvParams& p) {
-  if (p.cin % 64 != 0 || (size_t)p.N * p.H * p.W * p.cin * 2 >= (size_t)0xE0000000u ||
+// 0 = not eligible, else the wave-row count of the instantiation to use (es = bytes per element)
+static int ring_variant(const ConvParams& p, int es = 2) {
+  if (p.cin % 64 != 0 || (size_t)p.N * p.H * p.W * p.cin * es >= (size_t)0xE0000000u ||
       p.m_total >= 0x7fffff00L)
     return 0;
   if (p.cout % 256 == 0 && p.cin % 128 == 0) return 2;
@@ -508,7 +571,27 @@ static int launch_conv(const ConvParams& p, int pool, hipStream_t st) {
   using C128x64 = GemmCfg<T, 2, 2, 2, 1>;
 #define OIBL_CONV_DISPATCH(CFG) \
   return pool ? launch_conv_cfg<CFG, true>(p, st) : launch_conv_cfg<CFG, false>(p, st)
-  if constexpr (sizeof(T) == 2) {
+  if constexpr (std::is_same<T, bf16x3_t>::value) {
+    // ring kernels as in bf16 (pooled layers never write fp32); generic tiles whose staged output
+    // (4 bytes per element) fits next to nothing else in LDS: 256 x {128, 64}, 128 x {128, 64}
+    using C256x128 = GemmCfg<T, 4, 2, 2, 2>;
+    using C256x64 = GemmCfg<T, 4, 2, 2, 1>;
+    const int rv = (g_regstage || p.ablate || (pool && p.out_f32)) ? 0 : ring_variant(p, 4);
+    const long t256 = (p.m_total + 255) / 256;
+    const long ring_tiles = rv == 2 ? t256 * (p.cout / 256) : ((p.m_total + 511) / 512) * (p.cout / 128);
+    int mode = g_conv_tile;
+    if (rv && (mode == 4 || (mode == 0 && ring_tiles >= g_ring_min_tiles))) {
+      if (rv == 2)
+        return pool ? launch_conv_ring<2, true, true>(p, st) : launch_conv_ring<2, false, true>(p, st);
+      return pool ? launch_conv_ring<4, true, true>(p, st) : launch_conv_ring<4, false, true>(p, st);
+    }
+    if (mode == 4 || mode == 3) mode = 0;
+    if (mode == 0) mode = t256 * (p.cout / (p.cout % 128 == 0 ? 128 : 64)) >= 512 ? 2 : 1;
+    if (mode >= 2) {
+      if (p.cout % 128 == 0) { OIBL_CONV_DISPATCH(C256x128); }
+      OIBL_CONV_DISPATCH(C256x64);
+    }
+  } else if constexpr (sizeof(T) == 2) {
     using C256x256 = GemmCfg<T, 2, 4, 4, 2>;
     using C256x128 = GemmCfg<T, 4, 2, 2, 2>;
     using C256x64 = GemmCfg<T, 4, 2, 2, 1>;
@@ -1344,12 +1427,16 @@ static const VggLayer kVgg[OIBL_VGG16_NUM_CONV] = {
     {256, 256, 1, 0}, {256, 256, 1, 1}, {256, 512, 1, 0}, {512, 512, 1, 0}, {512, 512, 1, 1},
     {512, 512, 1, 0}, {512, 512, 1, 0}, {512, 512, 0, 0}};
 
+static bool precision_ok(int precision) {
+  return precision == OIBL_BF16 || precision == OIBL_F32 || precision == OIBL_BF16X3;
+}
+
+// out_f32 (bf16x3 only): write the output as plain fp32 NHWC
 static int conv3x3_impl(const void* in, int N, int H, int W, int cin, const void* packed_w,
                         const float* bias, int cout, int relu, int pool, int precision, void* out,
-                        hipStream_t st) {
+                        hipStream_t st, int out_f32 = 0) {
   OIBL_REQUIRE(in && packed_w && bias && out, "conv3x3: null pointer");
-  OIBL_REQUIRE(precision == OIBL_BF16 || precision == OIBL_F32, "conv3x3: bad precision %d",
-               precision);
+  OIBL_REQUIRE(precision_ok(precision), "conv3x3: bad precision %d", precision);
   const int bk = precision == OIBL_BF16 ? 64 : 32;
   OIBL_REQUIRE(N > 0 && H > 0 && W > 0, "conv3x3: bad shape N=%d H=%d W=%d", N, H, W);
   OIBL_REQUIRE(cin % bk == 0 && cout % 64 == 0, "conv3x3: unsupported channels cin=%d cout=%d", cin,
@@ -1377,6 +1464,7 @@ static int conv3x3_impl(const void* in, int N, int H, int W, int cin, const void
   p.cout = cout;
   p.relu = relu;
   p.ablate = g_conv_ablate;
+  p.out_f32 = precision == OIBL_BF16X3 ? out_f32 : 0;
   p.tiles_n = 0;
   if (pool) {
     p.out_rows = (long)N * (H / 2) * (W / 2);
@@ -1385,6 +1473,7 @@ static int conv3x3_impl(const void* in, int N, int H, int W, int cin, const void
     p.out_rows = (long)N * H * W;
     p.m_total = p.out_rows;
   }
+  if (precision == OIBL_BF16X3) return launch_conv<bf16x3_t>(p, pool, st);
   return precision == OIBL_BF16 ? launch_conv<bf16_t>(p, pool, st) : launch_conv<float>(p, pool, st);
 }
 
@@ -1449,14 +1538,17 @@ int oibl_pack_conv3x3_weights(const float* w_oihw, int cout, int cin, int precis
                               void* stream) {
   OIBL_REQUIRE(w_oihw && packed, "pack_conv3x3_weights: null pointer");
   OIBL_REQUIRE(cout > 0 && cin > 0, "pack_conv3x3_weights: bad shape");
-  OIBL_REQUIRE(precision == OIBL_BF16 || precision == OIBL_F32,
-               "pack_conv3x3_weights: bad precision %d", precision);
+  OIBL_REQUIRE(precision_ok(precision), "pack_conv3x3_weights: bad precision %d", precision);
+  OIBL_REQUIRE(precision != OIBL_BF16X3 || cin % 32 == 0, "pack_conv3x3_weights: bf16x3 needs Cin %% 32 == 0");
   const size_t total = (size_t)9 * cout * cin;
   unsigned blocks = (unsigned)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
   if (precision == OIBL_BF16)
     hipLaunchKernelGGL(pack_conv3x3_kernel<bf16_t>, dim3(blocks), dim3(256), 0,
                        (hipStream_t)stream, w_oihw, (bf16_t*)packed, cout, cin);
+  else if (precision == OIBL_BF16X3)
+    hipLaunchKernelGGL(pack_conv3x3_kernel<bf16x3_t>, dim3(blocks), dim3(256), 0,
+                       (hipStream_t)stream, w_oihw, (bf16x3_t*)packed, cout, cin);
   else
     hipLaunchKernelGGL(pack_conv3x3_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        w_oihw, (float*)packed, cout, cin);
@@ -1475,17 +1567,20 @@ int oibl_conv1_1_nchw(const float* x_nchw, int N, int H, int W, const float* w_o
                       const float* bias, int precision, void* out, void* stream) {
   OIBL_REQUIRE(x_nchw && w_oihw && bias && out, "conv1_1: null pointer");
   OIBL_REQUIRE(N > 0 && H > 0 && W > 0, "conv1_1: bad shape N=%d H=%d W=%d", N, H, W);
-  OIBL_REQUIRE(precision == OIBL_BF16 || precision == OIBL_F32, "conv1_1: bad precision %d",
-               precision);
+  OIBL_REQUIRE(precision_ok(precision), "conv1_1: bad precision %d", precision);
   const long nstrips = (long)N * H * ((W + 7) / 8);
   const long grid = (nstrips + 3) / 4;
   OIBL_REQUIRE(grid <= 0x7fffffffL, "conv1_1: grid too large");
-  if (precision == OIBL_BF16 && !g_conv11_valu) {
+  if (precision == OIBL_BF16X3 || (precision == OIBL_BF16 && !g_conv11_valu)) {
     const int tiles_per_row = (W + C11_TW - 1) / C11_TW;
     const long ntiles = (long)N * H * tiles_per_row;
     const unsigned blocks = (unsigned)(ntiles < 4096 ? ntiles : 4096);
-    hipLaunchKernelGGL(conv1_1_mfma_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x_nchw,
-                       w_oihw, bias, (bf16_t*)out, N, H, W, tiles_per_row, ntiles);
+    if (precision == OIBL_BF16X3)
+      hipLaunchKernelGGL(conv1_1_mfma_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                         x_nchw, w_oihw, bias, (char*)out, N, H, W, tiles_per_row, ntiles);
+    else
+      hipLaunchKernelGGL(conv1_1_mfma_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                         x_nchw, w_oihw, bias, (char*)out, N, H, W, tiles_per_row, ntiles);
   } else if (precision == OIBL_BF16)
     hipLaunchKernelGGL(conv1_1_kernel<bf16_t>, dim3((unsigned)grid), dim3(256), 0,
                        (hipStream_t)stream, x_nchw, w_oihw, bias, (bf16_t*)out, N, H, W);
@@ -1588,8 +1683,7 @@ static int vgg_forward_impl(const void* x, int u8, const float* mean3, const flo
                             void* ev_igemm_begin, void* ev_igemm_end) {
   OIBL_REQUIRE(x && packed_w_host && bias_host && feat && ws, "vgg16: null pointer");
   OIBL_REQUIRE(!u8 || (mean3 && std3), "vgg16: uint8 input needs the mean / std constants");
-  OIBL_REQUIRE(precision == OIBL_BF16 || precision == OIBL_F32, "vgg16: bad precision %d",
-               precision);
+  OIBL_REQUIRE(precision_ok(precision), "vgg16: bad precision %d", precision);
   OIBL_REQUIRE(N > 0 && H >= 16 && W >= 16, "vgg16: bad shape N=%d H=%d W=%d", N, H, W);
   OIBL_REQUIRE((uintptr_t)ws % 256 == 0, "vgg16: workspace must be 256-byte aligned");
   const size_t base_need = oibl_vgg16_workspace_bytes(N, H, W, precision);
@@ -1640,8 +1734,10 @@ static int vgg_forward_impl(const void* x, int u8, const float* mean3, const flo
   }
   for (int l = l0; l < OIBL_VGG16_NUM_CONV; ++l) {
     void* dst = (l == OIBL_VGG16_NUM_CONV - 1) ? feat : (l % 2 == 0 ? (void*)bufA : (void*)bufB);
+    // bf16x3: the last layer hands the head a plain fp32 map
     rc = conv3x3_impl(cur, N, h, w, kVgg[l].cin, packed_w_host[l], bias_host[l], kVgg[l].cout,
-                      kVgg[l].relu, kVgg[l].pool, precision, dst, st);
+                      kVgg[l].relu, kVgg[l].pool, precision, dst, st,
+                      l == OIBL_VGG16_NUM_CONV - 1);
     if (rc) return rc;
     if (kVgg[l].pool) {
       h /= 2;
@@ -1673,6 +1769,32 @@ int oibl_vgg16_conv5_forward_u8(const uint8_t* x_nhwc, int N, int H, int W, cons
                                 void* ev_igemm_end) {
   return vgg_forward_impl(x_nhwc, 1, mean3_host, std3_host, N, H, W, packed_w_host, bias_host,
                           precision, feat, ws, ws_bytes, stream, ev_igemm_begin, ev_igemm_end);
+}
+
+int oibl_x3_split_rows(const float* src, void* dst, size_t rows, int C, void* stream) {
+  OIBL_REQUIRE(src && dst, "x3_split_rows: null pointer");
+  OIBL_REQUIRE(C > 0 && C % 32 == 0, "x3_split_rows: C=%d must be a positive multiple of 32", C);
+  if (rows == 0) return OIBL_OK;
+  const size_t n = rows * (size_t)C;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(x3_split_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src,
+                     (char*)dst, n, C);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
+
+int oibl_x3_join_rows(const void* src, float* dst, size_t rows, int C, void* stream) {
+  OIBL_REQUIRE(src && dst, "x3_join_rows: null pointer");
+  OIBL_REQUIRE(C > 0 && C % 32 == 0, "x3_join_rows: C=%d must be a positive multiple of 32", C);
+  if (rows == 0) return OIBL_OK;
+  const size_t n = rows * (size_t)C;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(x3_join_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const char*)src, dst, n, C);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
 }
 
 }  // extern "C"

@@ -9,6 +9,11 @@
 // for the whole kernel (weights) or for one tap (pixels); the per-K-tile part is a scalar offset.
 // A tap that leaves the image gets an offset beyond num_records: the buffer unit returns zeros —
 // zero padding without a padded copy, a zero line or any per-tile select.
+//
+// X3 = bf16x3 activations and weights (common.h): a pixel's channels are groups of [32 hi | 32 lo],
+// a K-tile is one such 128-byte group (32 real channels), so the loaders only see 4-byte elements;
+// the main loop runs 12 MFMAs per phase and the epilogue splits every output into its (hi, lo) pair
+// again — or, for the layer that feeds the fp32 head, stores plain fp32 (RingParams::out_f32).
 #pragma once
 
 #include "ring_core.h"
@@ -33,6 +38,7 @@ struct RingParams {
   unsigned hw_mul, hw_sh, w_mul, w_sh;
   int ablate;  // timing experiments only (WRONG results): 1 = pixel loads of taps != 0 all hit one
                // line, 2 = weight loads after the first K-tile all hit one line, 3 = both
+  int out_f32;  // X3, !POOL only: write plain fp32 NHWC instead of the (hi, lo) groups
 };
 
 // mul, sh with floor(m / d) == (m * mul) >> sh for every m < 2^31 (d >= 1):  sh = 31 + ceil(log2 d),
@@ -47,18 +53,19 @@ __device__ static inline unsigned ring_div_u31(unsigned m, unsigned mul, unsigne
   return (unsigned)(((unsigned long long)m * mul) >> sh);
 }
 
-template <int WM, bool POOL>
+// epilogue staging: the output tile (X3 without pooling: one half of its rows at a time)
+template <int WM, bool POOL, bool X3 = false>
 constexpr int ring_lds_bytes() {
   using G = RingGeo<WM>;
-  constexpr int rows = POOL ? G::BM / 4 : G::BM;
-  constexpr int epi = rows * (G::BN * 2 + 16);
+  constexpr int rows = POOL ? G::BM / 4 : (X3 ? G::BM / 2 : G::BM);
+  constexpr int epi = rows * (G::BN * (X3 ? 4 : 2) + 16);
   return epi > G::MAIN_LDS ? epi : G::MAIN_LDS;
 }
 
 // A operand: im2col rows of the NHWC input.  Per lane and LDS-DMA instruction: the byte offset of
 // the pixel (centre tap) and a 9-bit tap-validity mask; per tap: the offsets actually used
 // (RG_OOB when the tap leaves the image); per K-tile: a scalar channel-chunk offset.
-template <int NA, bool POOL>
+template <int NA, bool POOL, bool X3 = false>
 struct ConvRingALoader {
   __amdgpu_buffer_rsrc_t rsrc;
   unsigned base[2 * NA], mask[2 * NA], cur[2 * NA];
@@ -66,8 +73,8 @@ struct ConvRingALoader {
   int tap, cc, cchunks, W, pix_bytes, ablate;
   __device__ inline void init(const RingParams& p, int m0, const int (&tile_row)[2 * NA], int piece) {
     rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
-    pix_bytes = p.cin * 2;
-    cchunks = p.cin >> 6;
+    pix_bytes = p.cin * (X3 ? 4 : 2);
+    cchunks = p.cin >> (X3 ? 5 : 6);
     W = p.W;
     tap = 0;
     cc = -1;
@@ -129,7 +136,7 @@ struct ConvRingALoader {
 };
 
 // B operand: packed weights [tap][Cout][Cin]; row = output channel.
-template <int NB>
+template <int NB, bool X3 = false>
 struct ConvRingBLoader {
   __amdgpu_buffer_rsrc_t rsrc;
   unsigned off[2 * NB];
@@ -137,8 +144,8 @@ struct ConvRingBLoader {
   int tap, cc, cchunks, ablate;
   __device__ inline void init(const RingParams& p, int n0, const int (&tile_row)[2 * NB], int piece) {
     rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
-    const unsigned pix_bytes = (unsigned)p.cin * 2u;
-    cchunks = p.cin >> 6;
+    const unsigned pix_bytes = (unsigned)p.cin * (X3 ? 4u : 2u);
+    cchunks = p.cin >> (X3 ? 5 : 6);
     tap_stride = (unsigned)p.cout * pix_bytes;
     tap = 0;
     cc = -1;
@@ -168,7 +175,21 @@ struct ConvRingBLoader {
   }
 };
 
-template <int WM, bool POOL, bool ODD>
+// (hi, lo) pairs of four fp32 values as two dwords each: hi = bf16(v), lo = bf16(v - hi)
+__device__ static inline void ring_split4(float a0, float a1, float a2, float a3, uint2& hi, uint2& lo) {
+  typedef __attribute__((ext_vector_type(2))) float f2;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+  hi.x = __builtin_bit_cast(uint32_t, __builtin_convertvector((f2){a0, a1}, bf2));
+  hi.y = __builtin_bit_cast(uint32_t, __builtin_convertvector((f2){a2, a3}, bf2));
+  const float r0 = a0 - __builtin_bit_cast(float, hi.x << 16);
+  const float r1 = a1 - __builtin_bit_cast(float, hi.x & 0xffff0000u);
+  const float r2 = a2 - __builtin_bit_cast(float, hi.y << 16);
+  const float r3 = a3 - __builtin_bit_cast(float, hi.y & 0xffff0000u);
+  lo.x = __builtin_bit_cast(uint32_t, __builtin_convertvector((f2){r0, r1}, bf2));
+  lo.y = __builtin_bit_cast(uint32_t, __builtin_convertvector((f2){r2, r3}, bf2));
+}
+
+template <int WM, bool POOL, bool ODD, bool X3 = false>
 __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
   using G = RingGeo<WM>;
   constexpr int NA = G::NA, NB = G::NB;
@@ -181,7 +202,7 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
   const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
   const int m0 = tm * G::BM, n0 = tn * G::BN;
-  const int nsteps = 9 * (p.cin >> 6);
+  const int nsteps = 9 * (p.cin >> (X3 ? 5 : 6));
 
   const int piece = ring_piece(wave, lane);
   int rows_a[2 * NA], rows_b[2 * NB];
@@ -192,8 +213,8 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) rows_b[NB * h + i] = ring_b_row<WM>(wave, lane, h, i);
   }
-  ConvRingALoader<NA, POOL> la;
-  ConvRingBLoader<NB> lb;
+  ConvRingALoader<NA, POOL, X3> la;
+  ConvRingBLoader<NB, X3> lb;
   la.init(p, m0, rows_a, piece);
   lb.init(p, n0, rows_b, piece);
 
@@ -230,7 +251,7 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
   }
 
   const unsigned long long t_loop = prof ? __builtin_amdgcn_s_memtime() : 0;
-  ring_mainloop<WM, ODD, !POOL>(acc, smem, wave, lane, la, lb, nsteps);
+  ring_mainloop<WM, ODD, !POOL, X3>(acc, smem, wave, lane, la, lb, nsteps);
   // (the main loop ends on a workgroup barrier: the staging LDS is free for the epilogue)
   const unsigned long long t_epi = prof ? __builtin_amdgcn_s_memtime() : 0;
 
@@ -240,72 +261,112 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
   //             window is one register quad -> three v_max, 2-byte LDS writes of the pooled values.
   //      !POOL: accumulators transposed (lane = pixel, register quad = 4 consecutive channels):
   //             one packed 8-byte LDS write per quad, a quarter of the write instructions.
-  constexpr int PITCH = G::BN * 2 + 16;
-  constexpr int OUT_ROWS = POOL ? G::BM / 4 : G::BM;
-  if constexpr (POOL) {
-    const float floor_v = p.relu ? 0.f : -INFINITY;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = wn * 64 + j * 32 + (lane & 31);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float v = fmaxf(fmaxf(fmaxf(acc[i][j][4 * g], acc[i][j][4 * g + 1]),
-                                      fmaxf(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3])), floor_v);
-          const int row = (wm * 4 + i) * 8 + 2 * g + (lane >> 5);
-          *reinterpret_cast<uint16_t*>(smem + row * PITCH + col * 2) = f32_to_bf16_bits(v);
-        }
-    }
-  } else {
-    typedef __attribute__((ext_vector_type(2))) float f2;
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
-    typedef __attribute__((ext_vector_type(2))) short s2;
-    // ReLU on the packed pair: as signed 16-bit integers every negative bf16 is < 0 (see conv.hip)
-    const short fl = p.relu ? (short)0 : (short)-32768;
-    const s2 floor2 = {fl, fl};
-    const int half = lane >> 5;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int c0 = wn * 64 + j * 32 + 8 * g + 4 * half;  // first of this quad's 4 channels
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const bf2 lo = __builtin_convertvector((f2){acc[i][j][4 * g], acc[i][j][4 * g + 1]}, bf2);
-          const bf2 hi = __builtin_convertvector((f2){acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]}, bf2);
-          uint2 pk;
-          pk.x = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s2, lo), floor2));
-          pk.y = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s2, hi), floor2));
-          const int row = wm * 128 + i * 32 + (lane & 31);
-          *reinterpret_cast<uint2*>(smem + row * PITCH + c0 * 2) = pk;
-        }
-      }
-  }
-  __syncthreads();
-  const unsigned long long t_copy = prof ? __builtin_amdgcn_s_memtime() : 0;
-  constexpr int CPR = G::BN * 2 / 16;  // 16-byte chunks per output row
+  //      X3   : an output element is 4 bytes — the (hi, lo) pair at x3_off(channel) / + 64, or the
+  //             fp32 value when out_f32 is set; without pooling the tile is staged in two passes of
+  //             BM / 2 rows (accumulator row tiles {0, 1}, then {2, 3} of every wave).
+  constexpr int EB = X3 ? 4 : 2;
+  constexpr int PITCH = G::BN * EB + 16;
+  constexpr int PASSES = (X3 && !POOL) ? 2 : 1;
+  constexpr int OUT_ROWS = (POOL ? G::BM / 4 : G::BM) / PASSES;  // rows staged per pass
+  constexpr int CPR = G::BN * EB / 16;                           // 16-byte chunks per output row
   constexpr int ITERS = OUT_ROWS * CPR / 512, BATCH = ITERS < 8 ? ITERS : 8;
   static_assert(OUT_ROWS * CPR % 512 == 0 && ITERS % BATCH == 0, "copy-out shape");
   const long row0 = POOL ? (m0 >> 2) : m0;
-  char* obase = reinterpret_cast<char*>(p.out) + (long)n0 * 2;
-  const long orow_bytes = (long)p.cout * 2;
-  // LDS reads of a batch first, then its stores: the loads' latency is paid once per batch
+  char* obase = reinterpret_cast<char*>(p.out) + (long)n0 * EB;
+  const long orow_bytes = (long)p.cout * EB;
+  unsigned long long t_copy = 0;
 #pragma unroll
-  for (int it0 = 0; it0 < ITERS; it0 += BATCH) {
-    uint4 v[BATCH];
+  for (int pass = 0; pass < PASSES; ++pass) {
+    if constexpr (POOL) {
+      const float floor_v = p.relu ? 0.f : -INFINITY;
 #pragma unroll
-    for (int u = 0; u < BATCH; ++u) {
-      const int idx = (it0 + u) * 512 + (int)threadIdx.x;
-      v[u] = *reinterpret_cast<const uint4*>(smem + (idx / CPR) * PITCH + (idx % CPR) * 16);
+      for (int j = 0; j < 2; ++j) {
+        const int col = wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float v = fmaxf(fmaxf(fmaxf(acc[i][j][4 * g], acc[i][j][4 * g + 1]),
+                                        fmaxf(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3])), floor_v);
+            const int row = (wm * 4 + i) * 8 + 2 * g + (lane >> 5);
+            if constexpr (X3)
+              x3_store(smem + row * PITCH, col, v);
+            else
+              *reinterpret_cast<uint16_t*>(smem + row * PITCH + col * 2) = f32_to_bf16_bits(v);
+          }
+      }
+    } else if constexpr (X3) {
+      const float floor_v = p.relu ? 0.f : -INFINITY;
+      const int half = lane >> 5;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c0 = wn * 64 + j * 32 + 8 * g + 4 * half;  // first of this quad's 4 channels
+#pragma unroll
+          for (int i2 = 0; i2 < 2; ++i2) {
+            const int i = 2 * pass + i2;
+            const float a0 = fmaxf(acc[i][j][4 * g], floor_v), a1 = fmaxf(acc[i][j][4 * g + 1], floor_v);
+            const float a2 = fmaxf(acc[i][j][4 * g + 2], floor_v), a3 = fmaxf(acc[i][j][4 * g + 3], floor_v);
+            char* rowp = smem + (wm * 64 + i2 * 32 + (lane & 31)) * PITCH;
+            if (p.out_f32) {
+              *reinterpret_cast<float4*>(rowp + c0 * 4) = make_float4(a0, a1, a2, a3);
+            } else {
+              uint2 hi, lo;
+              ring_split4(a0, a1, a2, a3, hi, lo);
+              char* q = rowp + (c0 >> 5) * 128 + (c0 & 31) * 2;
+              *reinterpret_cast<uint2*>(q) = hi;
+              *reinterpret_cast<uint2*>(q + 64) = lo;
+            }
+          }
+        }
+    } else {
+      typedef __attribute__((ext_vector_type(2))) float f2;
+      typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+      typedef __attribute__((ext_vector_type(2))) short s2;
+      // ReLU on the packed pair: as signed 16-bit integers every negative bf16 is < 0 (see conv.hip)
+      const short fl = p.relu ? (short)0 : (short)-32768;
+      const s2 floor2 = {fl, fl};
+      const int half = lane >> 5;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c0 = wn * 64 + j * 32 + 8 * g + 4 * half;  // first of this quad's 4 channels
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const bf2 lo = __builtin_convertvector((f2){acc[i][j][4 * g], acc[i][j][4 * g + 1]}, bf2);
+            const bf2 hi = __builtin_convertvector((f2){acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]}, bf2);
+            uint2 pk;
+            pk.x = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s2, lo), floor2));
+            pk.y = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s2, hi), floor2));
+            const int row = wm * 128 + i * 32 + (lane & 31);
+            *reinterpret_cast<uint2*>(smem + row * PITCH + c0 * 2) = pk;
+          }
+        }
     }
+    __syncthreads();
+    if (pass == 0 && prof) t_copy = __builtin_amdgcn_s_memtime();
+    // LDS reads of a batch first, then its stores: the loads' latency is paid once per batch
 #pragma unroll
-    for (int u = 0; u < BATCH; ++u) {
-      const int idx = (it0 + u) * 512 + (int)threadIdx.x;
-      const long grow = row0 + idx / CPR;
-      if (grow < p.out_rows)
-        *reinterpret_cast<uint4*>(obase + grow * orow_bytes + (idx % CPR) * 16) = v[u];
+    for (int it0 = 0; it0 < ITERS; it0 += BATCH) {
+      uint4 v[BATCH];
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const int idx = (it0 + u) * 512 + (int)threadIdx.x;
+        v[u] = *reinterpret_cast<const uint4*>(smem + (idx / CPR) * PITCH + (idx % CPR) * 16);
+      }
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const int idx = (it0 + u) * 512 + (int)threadIdx.x;
+        const int lr = idx / CPR;
+        // staged row -> tile row: all rows in order, or (two passes) 64 of every wave row's 128
+        const long grow = row0 + (PASSES == 1 ? lr : (lr >> 6) * 128 + pass * 64 + (lr & 63));
+        if (grow < p.out_rows)
+          *reinterpret_cast<uint4*>(obase + grow * orow_bytes + (idx % CPR) * 16) = v[u];
+      }
     }
+    if (pass + 1 < PASSES) __syncthreads();  // the staging rows are rewritten by the next pass
   }
   if (prof) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

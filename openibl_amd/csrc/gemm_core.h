@@ -25,7 +25,13 @@
 // 16 B = 4 consecutive floats of its row and feeds them to 4 successive MFMAs; A and B use the
 // same (lane half, element) -> k assignment, so the products pair up correctly and only the
 // summation order over k differs from ascending (irrelevant to the result beyond fp32 rounding).
+//
+// bf16x3 (common.h): a K-step row is [32 hi | 32 lo]; the four k-chunks a lane reads are hi[0:16],
+// hi[16:32], lo[0:16], lo[16:32] and the step evaluates lo.hi + hi.lo + hi.hi per 16-wide half
+// (6 MFMAs instead of 4 per tile pair, 32 real K elements instead of 64).
 #pragma once
+
+#include <type_traits>
 
 #include "common.h"
 
@@ -59,6 +65,8 @@ struct Mma<bf16_t> {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
   }
 };
+template <>
+struct Mma<bf16x3_t> : Mma<bf16_t> {};
 template <>
 struct Mma<float> {
   using Frag = f32x4_t;
@@ -203,22 +211,57 @@ __device__ static inline void gemm_nt_mainloop(f32x16_t (&acc)[Cfg::TM][Cfg::TN]
 
     const char* abase = lds + cur * Cfg::STAGE_BYTES + a_wave_off;
     const char* bbase = lds + cur * Cfg::STAGE_BYTES + b_wave_off;
+    if constexpr (std::is_same<T, bf16x3_t>::value) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      Frag a[TM], b[TN];
+      for (int pr = 0; pr < 2; ++pr) {  // 16-wide half of the step's 32 K elements
+        Frag ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-        a[i] = *reinterpret_cast<const Frag*>(abase + i * 4096 + frag_off[kk]);
+        for (int i = 0; i < TM; ++i) {
+          ah[i] = *reinterpret_cast<const Frag*>(abase + i * 4096 + frag_off[pr]);
+          al[i] = *reinterpret_cast<const Frag*>(abase + i * 4096 + frag_off[pr + 2]);
+        }
 #pragma unroll
-      for (int i = 0; i < TN; ++i)
-        b[i] = *reinterpret_cast<const Frag*>(bbase + i * 4096 + frag_off[kk]);
-      if constexpr (GLDS) {
-        if (more) fetch_part(cur ^ 1, kk);
+        for (int i = 0; i < TN; ++i) {
+          bh[i] = *reinterpret_cast<const Frag*>(bbase + i * 4096 + frag_off[pr]);
+          bl[i] = *reinterpret_cast<const Frag*>(bbase + i * 4096 + frag_off[pr + 2]);
+        }
+        if constexpr (GLDS) {
+          if (more) {
+            fetch_part(cur ^ 1, 2 * pr);
+            fetch_part(cur ^ 1, 2 * pr + 1);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int jn = 0; jn < TN; ++jn) Mma<T>::mma(acc[i][jn], al[i], bh[jn]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int jn = 0; jn < TN; ++jn) Mma<T>::mma(acc[i][jn], ah[i], bl[jn]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int jn = 0; jn < TN; ++jn) Mma<T>::mma(acc[i][jn], ah[i], bh[jn]);
       }
+    } else {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int kk = 0; kk < 4; ++kk) {
+        Frag a[TM], b[TN];
 #pragma unroll
-        for (int jn = 0; jn < TN; ++jn) Mma<T>::mma(acc[i][jn], a[i], b[jn]);
+        for (int i = 0; i < TM; ++i)
+          a[i] = *reinterpret_cast<const Frag*>(abase + i * 4096 + frag_off[kk]);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+          b[i] = *reinterpret_cast<const Frag*>(bbase + i * 4096 + frag_off[kk]);
+        if constexpr (GLDS) {
+          if (more) fetch_part(cur ^ 1, kk);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int jn = 0; jn < TN; ++jn) Mma<T>::mma(acc[i][jn], a[i], b[jn]);
+      }
     }
     if constexpr (GLDS) {
       if (more) {

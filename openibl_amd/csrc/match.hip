@@ -50,7 +50,8 @@ __device__ static inline float4 load4_widen(const void* row, int i) {
 
 // The same reduction over the widened row, with the operand copy the contraction reads written on
 // the way: OUT = 1 the bf16 rounding (bf16 mode; nothing to write for bf16 storage, xo == nullptr),
-// OUT = 2 the fp32 widening of a 16-bit row (fp32 mode).  The descriptors are read once.
+// OUT = 2 the fp32 widening of a 16-bit row (fp32 mode), OUT = 3 the (hi, lo) split of bf16x3 mode
+// (rows of d / 32 groups [32 hi | 32 lo]).  The descriptors are read once.
 template <int ST, int OUT>
 __global__ void row_sqnorm_cast_kernel(const void* __restrict__ x, float* __restrict__ out,
                                        void* __restrict__ xo, int rows, int d) {
@@ -75,6 +76,19 @@ __global__ void row_sqnorm_cast_kernel(const void* __restrict__ x, float* __rest
       }
     } else if constexpr (OUT == 2) {
       *reinterpret_cast<float4*>(static_cast<float*>(xo) + (size_t)row * d + i) = v;
+    } else if constexpr (OUT == 3) {
+      uint2 hi, lo;
+      hi.x = (uint32_t)f32_to_bf16_bits(v.x) | ((uint32_t)f32_to_bf16_bits(v.y) << 16);
+      hi.y = (uint32_t)f32_to_bf16_bits(v.z) | ((uint32_t)f32_to_bf16_bits(v.w) << 16);
+      const float r0 = v.x - __builtin_bit_cast(float, hi.x << 16);
+      const float r1 = v.y - __builtin_bit_cast(float, hi.x & 0xffff0000u);
+      const float r2 = v.z - __builtin_bit_cast(float, hi.y << 16);
+      const float r3 = v.w - __builtin_bit_cast(float, hi.y & 0xffff0000u);
+      lo.x = (uint32_t)f32_to_bf16_bits(r0) | ((uint32_t)f32_to_bf16_bits(r1) << 16);
+      lo.y = (uint32_t)f32_to_bf16_bits(r2) | ((uint32_t)f32_to_bf16_bits(r3) << 16);
+      char* q = static_cast<char*>(xo) + (size_t)row * d * 4 + x3_off((size_t)i);
+      *reinterpret_cast<uint2*>(q) = hi;
+      *reinterpret_cast<uint2*>(q + 64) = lo;
     }
   }
   s = wave_sum(s);
@@ -166,7 +180,7 @@ struct PairRingParams {
   int group_m;                        // query tiles per ordering group (see above)
 };
 
-template <bool FILTER>
+template <bool FILTER, bool X3 = false>
 __global__ __launch_bounds__(512) void pairwise_ring_kernel(PairRingParams p) {
   using G = RingGeo<2>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -192,7 +206,7 @@ __global__ __launch_bounds__(512) void pairwise_ring_kernel(PairRingParams p) {
       rows_b[2 * h + i] = ring_b_row<2>(wave, lane, h, i);
     }
   RingRowLoader<2> la, lb;
-  la.init(p.x, p.x_bytes, m0, p.m, (long)p.d * 2, rows_a, piece);
+  la.init(p.x, p.x_bytes, m0, p.m, (long)p.d * (X3 ? 4 : 2), rows_a, piece);
   lb.init(p.y, p.y_bytes, n0, p.n, p.y_row_bytes, rows_b, piece);
 
   f32x16_t acc[4][2];
@@ -203,7 +217,7 @@ __global__ __launch_bounds__(512) void pairwise_ring_kernel(PairRingParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  ring_mainloop<2, false, false>(acc, smem, wave, lane, la, lb, p.d >> 6);
+  ring_mainloop<2, false, false, X3>(acc, smem, wave, lane, la, lb, p.d >> (X3 ? 5 : 6));
 
   // norms (and thresholds) of the tile's rows / columns -> LDS; out-of-range rows/columns are
   // clamped here and masked at the store
@@ -648,6 +662,7 @@ static bool st_ok(int st) { return st == OIBL_ST_F32 || st == OIBL_ST_F16 || st 
 // bytes of the operand copy the contraction reads instead of the stored rows (0: reads them as is)
 static size_t pw_copy_bytes(int rows, int d, int precision, int st) {
   if (precision == OIBL_BF16) return st == OIBL_ST_BF16 ? 0 : align_up((size_t)rows * d * 2, 256);
+  if (precision == OIBL_BF16X3) return align_up((size_t)rows * d * 4, 256);  // the (hi, lo) rows
   return st == OIBL_ST_F32 ? 0 : align_up((size_t)rows * d * 4, 256);
 }
 
@@ -660,19 +675,22 @@ size_t oibl_pairwise_workspace_bytes(int m, int n, int d, int precision) {
 }
 
 // ring kernel legality: bf16, an even number (>= 4) of 64-element K-tiles, 32-bit buffer offsets
-static bool pair_ring_legal(int m, int n, int d) {
-  const int ksteps = d / 64;
-  return d % 64 == 0 && ksteps >= 4 && (ksteps & 1) == 0 && (size_t)m * d * 2 < (size_t)0xE0000000u &&
-         (size_t)n * d * 2 < (size_t)0xE0000000u && n <= (1 << 20) && !g_regstage;
+// (es = bytes per operand element: 2 bf16, 4 bf16x3 with 32-element K-tiles)
+static bool pair_ring_legal(int m, int n, int d, int es = 2) {
+  const int ksteps = d * es / 128;
+  return d % 64 == 0 && ksteps >= 4 && (ksteps & 1) == 0 && (size_t)m * d * es < (size_t)0xE0000000u &&
+         (size_t)n * d * es < (size_t)0xE0000000u && n <= (1 << 20) && !g_regstage;
 }
-static bool pair_ring_wanted(int m, int n, int d) {
-  if (!g_match_ring || !pair_ring_legal(m, n, d)) return false;
+static bool mfma16(int precision) { return precision == OIBL_BF16 || precision == OIBL_BF16X3; }
+static int opnd_es(int precision) { return precision == OIBL_BF16 ? 2 : 4; }
+static bool pair_ring_wanted(int m, int n, int d, int es = 2) {
+  if (!g_match_ring || !pair_ring_legal(m, n, d, es)) return false;
   // below ~64 tiles of 256 x 256 the 128 x 128 kernel fills the chip better
   return g_match_ring == 2 || (long)((m + 255) / 256) * ((n + 255) / 256) >= 64;
 }
 
 extern "C++" {
-template <bool FILTER>
+template <bool FILTER, bool X3 = false>
 static int launch_pairwise_ring(PairRingParams& p, hipStream_t st) {
   p.tiles_m = (p.m + 255) / 256;
   p.tiles_n = (p.n + 255) / 256;
@@ -680,7 +698,7 @@ static int launch_pairwise_ring(PairRingParams& p, hipStream_t st) {
   const long grid = (long)p.tiles_m * p.tiles_n;
   OIBL_REQUIRE(grid > 0 && grid <= 0x7fffffffL, "pairwise: grid out of range");
   constexpr int lds = RingGeo<2>::MAIN_LDS;
-  auto kern = pairwise_ring_kernel<FILTER>;
+  auto kern = pairwise_ring_kernel<FILTER, X3>;
   OIBL_SET_MAX_LDS(kern, lds);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, p);
   OIBL_LAUNCH_CHECK();
@@ -697,6 +715,9 @@ static int prepare_rows(const void* x, int rows, int d, int precision, float* no
   if (precision == OIBL_BF16) {
     hipLaunchKernelGGL((row_sqnorm_cast_kernel<ST, 1>), grid, block, 0, st, x, norms, copy, rows, d);
     *opnd = ST == OIBL_ST_BF16 ? x : copy;
+  } else if (precision == OIBL_BF16X3) {
+    hipLaunchKernelGGL((row_sqnorm_cast_kernel<ST, 3>), grid, block, 0, st, x, norms, copy, rows, d);
+    *opnd = copy;
   } else if (ST == OIBL_ST_F32) {
     hipLaunchKernelGGL(row_sqnorm_kernel, grid, block, 0, st, (const float*)x, norms, rows, d);
     *opnd = x;
@@ -735,22 +756,23 @@ static int pairwise_launch(const void* xo, const void* yo, const float* xn, cons
                            int rows, int m_all, int n, int d, int precision, float* dist, size_t ldd,
                            hipStream_t st) {
   const size_t es = oibl_elem_size(precision);
-  if (precision == OIBL_BF16 && pair_ring_wanted(rows, n, d) && ldd <= ((size_t)1 << 20)) {
+  if (mfma16(precision) && pair_ring_wanted(rows, n, d, (int)es) && ldd <= ((size_t)1 << 20)) {
     PairRingParams q = {};
-    q.x = (const char*)xo + (size_t)row0 * d * 2;
+    q.x = (const char*)xo + (size_t)row0 * d * es;
     q.y = yo;
     q.xn = xn + row0;
     q.yn = yn;
     q.dist = dist;
     q.ldd = ldd;
-    q.x_bytes = (unsigned)((size_t)rows * d * 2);
-    q.y_bytes = (unsigned)((size_t)n * d * 2);
-    q.y_row_bytes = (long)d * 2;
+    q.x_bytes = (unsigned)((size_t)rows * d * es);
+    q.y_bytes = (unsigned)((size_t)n * d * es);
+    q.y_row_bytes = (long)d * es;
     q.yn_stride = 1;
     q.m = rows;
     q.n = n;
     q.d = d;
-    return launch_pairwise_ring<false>(q, st);
+    return precision == OIBL_BF16X3 ? launch_pairwise_ring<false, true>(q, st)
+                                    : launch_pairwise_ring<false>(q, st);
   }
   PairParams p;
   p.x = (const char*)xo + (size_t)row0 * d * es;
@@ -774,6 +796,14 @@ static int pairwise_launch(const void* xo, const void* yo, const float* xn, cons
     else
       hipLaunchKernelGGL((pairwise_kernel<Cfg, true>), dim3((unsigned)grid), dim3(Cfg::NTHREADS),
                          Cfg::MAIN_LDS_BYTES, st, p);
+  } else if (precision == OIBL_BF16X3) {
+    using Cfg = GemmCfg<bf16x3_t, 2, 2, 2, 2>;
+    if (g_regstage)
+      hipLaunchKernelGGL((pairwise_kernel<Cfg, false>), dim3((unsigned)grid), dim3(Cfg::NTHREADS),
+                         Cfg::MAIN_LDS_BYTES, st, p);
+    else
+      hipLaunchKernelGGL((pairwise_kernel<Cfg, true>), dim3((unsigned)grid), dim3(Cfg::NTHREADS),
+                         Cfg::MAIN_LDS_BYTES, st, p);
   } else {
     using Cfg = GemmCfg<float, 2, 2, 2, 2>;
     if (g_regstage)
@@ -791,8 +821,7 @@ int oibl_pairwise_sqdist_st(const void* x, int x_st, int m, const void* y, int y
                             int precision, float* dist, size_t ldd, void* ws, size_t ws_bytes,
                             void* stream) {
   OIBL_REQUIRE(x && y && dist && ws, "pairwise: null pointer");
-  OIBL_REQUIRE(precision == OIBL_BF16 || precision == OIBL_F32, "pairwise: bad precision %d",
-               precision);
+  OIBL_REQUIRE(mfma16(precision) || precision == OIBL_F32, "pairwise: bad precision %d", precision);
   OIBL_REQUIRE(st_ok(x_st) && st_ok(y_st), "pairwise: bad storage type %d / %d", x_st, y_st);
   OIBL_REQUIRE(m > 0 && n > 0 && d > 0 && d % 64 == 0 && ldd >= (size_t)n,
                "pairwise: unsupported shape m=%d n=%d d=%d ldd=%zu", m, n, d, ldd);
@@ -837,7 +866,7 @@ static TopkPlan topk_plan(int m, int n, int d, int k, int precision, int x_st, i
   // lists stay on the register selection path of row_topk.
   int S = 1024;
   while ((S < 4 * k || (long)S * 800 < (long)k * n) && S < SEL_MAX_N) S *= 2;
-  t.fused = precision == OIBL_BF16 && g_match_ring && pair_ring_legal(m, n, d) && n >= 8 * S &&
+  t.fused = mfma16(precision) && g_match_ring && pair_ring_legal(m, n, d, opnd_es(precision)) && n >= 8 * S &&
             (long)((m + 255) / 256) * ((n + 255) / 256) >= 64;
   t.S = S;
   t.stride = n / S;                       // sample = gallery rows 0, stride, 2 stride, ...
@@ -890,8 +919,7 @@ int oibl_sqdist_topk_st(const void* x, int x_st, int m, const void* y, int y_st,
                         int index_base, int precision, int exact, float* out_val, int32_t* out_idx,
                         int32_t* overflow, void* ws, size_t ws_bytes, void* stream) {
   OIBL_REQUIRE(x && y && out_val && out_idx && ws, "sqdist_topk: null pointer");
-  OIBL_REQUIRE(precision == OIBL_BF16 || precision == OIBL_F32, "sqdist_topk: bad precision %d",
-               precision);
+  OIBL_REQUIRE(mfma16(precision) || precision == OIBL_F32, "sqdist_topk: bad precision %d", precision);
   OIBL_REQUIRE(st_ok(x_st) && st_ok(y_st), "sqdist_topk: bad storage type %d / %d", x_st, y_st);
   OIBL_REQUIRE(m > 0 && n > 0 && d > 0 && d % 64 == 0, "sqdist_topk: unsupported shape m=%d n=%d d=%d",
                m, n, d);
@@ -925,14 +953,16 @@ int oibl_sqdist_topk_st(const void* x, int x_st, int m, const void* y, int y_st,
     q.yn = yn;
     q.dist = sample;
     q.ldd = (size_t)t.S;
-    q.x_bytes = (unsigned)((size_t)m * d * 2);
-    q.y_bytes = (unsigned)((size_t)n * d * 2);
-    q.y_row_bytes = (long)d * 2 * t.stride;
+    const bool x3 = precision == OIBL_BF16X3;
+    const size_t es = (size_t)opnd_es(precision);
+    q.x_bytes = (unsigned)((size_t)m * d * es);
+    q.y_bytes = (unsigned)((size_t)n * d * es);
+    q.y_row_bytes = (long)d * es * t.stride;
     q.yn_stride = t.stride;
     q.m = m;
     q.n = t.S;
     q.d = d;
-    rc = launch_pairwise_ring<false>(q, st);
+    rc = x3 ? launch_pairwise_ring<false, true>(q, st) : launch_pairwise_ring<false>(q, st);
     if (rc) return rc;
     launch_row_topk(sample, nullptr, m, t.S, (size_t)t.S, k, 0, sval, sidx, nullptr, nullptr, st);
     OIBL_LAUNCH_CHECK();
@@ -940,7 +970,7 @@ int oibl_sqdist_topk_st(const void* x, int x_st, int m, const void* y, int y_st,
     int* cnt = (int*)(wsb + t.off_cnt);
     OIBL_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)m * sizeof(int), st));
     q.dist = nullptr;
-    q.y_row_bytes = (long)d * 2;
+    q.y_row_bytes = (long)d * es;
     q.yn_stride = 1;
     q.n = n;
     q.thr = sval + (k - 1);
@@ -951,7 +981,7 @@ int oibl_sqdist_topk_st(const void* x, int x_st, int m, const void* y, int y_st,
     q.cap = t.cap;
     q.index_base = index_base;
     q.index_stride = 1;
-    rc = launch_pairwise_ring<true>(q, st);
+    rc = x3 ? launch_pairwise_ring<true, true>(q, st) : launch_pairwise_ring<true>(q, st);
     if (rc) return rc;
     // 3. exact top-k of every candidate list ((value, index) keys: independent of append order)
     launch_row_topk(q.cand_val, q.cand_idx, m, t.cap, (size_t)t.cap, k, 0, out_val, out_idx, cnt,

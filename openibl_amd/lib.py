@@ -67,6 +67,8 @@ SIGNATURES = {
     "oibl_sqdist_topk_st": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                     c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                     c_void_p]),
+    "oibl_x3_split_rows": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "oibl_x3_join_rows": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "oibl_cast_f32_to_f16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "oibl_cast_f16_to_f32": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "oibl_resize_bilinear_nchw": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int,
@@ -91,7 +93,7 @@ _HOOKS = {"oibl_debug_set_regstage": (c_int, [c_int]),
           "oibl_debug_set_match_group": (c_int, [c_int]),
           "oibl_debug_set_prof_buffer": (c_int, [c_void_p])}
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class OpenIBLAmdError(RuntimeError):
@@ -112,10 +114,13 @@ def load():
         try:
             if not _build.is_current():
                 _build.build(verbose=False)
-        except Exception as e:  # stale-but-present library is still usable
+        except Exception as e:  # a stale-but-present library is still usable — but say so
             if not path.exists():
                 raise OpenIBLAmdError(
                     f"openibl_amd: the HIP extension is not built and cannot be built here: {e}")
+            import warnings
+            warnings.warn(f"openibl_amd: {path.name} is older than csrc/ and could not be rebuilt "
+                          f"({e}); loading the stale library")
     if not path.exists():
         raise OpenIBLAmdError(
             f"openibl_amd: {path} is missing; run `python -m openibl_amd.build` (needs hipcc). "

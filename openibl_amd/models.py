@@ -32,12 +32,13 @@ _CFG_D = (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 51
 
 
 def default_precision() -> str:
-    """'fp32' (exact fp32 MFMA, reference-grade numerics) unless OPENIBL_AMD_PRECISION=bf16."""
+    """'fp32' (exact fp32 MFMA, reference-grade numerics) unless OPENIBL_AMD_PRECISION is set to
+    'bf16x3' (split bf16: fp32-class descriptors at 3x the bf16 matrix work) or 'bf16'."""
     return os.environ.get("OPENIBL_AMD_PRECISION", "fp32").lower()
 
 
 class _PrecisionMixin:
-    """`module.set_precision('bf16' | 'fp32')` switches the arithmetic of the contractions."""
+    """`module.set_precision('bf16' | 'bf16x3' | 'fp32')` switches the arithmetic of the contractions."""
 
     def set_precision(self, precision: str):
         ops.precision_code(precision)
@@ -50,6 +51,22 @@ class _PrecisionMixin:
     @property
     def precision(self) -> str:
         return getattr(self, "_precision", None) or default_precision()
+
+    def invalidate(self):
+        """Drop every packed / cast copy of the parameters (they are rebuilt by the next forward).
+        The caches are keyed on (data_ptr, _version, device) of the parameters, which catches
+        `load_state_dict`, `.to()` and in-place autograd-visible updates, but NOT writes through
+        `param.data` (`p.data.copy_(...)`, the idiom of the reference's NetVLAD._init_params,
+        ibl/models/netvlad.py:34-42): call this after such an update.  A GraphedDescriptor froze
+        its copies at capture time and has to be re-created."""
+        for m in self.modules():
+            if isinstance(m, _PrecisionMixin):
+                m._cache = {}
+        return self
+
+    def _hook_state_dict_loads(self):
+        # load_state_dict copies through param.data as well on some paths: always start clean
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate())
 
 
 def _fingerprint(params: List[torch.Tensor]) -> Tuple:
@@ -82,6 +99,7 @@ class VGG(_PrecisionMixin, nn.Module):
         self.base = nn.Sequential(*layers[:-2])   # drop the last ReLU and max-pool (vgg.py:41-42)
         self.gap = nn.AdaptiveMaxPool2d(1)
         self._cache: Dict = {}
+        self._hook_state_dict_loads()
         self._init_params()
         if not pretrained:
             self.reset_params()
@@ -163,6 +181,7 @@ class NetVLAD(_PrecisionMixin, nn.Module):
         self.clsts = None
         self.traindescs = None
         self._cache: Dict = {}
+        self._hook_state_dict_loads()
 
     def _init_params(self):
         raise NotImplementedError("NetVLAD._init_params (k-means initialisation for training) is "
@@ -212,6 +231,7 @@ class EmbedNetPCA(_PrecisionMixin, nn.Module):
         self.net_vlad = net_vlad
         self.pca_layer = nn.Conv2d(net_vlad.num_clusters * net_vlad.dim, dim, 1, stride=1, padding=0)
         self._cache: Dict = {}
+        self._hook_state_dict_loads()
 
     def _init_params(self):
         self.base_model._init_params()

@@ -14,8 +14,12 @@ from . import lib as _lib
 
 BF16 = 0
 F32 = 1
-_DTYPES = {BF16: torch.bfloat16, F32: torch.float32}
-_NAMES = {"bf16": BF16, "bfloat16": BF16, "fp32": F32, "f32": F32, "float32": F32}
+BF16X3 = 2   # split bf16: (hi, lo) operand pairs, three MFMAs per product, fp32-class results
+# element containers: bf16x3 activations / packed weights are opaque 4-byte elements (rows of
+# [32 hi | 32 lo] groups, see x3_split) carried in int32 tensors of the logical shape
+_DTYPES = {BF16: torch.bfloat16, F32: torch.float32, BF16X3: torch.int32}
+_NAMES = {"bf16": BF16, "bfloat16": BF16, "fp32": F32, "f32": F32, "float32": F32,
+          "bf16x3": BF16X3, "x3": BF16X3}
 
 
 def precision_code(p) -> int:
@@ -23,10 +27,18 @@ def precision_code(p) -> int:
         try:
             return _NAMES[p.lower()]
         except KeyError:
-            raise ValueError(f"unknown precision {p!r} (use 'bf16' or 'fp32')")
-    if p in (BF16, F32):
+            raise ValueError(f"unknown precision {p!r} (use 'bf16', 'bf16x3' or 'fp32')")
+    if p in (BF16, F32, BF16X3):
         return int(p)
     raise ValueError(f"unknown precision {p!r}")
+
+
+def head_precision(p) -> int:
+    """Precision of the small contractions behind the backbone (NetVLAD assignment, PCA): bf16x3
+    runs them in exact fp32 — they are HBM / latency bound there (the PCA streams its weight once
+    per batch), so splitting the operands would buy nothing."""
+    p = precision_code(p)
+    return F32 if p == BF16X3 else p
 
 
 def elem_dtype(p) -> torch.dtype:
@@ -79,7 +91,7 @@ def release_workspaces() -> None:
 # ---------------------------------------------------------------------------------------------
 def cast(x: torch.Tensor, precision) -> torch.Tensor:
     """fp32 tensor -> tensor of the precision's element type (bf16 round-to-nearest-even)."""
-    p = precision_code(precision)
+    p = head_precision(precision)
     dev = _need_cuda(x)
     if x.dtype != torch.float32:
         raise ValueError("cast expects float32 input")
@@ -100,6 +112,31 @@ def to_f32(x: torch.Tensor) -> torch.Tensor:
     out = torch.empty(x.shape, dtype=torch.float32, device=dev)
     _lib.check(_lib.load().oibl_cast_bf16_to_f32(_ptr(x), _ptr(out), x.numel(), _stream(dev)),
                "cast_bf16_to_f32")
+    return out
+
+
+def x3_split(x: torch.Tensor) -> torch.Tensor:
+    """float32 [..., C] (C % 32 == 0) -> the bf16x3 operand layout (int32 container, same shape):
+    per row, C/32 groups of [32 x hi | 32 x lo] with hi = bf16(v), lo = bf16(v - hi)."""
+    dev = _need_cuda(x)
+    if x.dtype != torch.float32 or x.dim() < 1 or x.shape[-1] % 32 != 0:
+        raise ValueError("x3_split expects a float32 tensor whose last dimension is a multiple of 32")
+    out = torch.empty(x.shape, dtype=torch.int32, device=dev)
+    C_ = int(x.shape[-1])
+    _lib.check(_lib.load().oibl_x3_split_rows(_ptr(x), _ptr(out), x.numel() // C_, C_, _stream(dev)),
+               "x3_split_rows")
+    return out
+
+
+def x3_join(x: torch.Tensor) -> torch.Tensor:
+    """bf16x3 tensor (int32 container) -> float32 hi + lo (exact)."""
+    dev = _need_cuda(x)
+    if x.dtype != torch.int32 or x.dim() < 1 or x.shape[-1] % 32 != 0:
+        raise ValueError("x3_join expects an int32 bf16x3 container whose last dimension is a multiple of 32")
+    out = torch.empty(x.shape, dtype=torch.float32, device=dev)
+    C_ = int(x.shape[-1])
+    _lib.check(_lib.load().oibl_x3_join_rows(_ptr(x), _ptr(out), x.numel() // C_, C_, _stream(dev)),
+               "x3_join_rows")
     return out
 
 
@@ -239,7 +276,8 @@ def vgg16_conv5(x: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequen
     if ws_bytes == 0:
         raise ValueError(f"vgg16_conv5: unsupported input shape {tuple(x.shape)}")
     ws = workspace(ws_bytes, dev, "vgg")
-    feat = torch.empty((N, h, w, 512), dtype=_DTYPES[p], device=dev)
+    # bf16x3: the last layer writes a plain fp32 map for the (fp32) head
+    feat = torch.empty((N, h, w, 512), dtype=_DTYPES[head_precision(p)], device=dev)
     wp = (C.c_void_p * 13)(*[t.data_ptr() for t in weights])
     bp = (C.c_void_p * 13)(*[t.data_ptr() for t in biases])
     ev0 = ev1 = None
@@ -282,8 +320,8 @@ def nhwc_to_nchw_f32(feat: torch.Tensor) -> torch.Tensor:
 
 
 def nchw_f32_to_nhwc(x: torch.Tensor, precision) -> torch.Tensor:
-    """[N][C][h][w] fp32 -> [N][h][w][C] T."""
-    p = precision_code(precision)
+    """[N][C][h][w] fp32 -> [N][h][w][C] T (bf16x3: fp32, what its head consumes)."""
+    p = head_precision(precision)
     dev = _need_cuda(x)
     if x.dtype != torch.float32 or x.dim() != 4:
         raise ValueError("nchw_f32_to_nhwc expects a float32 [N][C][h][w] tensor")

@@ -69,7 +69,7 @@ def main():
     if p == "bf16":
         t, _ = timed(lambda: ops.vgg16_stem(x, packed[0], biases[0], packed[1], biases[1]), a.iters)
         rows.append(("stem fused (conv1_1+conv01)", t, rows[0][2] + rows[1][2]))
-    feat = act
+    feat = ops.x3_join(act) if p == "bf16x3" else act   # the whole-backbone entry writes fp32 directly
     aw = sd["net_vlad.conv.weight"].reshape(64, 512).contiguous().to(dev)
     cent = sd["net_vlad.centroids"].to(dev)
     t, (_, vl) = timed(lambda: ops.netvlad(feat, aw, cent, True, False, True), a.iters)
