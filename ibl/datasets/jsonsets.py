@@ -29,7 +29,17 @@ class _JsonDataset(Dataset):
             raise RuntimeError("Dataset not found.")
         meta, splits = read_json(meta_f), read_json(splits_f)
         ident, utm = meta['identities'], meta['utm']
-        self.train = _pluck(ident, utm, sorted(splits.get('q_train', [])))
+        # examples/test.py:37-38 reads pitts.q_train / pitts.db_train (the PCA training set);
+        # train = q_train + db_train before the queries without positives are dropped
+        # (ibl/utils/data/dataset.py:75-88)
+        self.q_train = _pluck(ident, utm, sorted(splits.get('q_train', [])))
+        self.db_train = _pluck(ident, utm, sorted(splits.get('db_train', [])))
+        self.train = self.q_train + self.db_train
+        if self.q_train and self.db_train:
+            self.train_pos, self.train_neg, sel = get_groundtruth(
+                self.q_train, self.db_train, self.intra_thres, self.inter_thres)
+            self.train_neg = [self.train_neg[i] for i in sel]
+            self.q_train = [self.q_train[i] for i in sel]
         self.q_val = _pluck(ident, utm, sorted(splits.get('q_val', [])))
         self.db_val = _pluck(ident, utm, sorted(splits.get('db_val', [])))
         self.q_test = _pluck(ident, utm, sorted(splits.get('q_test', [])))

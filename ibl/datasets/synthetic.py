@@ -39,7 +39,8 @@ class Synthetic(Dataset):
         self.db_test = [(f, pid, 40.0 * i, 0.0) for i, (f, pid) in enumerate(g)]
         self.q_test = [(f, pid, 40.0 * (i % num_gallery) + 5.0, 3.0) for i, (f, pid) in enumerate(q)]
         self.db_val, self.q_val = list(self.db_test), list(self.q_test)
-        self.train = list(self.q_test)
+        self.q_train, self.db_train = list(self.q_test), list(self.db_test)   # what test.py:37-38 reads
+        self.train = self.q_train + self.db_train
         self.test_pos, sel = get_groundtruth(self.q_test, self.db_test, self.inter_thres)
         self.q_test = [self.q_test[i] for i in sel]
         self.val_pos = list(self.test_pos)

@@ -576,6 +576,7 @@ static int launch_conv(const ConvParams& p, int pool, hipStream_t st) {
     // (4 bytes per element) fits next to nothing else in LDS: 256 x {128, 64}, 128 x {128, 64}
     using C256x128 = GemmCfg<T, 4, 2, 2, 2>;
     using C256x64 = GemmCfg<T, 4, 2, 2, 1>;
+    using C512x64 = GemmCfg<T, 8, 1, 2, 2>;  // Cout = 64 (conv1_2): 64 x 64 per wave instead of 64 x 32
     const int rv = (g_regstage || p.ablate || (pool && p.out_f32)) ? 0 : ring_variant(p, 4);
     const long t256 = (p.m_total + 255) / 256;
     const long ring_tiles = rv == 2 ? t256 * (p.cout / 256) : ((p.m_total + 511) / 512) * (p.cout / 128);
@@ -585,8 +586,12 @@ static int launch_conv(const ConvParams& p, int pool, hipStream_t st) {
         return pool ? launch_conv_ring<2, true, true>(p, st) : launch_conv_ring<2, false, true>(p, st);
       return pool ? launch_conv_ring<4, true, true>(p, st) : launch_conv_ring<4, false, true>(p, st);
     }
-    if (mode == 4 || mode == 3) mode = 0;
-    if (mode == 0) mode = t256 * (p.cout / (p.cout % 128 == 0 ? 128 : 64)) >= 512 ? 2 : 1;
+    if (mode == 4) mode = 0;
+    if (mode == 0) {
+      if (p.cout % 128 != 0 && (p.m_total + 511) / 512 * (p.cout / 64) >= 512) mode = 3;
+      else mode = t256 * (p.cout / (p.cout % 128 == 0 ? 128 : 64)) >= 512 ? 2 : 1;
+    }
+    if (mode == 3 && p.cout % 128 != 0) { OIBL_CONV_DISPATCH(C512x64); }
     if (mode >= 2) {
       if (p.cout % 128 == 0) { OIBL_CONV_DISPATCH(C256x128); }
       OIBL_CONV_DISPATCH(C256x64);

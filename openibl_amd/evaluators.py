@@ -73,12 +73,23 @@ def extract_cnn_feature(model, inputs, vlad=True, gpu=None, scales=None):
     return ops.l2_normalize(out.float().contiguous())
 
 
+FAST_EXTRACTION = True   # False: batch-by-batch eager launches (the cross-check of the replayed path)
+
+
 def _extract_local(model, data_loader, vlad, pca, gpu, print_freq, rank, scales=None, store_dtype=None):
     """Run the loader of this rank; returns the [n_local][d] descriptor matrix ON DEVICE, in
-    `store_dtype` (None = float32; float16 / bfloat16 = 16-bit descriptor storage)."""
+    `store_dtype` (None = float32; float16 / bfloat16 = 16-bit descriptor storage).
+
+    Embed* models take the replayed route of openibl_amd.extract (hipGraph per batch shape, copy /
+    backbone / head on three streams, descriptors written straight into a pre-sized matrix); other
+    modules and multi-scale extraction run batch by batch.  Same kernels, same bits."""
     model.eval()
     if pca is not None:
         pca.load(gpu=gpu)
+    from . import extract
+    if FAST_EXTRACTION and scales is None and extract.fast_path_supported(model):
+        return extract.extract_descriptors(model, data_loader, vlad=vlad, pca=pca, gpu=gpu,
+                                           print_freq=print_freq, rank=rank, store_dtype=store_dtype)
     batch_t, data_t = _Meter(), _Meter()
     chunks = []
     end = time.time()
@@ -240,6 +251,19 @@ def recalls_from_topk_device(topk_idx: torch.Tensor, gt: Sequence[Sequence[int]]
     return correct / len(gt)
 
 
+MAX_RANK_PREFIX = 1024   # longest ranked prefix oibl_row_topk / oibl_first_hit_rank produce
+
+
+def _check_prefix(k: int) -> None:
+    """The reference counts over max(recall_topk) predictions, 12x that with nms
+    (evaluators.py:152-153).  A prefix the kernels cannot produce is an error, never a silent
+    truncation: truncated lists would change Recall@N."""
+    if k > MAX_RANK_PREFIX:
+        raise ValueError(f"recall counting needs the {k} nearest gallery entries per query; the "
+                         f"device ranking is limited to {MAX_RANK_PREFIX} (max(recall_topk) <= "
+                         f"{MAX_RANK_PREFIX}, or <= {MAX_RANK_PREFIX // 12} with nms=True)")
+
+
 def _print_recalls(recalls, recall_topk):
     print("Recall Scores:")
     for i, k in enumerate(recall_topk):
@@ -252,8 +276,8 @@ def evaluate_all(distmat, gt, gallery, recall_topk=[1, 5, 10], nms=False):
     reduced on the GPU by the top-k kernel (ties: lowest gallery index first)."""
     rank, _ = _rank_world()
     d = _to_tensor(distmat).float()
-    k = max(recall_topk) * (12 if nms else 1)
-    k = min(k, d.shape[1], 1024)
+    k = min(max(recall_topk) * (12 if nms else 1), d.shape[1])
+    _check_prefix(k)
     dev = _device()
     _, idx = ops.row_topk(d.to(dev).contiguous(), k)
     if rank == 0:
@@ -309,10 +333,22 @@ class Evaluator(object):
                                  self.descriptor_dtype)
         g_local = _extract_local(self.model, gallery_loader, vlad, pca, gpu, 10, rank, self.scales,
                                  self.descriptor_dtype)
+        # This flow relies on the dealing of DistributedSliceSampler (contiguous slices of
+        # ceil(L / W) items, wrap-around padding): global gallery indices come from slice_bounds.
+        # A loader with another sampler / drop_last would silently shift them — refuse instead.
+        for what, local, items in (("query", q_local, query), ("gallery", g_local, gallery)):
+            per = sharded.slice_bounds(len(items), rank, world)[1]
+            if local.shape[0] != per:
+                raise ValueError(
+                    f"Evaluator.evaluate(device_resident=True): the {what} loader of rank {rank} "
+                    f"yielded {local.shape[0]} items, DistributedSliceSampler would yield {per}; "
+                    "use DistributedSliceSampler(dataset) without drop_last, or pass "
+                    "device_resident=False for the reference's host flow")
         q_all = sharded.all_gather_rows(q_local)[: len(query)].contiguous()
         start, _, n_valid = sharded.slice_bounds(len(gallery), rank, world)
         g_local = g_local[:n_valid].contiguous()
-        k = min(max(recall_topk) * (12 if nms else 1), len(gallery), 1024)
+        k = min(max(recall_topk) * (12 if nms else 1), len(gallery))
+        _check_prefix(k)
         if rank == 0:
             print("===> Start calculating pairwise distances")
         _, idx = sharded.sharded_topk(q_all, g_local, k, start, prec)

@@ -1,0 +1,310 @@
+"""The replayed, double-buffered forward behind `ibl.evaluators.extract_features`
+(ibl/evaluators.py:36-103) and behind `EmbedNetPCA.graphed()`.
+
+`GraphedForward` captures a forward of a fixed batch shape once into two hipGraphs — backbone (the
+matrix-core launches) and head (everything after the conv5_3 map) — and replays them: a batch costs
+the host two graph launches instead of ~30 kernel launches.  With `pipeline=True` there are two
+slots, each with its own input buffer, feature map and output:
+
+    copy stream    H2D of batch i+1 into slot (i+1) % 2      (pinned host memory -> no host stall)
+    main stream    backbone graph of batch i    (slot i % 2)
+    side stream    head graph of batch i-1, then the hand-off of its descriptors
+
+so the PCIe copy and the head's latency / HBM-bound kernels hide behind matrix-core work.
+
+`extract_descriptors` is the loop of `extract_features` over one rank's loader built on it: a batch
+shape is run eagerly the first time it is seen (which also packs weights and sizes workspaces) and
+captured the second time; descriptors land in a pre-sized device matrix in loader order.  The
+kernels, their order and their arithmetic are those of the eager path, so the descriptors are
+bit-identical to `extract_cnn_feature` batch by batch (tested).
+"""
+from __future__ import annotations
+
+import time
+from collections import OrderedDict
+from typing import Callable, Optional
+
+import torch
+
+from . import ops
+
+__all__ = ["GraphedForward", "extract_descriptors", "unwrap_model", "MAX_CACHED_SHAPES"]
+
+MAX_CACHED_SHAPES = 3     # captured (shape, dtype) entries kept per extraction (each owns its
+                          # activation workspaces: ~2.5 GB for 32 x 480x640 in bf16)
+
+
+def unwrap_model(model):
+    """The module behind DistributedDataParallel / DataParallel wrappers (examples/test.py:67-69)."""
+    while hasattr(model, "module") and isinstance(getattr(model, "module"), torch.nn.Module):
+        model = model.module
+    return model
+
+
+class GraphedForward:
+    """Two-graph replay of `head_fn(backbone_fn(x))` for one input shape.
+
+        fwd = GraphedForward(backbone_fn, head_fn, example, pipeline=True)
+        out = fwd(x)              # x: device tensor or (pinned) host tensor of the example's shape
+        out = fwd()               # again on the batch resident in the slot
+        fwd.wait()                # the current stream waits for every head launched so far
+
+    backbone_fn(x) -> feature map and head_fn(feat) -> output tensor must only launch work on the
+    current stream and allocate through torch (graph-pool allocations).  The returned tensor is
+    the slot's static output: complete after `wait()` (or a device synchronisation), overwritten
+    by the call `depth` calls later.  `dest=` hands the result off instead: the rows are copied
+    into `dest` on the side stream right behind the head, and the slot is free again without the
+    caller synchronising.
+    `events`: optional (start, stop) torch.cuda.Event pair recorded on the launching stream right
+    around the backbone graph (bench.py's matrix-core span)."""
+
+    def __init__(self, backbone_fn: Callable, head_fn: Callable, example: torch.Tensor,
+                 pipeline: bool = False):
+        if not example.is_cuda or example.dim() != 4 or example.dtype not in (torch.float32, torch.uint8):
+            raise ValueError("graphed forward: example must be a CUDA tensor, float32 [N][3][H][W] "
+                             "or uint8 [N][H][W][3]")
+        dev = example.device
+        self.device = dev
+        self.pipeline = bool(pipeline)
+        self.depth = 2 if self.pipeline else 1
+        self.calls = 0
+        self.side = torch.cuda.Stream(device=dev) if self.pipeline else None
+        self.copy = torch.cuda.Stream(device=dev) if self.pipeline else None
+        # never aliases a caller's tensor; every slot starts with the example in place
+        self.static_in = [example.clone(memory_format=torch.contiguous_format) for _ in range(self.depth)]
+        self.in_ready = [torch.cuda.Event() for _ in range(self.depth)]
+        self.bb_done = [torch.cuda.Event() for _ in range(self.depth)]
+        self.head_done = [torch.cuda.Event() for _ in range(self.depth)]
+        self.g_backbone, self.g_head, self.out = [], [], []
+        self._keep = []   # every tensor captured by a graph stays referenced: a tensor freed between
+                          # two captures hands its block of the shared pool to the next capture, and
+                          # the two pipeline slots would alias
+        with torch.no_grad():
+            head_fn(backbone_fn(self.static_in[0]))   # packs weights, sizes every workspace, warms up
+            torch.cuda.synchronize(dev)
+            pool = None
+            for j in range(self.depth):
+                gb = torch.cuda.CUDAGraph()
+                # thread_local: a communicator's watchdog thread (RCCL, one process per GPU) may
+                # touch the HIP runtime while this thread captures
+                with torch.cuda.graph(gb, pool=pool, capture_error_mode="thread_local"):
+                    feat = backbone_fn(self.static_in[j])
+                pool = gb.pool()
+                gh = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gh, pool=pool, capture_error_mode="thread_local"):
+                    out = head_fn(feat)
+                self.g_backbone.append(gb)
+                self.g_head.append(gh)
+                self.out.append(out)
+                self._keep += [feat, out]
+            self._keep += ops.workspaces_snapshot()   # scratch the graphs recorded pointers into
+
+    @property
+    def shape(self):
+        return self.static_in[0].shape
+
+    def __call__(self, x: Optional[torch.Tensor] = None, events=None,
+                 dest: Optional[torch.Tensor] = None) -> torch.Tensor:
+        j = self.calls % self.depth
+        self.calls += 1
+        main = torch.cuda.current_stream(self.device)
+        if x is not None:                     # x=None: run again on the batch resident in slot j
+            if x.shape != self.static_in[j].shape or x.dtype != self.static_in[j].dtype:
+                raise ValueError(f"graphed forward was captured for {tuple(self.static_in[j].shape)} "
+                                 f"{self.static_in[j].dtype}")
+            if self.pipeline:
+                # the previous backbone that read this slot's input has finished; whatever produced
+                # x on the caller's stream has, too
+                self.copy.wait_event(self.bb_done[j])
+                if x.is_cuda:
+                    self.copy.wait_stream(main)
+                with torch.cuda.stream(self.copy):
+                    self.static_in[j].copy_(x, non_blocking=True)
+                    self.in_ready[j].record(self.copy)
+                main.wait_event(self.in_ready[j])
+            else:
+                self.static_in[j].copy_(x, non_blocking=True)
+        if self.pipeline:
+            main.wait_event(self.head_done[j])   # slot j's feature map / output are free again
+        if events is not None:
+            events[0].record()
+        self.g_backbone[j].replay()
+        if events is not None:
+            events[1].record()
+        if not self.pipeline:
+            self.g_head[j].replay()
+            if dest is not None:
+                dest.copy_(self.out[j], non_blocking=True)
+            return self.out[j]
+        self.bb_done[j].record(main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.bb_done[j])
+            self.g_head[j].replay()
+            if dest is not None:
+                dest.copy_(self.out[j], non_blocking=True)
+            self.head_done[j].record(self.side)
+        return self.out[j]
+
+    def wait(self) -> None:
+        """Make the current stream wait for every head (and hand-off copy) launched so far."""
+        if self.pipeline:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
+
+
+# ---------------------------------------------------------------------------------------------
+def _head_fn(core, vlad: bool, pca, store_dtype):
+    """What extract_cnn_feature (+ PCA.infer, + descriptor storage) computes behind the conv5_3 map
+    (ibl/evaluators.py:22-34, 55-57), as a function of the NHWC feature map."""
+    from .models import EmbedNetPCA
+
+    def head(feat):
+        if isinstance(core, EmbedNetPCA):
+            out = core.head_from_features(feat)
+        elif vlad:
+            _, out = core.net_vlad.aggregate_nhwc(feat, want_raw=False, want_norm=True)
+        else:
+            out = ops.global_maxpool_nhwc(feat)
+        out = ops.l2_normalize(out)
+        if pca is not None:
+            out = pca.infer(out)
+        return ops.store_descriptors(out, store_dtype)
+
+    return head
+
+
+def fast_path_supported(model) -> bool:
+    from .models import EmbedNet, EmbedNetPCA, EmbedRegionNet
+    return isinstance(unwrap_model(model), (EmbedNet, EmbedNetPCA, EmbedRegionNet))
+
+
+class _PinnedStage:
+    """Two pinned host buffers for batches the loader did not pin (pin_memory=False): the batch is
+    copied into one of them on the host, then travels asynchronously like a pinned batch."""
+
+    def __init__(self):
+        self.bufs = [None, None]
+        self.done = [None, None]
+        self.i = 0
+
+    def stage(self, x: torch.Tensor, dev) -> torch.Tensor:
+        j = self.i
+        self.i ^= 1
+        if self.done[j] is not None:
+            self.done[j].synchronize()        # the H2D that read this buffer last has completed
+        b = self.bufs[j]
+        if b is None or b.numel() < x.numel() or b.dtype != x.dtype:
+            b = torch.empty(x.numel(), dtype=x.dtype).pin_memory()
+            self.bufs[j] = b
+        v = b[: x.numel()].view(x.shape)
+        v.copy_(x)
+        return v, j
+
+    def mark(self, j: int, stream) -> None:
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        self.done[j] = ev
+
+
+def extract_descriptors(model, data_loader, vlad=True, pca=None, gpu=None, print_freq=10, rank=0,
+                        store_dtype=None, use_graphs: bool = True) -> torch.Tensor:
+    """Descriptors of every item one rank's loader yields, in loader order, as one device matrix
+    [n_local][d] (float32, or `store_dtype`).  The caller has put the model in eval mode and loaded
+    `pca`.  Batches may be float32 [N][3][H][W] (normalised) or uint8 [N][H][W][3] (raw), pinned or
+    not, of any mix of shapes."""
+    core = unwrap_model(model)
+    dev = torch.device("cuda", torch.cuda.current_device() if gpu is None else gpu)
+    backbone = core.base_model.features_nhwc
+    head = _head_fn(core, vlad, pca, store_dtype)
+    try:
+        n_items = len(data_loader.sampler)
+    except Exception:
+        n_items = None
+    try:
+        n_batches = len(data_loader)
+    except Exception:
+        n_batches = -1
+    final, chunks, row = None, [], 0
+    seen, graphs = {}, OrderedDict()
+    stage = _PinnedStage()
+    main = torch.cuda.current_stream(dev)
+    last_fwd = None
+    t_end = time.time()
+    t_data = t_batch = 0.0
+    with torch.no_grad():
+        for i, batch in enumerate(data_loader):
+            imgs = batch[0]
+            if not torch.is_tensor(imgs):
+                imgs = torch.as_tensor(imgs)
+            if imgs.dtype != torch.uint8 and imgs.dtype != torch.float32:
+                imgs = imgs.float()
+            imgs = imgs.contiguous()
+            t_data = time.time() - t_end
+            slot = None
+            if not imgs.is_cuda and not imgs.is_pinned():
+                imgs, slot = stage.stage(imgs, dev)
+            n = int(imgs.shape[0])
+            key = (tuple(imgs.shape), imgs.dtype)
+            seen[key] = seen.get(key, 0) + 1
+            fwd = graphs.get(key)
+            if fwd is None and use_graphs and seen[key] >= 2:
+                if last_fwd is not None:
+                    last_fwd.wait()
+                main.synchronize()            # capture starts from an idle device
+                ex = imgs.to(dev, non_blocking=False)
+                fwd = GraphedForward(backbone, head, ex, pipeline=True)
+                graphs[key] = fwd
+                while len(graphs) > MAX_CACHED_SHAPES:
+                    graphs.popitem(last=False)
+            if fwd is not None:
+                graphs.move_to_end(key)
+            if final is None and fwd is None:
+                # first batch: eager (packs the weights, sizes the workspaces, tells d and the dtype)
+                out = head(backbone(imgs.to(dev, non_blocking=True)))
+                if slot is not None:
+                    stage.mark(slot, main)
+                d = int(out.shape[1])
+                if n_items is not None:
+                    final = torch.empty((n_items, d), dtype=out.dtype, device=dev)
+                    final[row:row + n].copy_(out)
+                else:
+                    chunks.append(out)
+            else:
+                dst = None
+                if final is not None:
+                    if row + n > final.shape[0]:       # the loader yields more than its sampler said
+                        final = torch.cat([final, torch.empty((row + n - final.shape[0], final.shape[1]),
+                                                              dtype=final.dtype, device=dev)])
+                    dst = final[row:row + n]
+                if fwd is not None:
+                    if last_fwd is not None and last_fwd is not fwd:
+                        last_fwd.wait()               # another shape's side stream: keep the order simple
+                    out = fwd(imgs, dest=dst)
+                    if slot is not None:
+                        stage.mark(slot, fwd.copy)
+                    last_fwd = fwd
+                    if dst is None:
+                        fwd.wait()
+                        chunks.append(out.clone())
+                else:
+                    if last_fwd is not None:
+                        last_fwd.wait()
+                    out = head(backbone(imgs.to(dev, non_blocking=True)))
+                    if slot is not None:
+                        stage.mark(slot, main)
+                    if dst is not None:
+                        dst.copy_(out)
+                    else:
+                        chunks.append(out)
+            row += n
+            t_batch = time.time() - t_end
+            t_end = time.time()
+            if (i + 1) % print_freq == 0 and rank == 0:
+                print("Extract Features: [{}/{}]\tTime {:.3f}\tData {:.3f}\t".format(
+                    i + 1, n_batches, t_batch, t_data))
+        if last_fwd is not None:
+            last_fwd.wait()
+    if final is not None:
+        return final[:row]
+    if not chunks:
+        return torch.empty((0, 0), device=dev)
+    return torch.cat(chunks)

@@ -66,7 +66,9 @@ class _PrecisionMixin:
 
     def _hook_state_dict_loads(self):
         # load_state_dict copies through param.data as well on some paths: always start clean
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate())
+        def _drop(module, incompatible_keys):   # (a post hook must return None)
+            module.invalidate()
+        self.register_load_state_dict_post_hook(_drop)
 
 
 def _fingerprint(params: List[torch.Tensor]) -> Tuple:
@@ -247,102 +249,40 @@ class EmbedNetPCA(_PrecisionMixin, nn.Module):
             hit = self._cache["pca"]
         return hit[1], hit[2]
 
-    @torch.no_grad()
-    def forward(self, x):
-        feat = self.base_model.features_nhwc(x)
+    def head_from_features(self, feat: torch.Tensor) -> torch.Tensor:
+        """conv5_3 map (NHWC) -> descriptors: NetVLAD, intra + L2 norm, PCA, L2 (netvlad.py:98-108)."""
         _, vlad = self.net_vlad.aggregate_nhwc(feat, want_raw=False, want_norm=True)
         w, b = self._pca_params()
         return ops.pca(vlad, w, b, l2norm=True)
 
-    def graphed(self, example: torch.Tensor, pipeline: bool = False) -> "GraphedDescriptor":
+    @torch.no_grad()
+    def forward(self, x):
+        return self.head_from_features(self.base_model.features_nhwc(x))
+
+    def graphed(self, example: torch.Tensor, pipeline: bool = False):
         """hipGraph-replayed forward for a fixed batch shape (see GraphedDescriptor)."""
         return GraphedDescriptor(self, example, pipeline=pipeline)
 
 
-class GraphedDescriptor:
-    """`EmbedNetPCA.forward` captured once into hipGraphs and replayed: backbone (the 12 matrix-core
-    launches) and head (NetVLAD + PCA, ~10 launches).  A forward then costs the host two graph
-    launches instead of ~30 kernel launches — on a shared host the eager path can become
-    launch-bound at ~5 ms per batch.  Shapes, precision and parameters are frozen at capture time;
-    the returned descriptor tensor is static and overwritten by a later call (clone it to keep it).
+def GraphedDescriptor(model: "EmbedNetPCA", example: torch.Tensor, pipeline: bool = False):
+    """`EmbedNetPCA.forward` captured once into hipGraphs and replayed (openibl_amd.extract
+    .GraphedForward): backbone (the matrix-core launches) and head (NetVLAD + PCA, ~10 launches).  A
+    forward then costs the host two graph launches instead of ~30 kernel launches — on a shared host
+    the eager path can become launch-bound at ~5 ms per batch.  Shapes, precision and parameters are
+    frozen at capture time; the returned descriptor tensor is static and overwritten by a later call
+    (clone it to keep it).
 
         fwd = model.graphed(example_batch)        # example_batch: resident [N][3][H][W] fp32
-        desc = fwd(batch)                         # same shape; copied into the static input
+        desc = fwd(batch)                         # same shape; copied into the slot's static input
         desc = fwd()                              # again on the batch already in place
 
-    pipeline=True double-buffers the feature map and runs the head of batch i on a second stream
-    while the backbone of batch i+1 already occupies the matrix cores (the head's kernels are
-    latency / HBM bound: ~0.15 ms per batch that otherwise leaves the chip mostly idle).  The
-    tensor returned by call i is then complete once `fwd.wait()` (or a device synchronisation) has
-    returned, and is overwritten by call i+2.
-    `events`: optional (start, stop) torch.cuda.Event pair recorded on the launching stream right
-    around the backbone graph (bench.py's matrix-core span)."""
-
-    def __init__(self, model: "EmbedNetPCA", example: torch.Tensor, pipeline: bool = False):
-        if not example.is_cuda or example.dtype not in (torch.float32, torch.uint8) or example.dim() != 4:
-            raise ValueError("graphed(): example must be a CUDA tensor, float32 [N][3][H][W] or "
-                             "uint8 [N][H][W][3]")
-        self.static_in = example.clone(memory_format=torch.contiguous_format)   # never aliases a caller's tensor
-        self.pipeline = bool(pipeline)
-        self.depth = 2 if self.pipeline else 1
-        self.calls = 0
-        self.side = torch.cuda.Stream(device=example.device) if self.pipeline else None
-        self.bb_done = [torch.cuda.Event() for _ in range(self.depth)]
-        self.head_done = [torch.cuda.Event() for _ in range(self.depth)]
-        self.g_backbone, self.g_head, self.out = [], [], []
-        self._keep = []   # every tensor captured by a graph stays referenced: a tensor freed between
-                          # two captures hands its block of the shared pool to the next capture, and
-                          # the two pipeline slots would alias
-        with torch.no_grad():
-            model(self.static_in)               # packs weights, sizes every workspace, warms up
-            torch.cuda.synchronize(example.device)
-            pool = None
-            for _ in range(self.depth):
-                gb = torch.cuda.CUDAGraph()
-                # thread_local: a communicator's watchdog thread (RCCL, one process per GPU) may
-                # touch the HIP runtime while this thread captures
-                with torch.cuda.graph(gb, pool=pool, capture_error_mode="thread_local"):
-                    feat = model.base_model.features_nhwc(self.static_in)
-                pool = gb.pool()
-                gh = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gh, pool=pool, capture_error_mode="thread_local"):
-                    _, vlad = model.net_vlad.aggregate_nhwc(feat, want_raw=False, want_norm=True)
-                    w, b = model._pca_params()
-                    out = ops.pca(vlad, w, b, l2norm=True)
-                self.g_backbone.append(gb)
-                self.g_head.append(gh)
-                self.out.append(out)
-                self._keep += [feat, vlad, w, b, out]
-
-    def __call__(self, x: torch.Tensor = None, events=None) -> torch.Tensor:
-        j = self.calls % self.depth
-        self.calls += 1
-        main = torch.cuda.current_stream(self.static_in.device)
-        if x is not None:                     # x=None: run again on the batch already in place
-            if x.shape != self.static_in.shape:
-                raise ValueError(f"graphed forward was captured for {tuple(self.static_in.shape)}")
-            self.static_in.copy_(x, non_blocking=True)
-        if self.pipeline:
-            main.wait_event(self.head_done[j])   # slot j's feature map / output are free again
-        if events is not None:
-            events[0].record()
-        self.g_backbone[j].replay()
-        if events is not None:
-            events[1].record()
-        if not self.pipeline:
-            self.g_head[j].replay()
-            return self.out[j]
-        self.bb_done[j].record(main)
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(self.bb_done[j])
-            self.g_head[j].replay()
-            self.head_done[j].record(self.side)
-        return self.out[j]
-
-    def wait(self) -> None:
-        """Make the current stream wait for every head launched so far (pipeline mode)."""
-        if self.pipeline:
-            torch.cuda.current_stream(self.static_in.device).wait_stream(self.side)
+    pipeline=True keeps two slots (input, feature map, output each) and runs the head of batch i on
+    a second stream while the backbone of batch i+1 already occupies the matrix cores; a batch passed
+    to the call travels on a third (copy) stream.  The tensor returned by call i is then complete
+    once `fwd.wait()` (or a device synchronisation) has returned, and is overwritten by call i+2."""
+    from .extract import GraphedForward
+    return GraphedForward(model.base_model.features_nhwc, model.head_from_features, example,
+                          pipeline=pipeline)
 
 
 class EmbedRegionNet(_PrecisionMixin, nn.Module):

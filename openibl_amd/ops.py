@@ -88,6 +88,12 @@ def release_workspaces() -> None:
     _WS.clear()
 
 
+def workspaces_snapshot():
+    """The scratch buffers currently alive (a captured hipGraph keeps those it recorded referenced:
+    the grow-only buffers are replaced, not resized, when a later call needs more)."""
+    return list(_WS.values())
+
+
 # ---------------------------------------------------------------------------------------------
 def cast(x: torch.Tensor, precision) -> torch.Tensor:
     """fp32 tensor -> tensor of the precision's element type (bf16 round-to-nearest-even)."""

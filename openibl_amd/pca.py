@@ -5,8 +5,8 @@
 PCA kernel (oibl_pca_forward): normalize(W v + b) (pca.py:117-121).
 
 Parameter files: the reference writes HDF5 (datasets U, lams, mu, Utmu; pca.py:77-84).  h5py is
-imported lazily; a `.npz` holding the same four arrays is accepted as well (and is what `train`
-writes when h5py is unavailable).
+imported lazily; an npz archive holding the same four arrays is accepted as well, recognised by
+content, and is what `train` writes — at the requested path — when h5py is unavailable.
 """
 from __future__ import annotations
 
@@ -28,20 +28,35 @@ def _rank() -> int:
         return 0
 
 
+_HDF5_MAGIC = b"\x89HDF\r\n\x1a\n"
+
+
 def _read_params(path: str):
-    if path.endswith(".npz") or (not os.path.exists(path) and os.path.exists(path + ".npz")):
-        z = np.load(path if path.endswith(".npz") else path + ".npz")
+    """(U, lams, mu, Utmu) from the reference's HDF5 file or from an npz archive holding the same
+    four arrays.  The format is sniffed from the file's first bytes, not from its name: without
+    h5py `train` writes the archive AT the path the caller chose (examples/test.py:109-111 decides
+    with osp.isfile(<...>.h5) whether to train again)."""
+    if not os.path.exists(path) and os.path.exists(path + ".npz"):
+        path = path + ".npz"                   # files written by earlier versions of this package
+    with open(path, "rb") as f:
+        magic = f.read(8)
+    if magic != _HDF5_MAGIC:
+        z = np.load(path)
         return z["U"], z["lams"], z["mu"], z["Utmu"]
     try:
         import h5py
     except ImportError as e:
-        raise ImportError(f"PCA.load: reading {path} needs h5py (or provide the same arrays as "
-                          f"{path}.npz)") from e
+        raise ImportError(f"PCA.load: {path} is an HDF5 file and h5py is not installed (an npz "
+                          "archive with the arrays U, lams, mu, Utmu at the same path is accepted "
+                          "as well)") from e
     with h5py.File(path, "r") as f:
         return f["U"][...], f["lams"][...], f["mu"][...], f["Utmu"][...]
 
 
 def _write_params(path: str, U, lams, mu, Utmu) -> str:
+    folder = os.path.dirname(path)
+    if folder:
+        os.makedirs(folder, exist_ok=True)
     try:
         import h5py
         if not hasattr(h5py, "File"):
@@ -49,11 +64,10 @@ def _write_params(path: str, U, lams, mu, Utmu) -> str:
         with h5py.File(path, "w") as f:
             for k, v in (("U", U), ("lams", lams), ("mu", mu), ("Utmu", Utmu)):
                 f.create_dataset(k, data=v)
-        return path
     except ImportError:
-        out = path if path.endswith(".npz") else path + ".npz"
-        np.savez(out, U=U, lams=lams, mu=mu, Utmu=Utmu)
-        return out
+        with open(path, "wb") as f:            # same four arrays, npz container, SAME path
+            np.savez(f, U=U, lams=lams, mu=mu, Utmu=Utmu)
+    return path
 
 
 class PCA:
@@ -106,22 +120,35 @@ class PCA:
         dev = torch.device("cuda", torch.cuda.current_device() if gpu is None else gpu)
         # same tensors and shapes as the reference keeps (pca.py:105-106)
         self.weight = torch.from_numpy(np.ascontiguousarray(U.T)).view(
-            self.pca_n_components, -1, 1, 1).float().to(dev)
+            U.shape[1], -1, 1, 1).float().to(dev)
         self.bias = torch.from_numpy(-Utmu).view(-1).float().to(dev)
         self._w_dev = None
 
-    def _kernel_weight(self) -> torch.Tensor:
+    def _kernel_params(self):
+        """(weight in the precision's element type, bias), both padded with zero rows to the next
+        multiple of 128 outputs — the projection kernel's tile — which leaves W v + b and its L2
+        norm unchanged (the padded outputs are exactly 0 and are sliced off again)."""
         prec = self.precision or default_precision()
-        key = (prec, self.weight.data_ptr(), self.weight._version)
+        key = (prec, self.weight.data_ptr(), self.weight._version, self.bias.data_ptr())
         if self._w_dev is None or self._w_dev[0] != key:
-            w2 = self.weight.reshape(self.pca_n_components, -1).contiguous()
-            self._w_dev = (key, ops.cast(w2, prec))
-        return self._w_dev[1]
+            n = int(self.weight.shape[0])
+            w2 = self.weight.reshape(n, -1).contiguous()
+            b = self.bias
+            pad = (-n) % 128
+            if pad:
+                w2 = torch.cat([w2, w2.new_zeros((pad, w2.shape[1]))]).contiguous()
+                b = torch.cat([b, b.new_zeros(pad)]).contiguous()
+            self._w_dev = (key, ops.cast(w2, prec), b)
+        return self._w_dev[1], self._w_dev[2]
 
     def infer(self, data: torch.Tensor) -> torch.Tensor:
-        """[N][dim] -> [N][pca_n_components], L2-normalised rows (pca.py:108-123)."""
+        """[N][dim] -> [N][n], L2-normalised rows (pca.py:108-123); n = pca_n_components, or the
+        number of components the parameter file holds if that is smaller."""
         if self.weight is None:
             raise RuntimeError("PCA.infer called before PCA.load")
-        out = ops.pca(data.float().contiguous(), self._kernel_weight(), self.bias, l2norm=True)
-        assert out.size(1) == self.pca_n_components
+        n = int(self.weight.shape[0])
+        w, b = self._kernel_params()
+        out = ops.pca(data.float().contiguous(), w, b, l2norm=True)
+        if out.size(1) != n:
+            out = out[:, :n].contiguous()
         return out

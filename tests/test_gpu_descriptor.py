@@ -54,8 +54,10 @@ def test_embednetpca_fp32_matches_reference(name, model, dev):
 
 @pytest.mark.parametrize("name", ["desc_small", "desc_480x640"])
 def test_embednetpca_bf16_reported_honestly(name, model, dev):
-    """bf16 operands cannot meet 1e-4 (~5e-3 expected); the test pins the error band
-    and the cosine instead, and the regstage / glds variants must agree bit for bit."""
+    """bf16 operands cannot meet 1e-4 (~5e-3 expected; measured 2.8e-3 at 480x640,
+    3.8e-3 at 64x96); the test pins that band — a 2x regression fails — and the cosine, and the
+    regstage / glds variants must agree bit for bit.  The 1e-4 mode at matrix-core speed is bf16x3
+    (tests/test_gpu_x3.py)."""
     g = load_golden(name)
     n, _, h, w = [int(v) for v in g["shape"]]
     x = synth.images(n, h, w, seed=int(g["image_seed"])).to(dev)
@@ -71,7 +73,7 @@ def test_embednetpca_bf16_reported_honestly(name, model, dev):
     err = rel_l2(desc, want)
     cos = torch.nn.functional.cosine_similarity(desc.double(), want.double(), dim=1).min().item()
     print(f"{name}: bf16 rel_l2={err:.3e} min cosine={cos:.6f}")
-    assert err < 3e-2 and cos > 0.9995
+    assert err < 6e-3 and cos > 0.99999
     assert torch.equal(desc, desc_rs)
 
 

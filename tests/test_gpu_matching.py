@@ -215,8 +215,9 @@ def test_sqdist_topk_full_size_properties(dev):
 @pytest.mark.parametrize("nms", [False, True])
 @pytest.mark.parametrize("m,n,k", [(37, 500, 10), (200, 3000, 120), (5, 40, 130), (64, 2000, 1024)])
 def test_first_hit_rank_equals_host_counting(dev, m, n, k, nms):
-    """Device recall counting == the reference's per-query loop (recalls_from_topk), with and
-    without spatial NMS, on random rankings with duplicate pids, padding and empty ground truth."""
+    """Device recall counting == the oracle's restatement of the reference's per-query loop
+    (oracle.matching.recalls_from_ranking), with and without spatial NMS, on random rankings with
+    duplicate pids, padding and empty ground truth; the host mirror recalls_from_topk agrees too."""
     from openibl_amd.evaluators import recalls_from_topk, recalls_from_topk_device
     rng = np.random.default_rng(m + n + k)
     kk = min(k, n)
@@ -230,6 +231,9 @@ def test_first_hit_rank_equals_host_counting(dev, m, n, k, nms):
     for topk in ((1, 5, 10), (1, 5, 10, 20, 25)):
         if nms and max(topk) * 12 > 1024:
             continue
-        want = recalls_from_topk(idx, gt, pids, topk, nms)
+        # the checker is the oracle's restatement of evaluators.py:149-160 (pinned to the reference's
+        # recalls by tests/test_oracle_golden.py); rows without their -1 padding
+        want = om.recalls_from_ranking([row[row >= 0] for row in idx], gt, pids, topk, nms)
         got = recalls_from_topk_device(torch.from_numpy(idx).to(dev), gt, pids, topk, nms)
         np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(recalls_from_topk(idx, gt, pids, topk, nms), want)

@@ -89,9 +89,11 @@ def test_conv3x3_x3(dev, N, H, W, cin, cout, relu, pool, regstage):
                   _host_conv(x, w, b, relu, pool), TOL_LAYER)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 4])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
 @pytest.mark.parametrize("N,H,W,cin,cout,relu,pool", [
     (2, 12, 20, 64, 64, True, True),
+    (3, 37, 45, 64, 64, True, True),      # conv1_2 family: 512 x 64 tile (tile=3), ragged, pooled
+    (2, 30, 40, 64, 64, False, False),
     (1, 9, 7, 128, 128, True, True),
     (3, 20, 24, 256, 256, True, False),
     (1, 30, 40, 512, 512, False, False),
@@ -240,7 +242,14 @@ def test_sqdist_topk_x3_fused_equals_matrix(dev):
     dm = ops.pairwise_sqdist(qd, gd, "bf16x3")
     v2, i2 = ops.row_topk(dm, 10)
     assert torch.equal(i, i2) and torch.equal(v, v2)
+    # against fp64: the selected entries are the true nearest ones up to the kernel's distance error
+    # (near-ties within ~1e-6 may legitimately swap, exactly as they do in the fp32 oracle)
+    d64 = (q.double().pow(2).sum(1)[:, None] + gal.double().pow(2).sum(1)[None, :]
+           - 2.0 * q.double() @ gal.double().T)
+    true_v = torch.sort(d64, dim=1).values[:, :10]
+    got_v = torch.gather(d64, 1, i.cpu().long())
+    assert (got_v - true_v).abs().max().item() < 5e-6
     want = om.ranking(om.pairwise_distance(q, gal).numpy())[:, :10]
     agree = (i.cpu().numpy() == want).mean()
     print(f"top-10 agreement with the fp32 oracle ranking: {agree:.6f}")
-    assert agree > 0.9999
+    assert agree > 0.999

@@ -161,3 +161,80 @@ def test_multiscale_definition_host_side(state_dict):
     assert abs(float(three.norm()) - 1.0) < 1e-5
     with pytest.raises((OpenIBLAmdError, ValueError)):
         multiscale.extract_multiscale(lambda t: t, x)      # CPU tensor: must not silently compute
+
+
+def test_json_dataset_has_every_attribute_test_py_reads(tmp_path):
+    """examples/test.py:33-56 reads q_train / db_train (PCA training set), q_test / db_test /
+    test_pos and images_dir from `datasets.create('pitts', ...)`."""
+    from helpers import synthetic_pitts
+    from ibl import datasets
+    root = synthetic_pitts.make(str(tmp_path / "pitts"))
+    ds = datasets.create("pitts", root, scale="30k", verbose=False)
+    assert len(ds.q_train) == 6 and len(ds.db_train) == 14 and len(ds.train) == 20
+    assert len(ds.train_pos) == len(ds.train_neg) == len(ds.q_train)
+    assert len(sorted(set(ds.q_train) | set(ds.db_train))) == 20          # test.py:38
+    assert len(ds.q_test) == 6 and len(ds.db_test) == 14 and all(len(p) == 1 for p in ds.test_pos)
+    assert len(ds.q_val) == 6 and len(ds.val_pos) == 6
+    assert ds.images_dir.endswith("raw")
+    with pytest.raises(RuntimeError):
+        datasets.create("pitts", str(tmp_path / "nowhere"), scale="30k")
+
+
+@pytest.mark.skipif(not __import__("os").path.isfile("/root/reference/examples/test.py"),
+                    reason="the reference tree is only present in the build container")
+def test_reference_test_py_get_data_runs_against_this_package(tmp_path):
+    """The reference's own examples/test.py, unmodified and loaded from where it lies, builds its
+    datasets / transforms / samplers / loaders through THIS repo's `ibl` (get_data, test.py:29-56)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    from helpers import synthetic_pitts
+    repo = Path(__file__).resolve().parent.parent
+    synthetic_pitts.make(str(tmp_path / "pitts"))
+    r = subprocess.run([sys.executable, str(repo / "tests" / "helpers" / "ref_testpy_probe.py"),
+                        str(tmp_path), "/root/reference/examples/test.py", str(repo)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "REFERENCE_GET_DATA_OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_logger_tees_and_leaves_stdout_open(tmp_path, capsys):
+    import sys
+    from ibl.utils.logging import Logger
+    path = tmp_path / "sub" / "log.txt"
+    with Logger(str(path)) as lg:
+        old, sys.stdout = sys.stdout, lg
+        try:
+            print("hello tee")
+            sys.stdout.flush()
+        finally:
+            sys.stdout = old
+        assert lg.file is not None and lg.console is old
+    assert lg.file is None
+    assert path.read_text() == "hello tee\n"
+    assert "hello tee" in capsys.readouterr().out
+    print("stdout still open")
+    Logger().write("no file\n")
+
+
+def test_pca_param_file_is_found_again_under_the_h5_name(tmp_path):
+    """examples/test.py:109-111 decides with osp.isfile('<...>.h5') whether to train the PCA again:
+    whatever container `train` writes must sit AT that path and be readable by `load`."""
+    import os.path as osp
+    import openibl_amd.pca as pmod
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((50, 24), generator=g)
+    path = str(tmp_path / "logs" / "pca_params_model_best.h5")
+    p = pmod.PCA(pca_n_components=8, pca_whitening=True, pca_parameters_path=path)
+    assert not osp.isfile(path)
+    p.train(x)
+    assert osp.isfile(path)
+    U, lams, mu, Utmu = pmod._read_params(path)
+    assert U.shape == (24, 8) and lams.shape == (8,) and mu.shape == (24, 1) and Utmu.shape == (8, 1)
+    np.testing.assert_allclose(U.T @ mu, Utmu, rtol=1e-4, atol=1e-5)
+
+
+def test_recall_prefix_beyond_the_kernel_limit_is_an_error():
+    from openibl_amd import evaluators as ev
+    ev._check_prefix(1024)
+    with pytest.raises(ValueError):
+        ev._check_prefix(1025)
