@@ -254,6 +254,25 @@ int oibl_sqdist_topk_st(const void* x, int x_st, int m, const void* y, int y_st,
                         int index_base, int precision, int exact, float* out_val, int32_t* out_idx,
                         int32_t* overflow, void* ws, size_t ws_bytes, void* stream);
 
+/* Prepared operands: a descriptor matrix that is matched many times (the resident gallery shard of
+ * a retrieval service, the query set that meets every shard) pays the norm / operand pass once.
+ *   oibl_match_operand_bytes : size of the operand buffer for (rows, d, precision, storage); 0 means
+ *       the contraction reads the stored rows in place (OIBL_BF16 on bf16 storage, OIBL_F32 on fp32
+ *       storage) and `operand` may be NULL.
+ *   oibl_match_prepare : norms[rows] = fp32 squared norms of the rows widened to fp32 (the
+ *       |x|^2 / |y|^2 terms of ibl/evaluators.py:127-128); operand = what the contraction reads:
+ *       bf16 rows (OIBL_BF16), [32 hi | 32 lo] groups (OIBL_BF16X3), fp32 rows (OIBL_F32).
+ *   oibl_sqdist_topk_prepared : oibl_sqdist_topk_st behind that pass, bit-identical results; xo / yo
+ *       are the prepared operands (or the stored rows where operand_bytes is 0). */
+size_t oibl_match_operand_bytes(int rows, int d, int precision, int st);
+int oibl_match_prepare(const void* x, int x_st, int rows, int d, int precision, float* norms,
+                       void* operand, void* stream);
+size_t oibl_sqdist_topk_prepared_workspace_bytes(int m, int n, int d, int k, int precision);
+int oibl_sqdist_topk_prepared(const void* xo, const float* xn, int m, const void* yo, const float* yn,
+                              int n, int d, int k, int index_base, int precision, int exact,
+                              float* out_val, int32_t* out_idx, int32_t* overflow, void* ws,
+                              size_t ws_bytes, void* stream);
+
 /* ---- top-k ------------------------------------------------------------------------ *
  * Replaces np.argsort(distmat, axis=1) (ibl/evaluators.py:143), of which evaluate_all only
  * consumes the first max(recall_topk) (or 12x that with nms) entries per row.

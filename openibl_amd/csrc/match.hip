@@ -856,7 +856,7 @@ struct TopkPlan {
   int S, stride, cap, chunk;
   size_t off_prep, off_sample, off_sval, off_sidx, off_cnt, off_cval, off_cidx, off_chunk, total;
 };
-static TopkPlan topk_plan(int m, int n, int d, int k, int precision, int x_st, int y_st) {
+static TopkPlan topk_plan(int m, int n, int d, int k, int precision, size_t prep_bytes) {
   TopkPlan t = {};
   // Sample size: the k-th smallest of S sampled distances lets ~ k n / S gallery rows through the
   // filter.  1024 rows keep the survivor density near 1 % of a tile (the filter epilogue's per-lane
@@ -880,7 +880,7 @@ static TopkPlan topk_plan(int m, int n, int d, int k, int precision, int x_st, i
   t.chunk = (int)chunk;
   size_t o = 0;
   t.off_prep = o;
-  o += align_up(oibl_pairwise_st_workspace_bytes(m, n, d, precision, x_st, y_st), 256);
+  o += align_up(prep_bytes, 256);
   t.off_sample = o;
   o += align_up((size_t)m * S * sizeof(float), 256);
   t.off_sval = o;
@@ -902,7 +902,7 @@ static TopkPlan topk_plan(int m, int n, int d, int k, int precision, int x_st, i
 size_t oibl_sqdist_topk_st_workspace_bytes(int m, int n, int d, int k, int precision, int x_st,
                                            int y_st) {
   if (m <= 0 || n <= 0 || d <= 0 || k <= 0 || !st_ok(x_st) || !st_ok(y_st)) return 0;
-  return topk_plan(m, n, d, k, precision, x_st, y_st).total;
+  return topk_plan(m, n, d, k, precision, oibl_pairwise_st_workspace_bytes(m, n, d, precision, x_st, y_st)).total;
 }
 size_t oibl_sqdist_topk_workspace_bytes(int m, int n, int d, int k, int precision) {
   return oibl_sqdist_topk_st_workspace_bytes(m, n, d, k, precision, OIBL_ST_F32, OIBL_ST_F32);
@@ -915,32 +915,14 @@ int oibl_sqdist_topk(const float* x, int m, const float* y, int n, int d, int k,
                              out_val, out_idx, overflow, ws, ws_bytes, stream);
 }
 
-int oibl_sqdist_topk_st(const void* x, int x_st, int m, const void* y, int y_st, int n, int d, int k,
-                        int index_base, int precision, int exact, float* out_val, int32_t* out_idx,
-                        int32_t* overflow, void* ws, size_t ws_bytes, void* stream) {
-  OIBL_REQUIRE(x && y && out_val && out_idx && ws, "sqdist_topk: null pointer");
-  OIBL_REQUIRE(mfma16(precision) || precision == OIBL_F32, "sqdist_topk: bad precision %d", precision);
-  OIBL_REQUIRE(st_ok(x_st) && st_ok(y_st), "sqdist_topk: bad storage type %d / %d", x_st, y_st);
-  OIBL_REQUIRE(m > 0 && n > 0 && d > 0 && d % 64 == 0, "sqdist_topk: unsupported shape m=%d n=%d d=%d",
-               m, n, d);
-  OIBL_REQUIRE(k >= 1 && k <= 1024, "sqdist_topk: k=%d outside [1, 1024]", k);
-  OIBL_REQUIRE((long)index_base + n <= 0x7fffffffL, "sqdist_topk: index_base + n overflows int32");
-  OIBL_REQUIRE((uintptr_t)ws % 256 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0,
-               "sqdist_topk: workspace must be 256-byte, x and y 16-byte aligned");
-  const TopkPlan t = topk_plan(m, n, d, k, precision, x_st, y_st);
-  if (ws_bytes < t.total) {
-    set_error("sqdist_topk: workspace %zu < required %zu bytes", ws_bytes, t.total);
-    return OIBL_E_WORKSPACE;
-  }
-  hipStream_t st = (hipStream_t)stream;
-  char* wsb = (char*)ws;
+// everything behind the norm / operand preparation: xo, yo are the rows the contraction reads
+// (bf16, (hi, lo) groups or fp32 by precision), xn, yn their fp32 squared norms
+static int sqdist_topk_core(const void* xo, const float* xn, int m, const void* yo, const float* yn,
+                            int n, int d, int k, int index_base, int precision, int exact,
+                            float* out_val, int32_t* out_idx, int32_t* overflow, char* wsb,
+                            const TopkPlan& t, hipStream_t st) {
+  int rc;
   if (overflow) OIBL_HIP_CHECK(hipMemsetAsync(overflow, 0, sizeof(int32_t), st));
-  const void *xo, *yo;
-  float *xn, *yn;
-  int rc = pairwise_prepare(x, x_st, m, y, y_st, n, d, precision, wsb + t.off_prep, &xo, &yo, &xn, &yn,
-                            stream);
-  if (rc) return rc;
-
   if (t.fused && !exact) {
     // 1. thresholds: k-th smallest distance to a strided sample of S gallery rows
     float* sample = (float*)(wsb + t.off_sample);
@@ -999,6 +981,82 @@ int oibl_sqdist_topk_st(const void* x, int x_st, int m, const void* y, int y_st,
     OIBL_LAUNCH_CHECK();
   }
   return OIBL_OK;
+}
+
+static int topk_args_ok(int m, int n, int d, int k, int index_base, int precision) {
+  OIBL_REQUIRE(mfma16(precision) || precision == OIBL_F32, "sqdist_topk: bad precision %d", precision);
+  OIBL_REQUIRE(m > 0 && n > 0 && d > 0 && d % 64 == 0, "sqdist_topk: unsupported shape m=%d n=%d d=%d",
+               m, n, d);
+  OIBL_REQUIRE(k >= 1 && k <= 1024, "sqdist_topk: k=%d outside [1, 1024]", k);
+  OIBL_REQUIRE((long)index_base + n <= 0x7fffffffL, "sqdist_topk: index_base + n overflows int32");
+  return OIBL_OK;
+}
+
+int oibl_sqdist_topk_st(const void* x, int x_st, int m, const void* y, int y_st, int n, int d, int k,
+                        int index_base, int precision, int exact, float* out_val, int32_t* out_idx,
+                        int32_t* overflow, void* ws, size_t ws_bytes, void* stream) {
+  OIBL_REQUIRE(x && y && out_val && out_idx && ws, "sqdist_topk: null pointer");
+  OIBL_REQUIRE(st_ok(x_st) && st_ok(y_st), "sqdist_topk: bad storage type %d / %d", x_st, y_st);
+  int rc = topk_args_ok(m, n, d, k, index_base, precision);
+  if (rc) return rc;
+  OIBL_REQUIRE((uintptr_t)ws % 256 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0,
+               "sqdist_topk: workspace must be 256-byte, x and y 16-byte aligned");
+  const TopkPlan t =
+      topk_plan(m, n, d, k, precision, oibl_pairwise_st_workspace_bytes(m, n, d, precision, x_st, y_st));
+  if (ws_bytes < t.total) {
+    set_error("sqdist_topk: workspace %zu < required %zu bytes", ws_bytes, t.total);
+    return OIBL_E_WORKSPACE;
+  }
+  char* wsb = (char*)ws;
+  const void *xo, *yo;
+  float *xn, *yn;
+  rc = pairwise_prepare(x, x_st, m, y, y_st, n, d, precision, wsb + t.off_prep, &xo, &yo, &xn, &yn,
+                        stream);
+  if (rc) return rc;
+  return sqdist_topk_core(xo, xn, m, yo, yn, n, d, k, index_base, precision, exact, out_val, out_idx,
+                          overflow, wsb, t, (hipStream_t)stream);
+}
+
+// ---- prepared operands: a gallery (or query set) that is matched many times ----------------------
+size_t oibl_match_operand_bytes(int rows, int d, int precision, int st) {
+  if (rows <= 0 || d <= 0 || !st_ok(st)) return 0;
+  return pw_copy_bytes(rows, d, precision, st);
+}
+
+int oibl_match_prepare(const void* x, int x_st, int rows, int d, int precision, float* norms,
+                       void* operand, void* stream) {
+  OIBL_REQUIRE(x && norms, "match_prepare: null pointer");
+  OIBL_REQUIRE(mfma16(precision) || precision == OIBL_F32, "match_prepare: bad precision %d", precision);
+  OIBL_REQUIRE(st_ok(x_st), "match_prepare: bad storage type %d", x_st);
+  OIBL_REQUIRE(rows > 0 && d > 0 && d % 64 == 0, "match_prepare: unsupported shape rows=%d d=%d", rows, d);
+  OIBL_REQUIRE(operand || pw_copy_bytes(rows, d, precision, x_st) == 0,
+               "match_prepare: this precision / storage pair needs an operand buffer");
+  OIBL_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)operand % 16 == 0, "match_prepare: unaligned pointer");
+  const void* opnd;
+  return prepare_rows_st(x, x_st, rows, d, precision, norms, operand, &opnd, (hipStream_t)stream);
+}
+
+size_t oibl_sqdist_topk_prepared_workspace_bytes(int m, int n, int d, int k, int precision) {
+  if (m <= 0 || n <= 0 || d <= 0 || k <= 0) return 0;
+  return topk_plan(m, n, d, k, precision, 0).total;
+}
+
+int oibl_sqdist_topk_prepared(const void* xo, const float* xn, int m, const void* yo, const float* yn,
+                              int n, int d, int k, int index_base, int precision, int exact,
+                              float* out_val, int32_t* out_idx, int32_t* overflow, void* ws,
+                              size_t ws_bytes, void* stream) {
+  OIBL_REQUIRE(xo && xn && yo && yn && out_val && out_idx && ws, "sqdist_topk_prepared: null pointer");
+  int rc = topk_args_ok(m, n, d, k, index_base, precision);
+  if (rc) return rc;
+  OIBL_REQUIRE((uintptr_t)ws % 256 == 0 && (uintptr_t)xo % 16 == 0 && (uintptr_t)yo % 16 == 0,
+               "sqdist_topk_prepared: workspace must be 256-byte, operands 16-byte aligned");
+  const TopkPlan t = topk_plan(m, n, d, k, precision, 0);
+  if (ws_bytes < t.total) {
+    set_error("sqdist_topk_prepared: workspace %zu < required %zu bytes", ws_bytes, t.total);
+    return OIBL_E_WORKSPACE;
+  }
+  return sqdist_topk_core(xo, xn, m, yo, yn, n, d, k, index_base, precision, exact, out_val, out_idx,
+                          overflow, (char*)ws, t, (hipStream_t)stream);
 }
 
 int oibl_first_hit_rank(const int32_t* topk_idx, int m, int k, const int32_t* gt_offsets,

@@ -76,22 +76,22 @@ class GraphedForward:
         self.bb_done = [torch.cuda.Event() for _ in range(self.depth)]
         self.head_done = [torch.cuda.Event() for _ in range(self.depth)]
         self.g_backbone, self.g_head, self.out = [], [], []
-        self._keep = []   # every tensor captured by a graph stays referenced: a tensor freed between
-                          # two captures hands its block of the shared pool to the next capture, and
-                          # the two pipeline slots would alias
+        self._keep = []
         with torch.no_grad():
             head_fn(backbone_fn(self.static_in[0]))   # packs weights, sizes every workspace, warms up
             torch.cuda.synchronize(dev)
-            pool = None
             for j in range(self.depth):
+                # Every graph captures into its OWN memory pool: the head of slot 0 runs on the side
+                # stream while the backbone of slot 1 runs on the main stream, so a temporary that
+                # head_fn frees during its capture must never be handed to a later capture (in a
+                # shared pool it would be, and the two slots would alias).
                 gb = torch.cuda.CUDAGraph()
                 # thread_local: a communicator's watchdog thread (RCCL, one process per GPU) may
                 # touch the HIP runtime while this thread captures
-                with torch.cuda.graph(gb, pool=pool, capture_error_mode="thread_local"):
+                with torch.cuda.graph(gb, capture_error_mode="thread_local"):
                     feat = backbone_fn(self.static_in[j])
-                pool = gb.pool()
                 gh = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gh, pool=pool, capture_error_mode="thread_local"):
+                with torch.cuda.graph(gh, capture_error_mode="thread_local"):
                     out = head_fn(feat)
                 self.g_backbone.append(gb)
                 self.g_head.append(gh)

@@ -69,6 +69,12 @@ SIGNATURES = {
                                     c_void_p]),
     "oibl_x3_split_rows": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "oibl_x3_join_rows": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "oibl_match_operand_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "oibl_match_prepare": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "oibl_sqdist_topk_prepared_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "oibl_sqdist_topk_prepared": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
+                                          c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_size_t, c_void_p]),
     "oibl_cast_f32_to_f16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "oibl_cast_f16_to_f32": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "oibl_resize_bilinear_nchw": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int,

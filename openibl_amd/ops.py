@@ -465,6 +465,18 @@ def resize_bilinear(x: torch.Tensor, size: Tuple[int, int]) -> torch.Tensor:
 
 
 # ---- matching ---------------------------------------------------------------------------------
+def _pad_dim(x: torch.Tensor) -> torch.Tensor:
+    """Descriptor rows zero-padded to the next multiple of 64 dimensions (the K-tile of the distance
+    kernels): zeros change neither norms nor dot products, so e.g. PCA(pca_n_components=16)
+    descriptors match like the reference's."""
+    d = int(x.shape[1])
+    if d % 64 == 0:
+        return x
+    out = torch.zeros((x.shape[0], d + (-d) % 64), dtype=x.dtype, device=x.device)
+    out[:, :d] = x
+    return out
+
+
 def pairwise_sqdist(x: torch.Tensor, y: torch.Tensor, precision=F32,
                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dist[i][j] = |x_i|^2 + |y_j|^2 - 2 x_i.y_j for x [m][d], y [n][d] stored as float32, float16
@@ -477,10 +489,11 @@ def pairwise_sqdist(x: torch.Tensor, y: torch.Tensor, precision=F32,
     if x.dim() != 2 or y.dim() != 2:
         raise ValueError("pairwise_sqdist expects [m][d] and [n][d]")
     xs, ys = storage_code(x), storage_code(y)
+    if int(y.shape[1]) != int(x.shape[1]):
+        raise ValueError("pairwise_sqdist: dimension mismatch")
+    x, y = _pad_dim(x), _pad_dim(y)
     m, d = map(int, x.shape)
     n = int(y.shape[0])
-    if int(y.shape[1]) != d:
-        raise ValueError("pairwise_sqdist: dimension mismatch")
     if out is None:
         out = torch.empty((m, n), dtype=torch.float32, device=dev)
     if m == 0 or n == 0:
@@ -561,10 +574,11 @@ def sqdist_topk(x: torch.Tensor, y: torch.Tensor, k: int, index_base: int = 0, p
     if x.dim() != 2 or y.dim() != 2:
         raise ValueError("sqdist_topk expects [m][d] and [n][d]")
     xs, ys = storage_code(x), storage_code(y)
+    if int(y.shape[1]) != int(x.shape[1]):
+        raise ValueError("sqdist_topk: dimension mismatch")
+    x, y = _pad_dim(x), _pad_dim(y)
     m, d = map(int, x.shape)
     n = int(y.shape[0])
-    if int(y.shape[1]) != d:
-        raise ValueError("sqdist_topk: dimension mismatch")
     ov = torch.full((m, k), float("inf"), dtype=torch.float32, device=dev)
     oi = torch.full((m, k), -1, dtype=torch.int32, device=dev)
     flag = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -579,6 +593,66 @@ def sqdist_topk(x: torch.Tensor, y: torch.Tensor, k: int, index_base: int = 0, p
         _lib.check(lib.oibl_sqdist_topk_st(_ptr(x), xs, m, _ptr(y), ys, n, d, k, int(index_base), p, ex,
                                            _ptr(ov), _ptr(oi), _ptr(flag), _ptr(ws), ws.numel(),
                                            _stream(dev)), "sqdist_topk")
+
+    if defer_check:
+        run(1 if exact else 0)
+        return ov, oi, flag
+    for ex in ([1] if exact else [0, 1]):
+        run(ex)
+        if ex == 1 or int(flag.item()) == 0:
+            break
+    return ov, oi
+
+
+class PreparedRows:
+    """A descriptor matrix ready for matching in one precision: the rows the contraction reads and
+    their fp32 squared norms (oibl_match_prepare).  Build it once for a matrix that is matched many
+    times — the resident gallery shard — and hand it to sqdist_topk / sharded_topk in place of the
+    tensor: the norm / operand pass (8 % of a 8192 x 81920 matching step) leaves the call."""
+
+    def __init__(self, x: torch.Tensor, precision):
+        p = precision_code(precision)
+        dev = _need_cuda(x)
+        if x.dim() != 2:
+            raise ValueError("PreparedRows expects [rows][d]")
+        x = _pad_dim(x.contiguous())
+        st = storage_code(x)
+        rows, d = map(int, x.shape)
+        self.precision, self.shape, self.device = p, (rows, d), dev
+        self.norms = torch.empty((rows,), dtype=torch.float32, device=dev)
+        self.operand = x
+        if rows == 0:
+            return
+        lib = _lib.load()
+        nbytes = lib.oibl_match_operand_bytes(rows, d, p, st)
+        buf = torch.empty((nbytes,), dtype=torch.uint8, device=dev) if nbytes else None
+        _lib.check(lib.oibl_match_prepare(_ptr(x), st, rows, d, p, _ptr(self.norms), _ptr(buf),
+                                          _stream(dev)), "match_prepare")
+        self._source = x          # read in place when there is no operand copy
+        if buf is not None:
+            self.operand = buf
+
+
+def sqdist_topk_prepared(x: "PreparedRows", y: "PreparedRows", k: int, index_base: int = 0,
+                         exact: bool = False, defer_check: bool = False):
+    """sqdist_topk on prepared operands (same results, bit for bit)."""
+    if x.precision != y.precision or x.shape[1] != y.shape[1]:
+        raise ValueError("sqdist_topk_prepared: operands prepared for different precisions / dimensions")
+    dev, p = x.device, x.precision
+    (m, d), n = x.shape, y.shape[0]
+    ov = torch.full((m, k), float("inf"), dtype=torch.float32, device=dev)
+    oi = torch.full((m, k), -1, dtype=torch.int32, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    if m == 0 or n == 0:
+        return (ov, oi, flag) if defer_check else (ov, oi)
+    lib = _lib.load()
+    ws = workspace(lib.oibl_sqdist_topk_prepared_workspace_bytes(m, n, d, k, p), dev, "sqdist_topk")
+
+    def run(ex: int) -> None:
+        _lib.check(lib.oibl_sqdist_topk_prepared(_ptr(x.operand), _ptr(x.norms), m, _ptr(y.operand),
+                                                 _ptr(y.norms), n, d, k, int(index_base), p, ex, _ptr(ov),
+                                                 _ptr(oi), _ptr(flag), _ptr(ws), ws.numel(), _stream(dev)),
+                   "sqdist_topk_prepared")
 
     if defer_check:
         run(1 if exact else 0)

@@ -50,6 +50,9 @@ def hip_local_topk(q: torch.Tensor, g: torch.Tensor, k: int, index_base: int, pr
         return (torch.full((Q, k), float("inf"), device=q.device),
                 torch.full((Q, k), -1, dtype=torch.int32, device=q.device),
                 torch.zeros(1, dtype=torch.int32, device=q.device))
+    if isinstance(g, ops.PreparedRows):      # resident gallery shard: its norm / operand pass is done
+        qp = q if isinstance(q, ops.PreparedRows) else ops.PreparedRows(q, g.precision)
+        return ops.sqdist_topk_prepared(qp, g, k, index_base=index_base, exact=exact, defer_check=True)
     return ops.sqdist_topk(q, g, k, index_base=index_base, precision=precision, exact=exact,
                            defer_check=True)
 
@@ -75,7 +78,8 @@ def sharded_topk(q_all: torch.Tensor, g_local: torch.Tensor, k: int, index_base:
     """k nearest gallery rows (squared L2) of every query over ALL ranks' gallery slices.
 
     q_all   [Q][d]  the full query set, identical on every rank
-    g_local [n][d]  this rank's valid gallery rows (padding rows removed)
+    g_local [n][d]  this rank's valid gallery rows (padding rows removed), or an ops.PreparedRows of
+                    them (a gallery matched repeatedly pays its norm / operand pass once)
     index_base      global gallery index of g_local[0]
     Returns (values [Q][k] ascending, indices [Q][k] int32 global), identical on every rank.
     Ties are broken towards the lowest global index, so the result does not depend on the number

@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--ablate", type=int, default=0)
     ap.add_argument("--c64", type=int, default=1)
+    ap.add_argument("--layers", type=int, default=13, help="time conv1_1 and the first LAYERS-1 3x3 layers only")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     ops.set_regstage(bool(a.regstage))
@@ -57,7 +58,7 @@ def main():
     t, act = timed(lambda: ops.conv1_1_nchw(x, packed[0], biases[0], p), a.iters)
     rows.append(("conv1_1", t, 2 * N * H * W * 64 * 27))
     h, w = H, W
-    for l in range(1, 13):
+    for l in range(1, min(13, a.layers)):
         cin, cout, relu, pool = ops.VGG16_CFG[l]
         inp = act
         t, act = timed(lambda: ops.conv3x3_nhwc(inp, packed[l], biases[l], bool(relu), bool(pool), p),
@@ -66,6 +67,10 @@ def main():
                      2 * N * h * w * cout * 9 * cin))
         if pool:
             h, w = h // 2, w // 2
+    if a.layers < 13:
+        for name, ms, fl in rows:
+            print(f"  tile={a.tile} {name:34s} {ms:9.3f} ms  {fl / ms / 1e9:9.1f} TFLOP/s")
+        return
     if p == "bf16":
         t, _ = timed(lambda: ops.vgg16_stem(x, packed[0], biases[0], packed[1], biases[1]), a.iters)
         rows.append(("stem fused (conv1_1+conv01)", t, rows[0][2] + rows[1][2]))

@@ -237,3 +237,28 @@ def test_first_hit_rank_equals_host_counting(dev, m, n, k, nms):
         got = recalls_from_topk_device(torch.from_numpy(idx).to(dev), gt, pids, topk, nms)
         np.testing.assert_array_equal(got, want)
         np.testing.assert_array_equal(recalls_from_topk(idx, gt, pids, topk, nms), want)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3", "fp32"])
+@pytest.mark.parametrize("store", [torch.float32, torch.bfloat16, torch.float16])
+def test_prepared_rows_equal_direct_call(dev, precision, store):
+    """A gallery prepared once (oibl_match_prepare) and matched through oibl_sqdist_topk_prepared
+    gives the lists of the all-in-one call bit for bit — fused path (16k gallery) and exact path —
+    and serves sharded_topk as the resident shard."""
+    from openibl_amd import sharded
+    q, gal, gt, _ = synth.retrieval_problem(300, 16384, seed=12)
+    qd = q.to(dev)
+    gd = ops.store_descriptors(gal.to(dev), store)
+    want_v, want_i = ops.sqdist_topk(qd, gd, 10, index_base=7, precision=precision)
+    gp = ops.PreparedRows(gd, precision)
+    qp = ops.PreparedRows(qd, precision)
+    v, i = ops.sqdist_topk_prepared(qp, gp, 10, index_base=7)
+    assert torch.equal(v, want_v) and torch.equal(i, want_i)
+    v, i = ops.sqdist_topk_prepared(qp, gp, 10, index_base=7, exact=True)
+    assert torch.equal(v, want_v) and torch.equal(i, want_i)
+    v, i = sharded.sharded_topk(qd, gp, 10, 7, precision)
+    assert torch.equal(v, want_v) and torch.equal(i, want_i)
+    small = ops.PreparedRows(gd[:100].contiguous(), precision)       # below every fused threshold
+    sv, si = ops.sqdist_topk_prepared(qp, small, 10)
+    wv, wi = ops.sqdist_topk(qd, gd[:100].contiguous(), 10, precision=precision)
+    assert torch.equal(sv, wv) and torch.equal(si, wi)

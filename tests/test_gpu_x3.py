@@ -89,7 +89,7 @@ def test_conv3x3_x3(dev, N, H, W, cin, cout, relu, pool, regstage):
                   _host_conv(x, w, b, relu, pool), TOL_LAYER)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("N,H,W,cin,cout,relu,pool", [
     (2, 12, 20, 64, 64, True, True),
     (3, 37, 45, 64, 64, True, True),      # conv1_2 family: 512 x 64 tile (tile=3), ragged, pooled
