@@ -284,6 +284,15 @@ int oibl_sqdist_topk_prepared(const void* xo, const float* xn, int m, const void
 int oibl_row_topk(const float* vals, const int32_t* idx_in, int m, int n, size_t ld, int k,
                   int index_base, float* out_val, int32_t* out_idx, void* stream);
 
+/* Full-row ranking: out_idx [m][n] int32 = stable ascending argsort of every row of vals [m][ld]
+ * (ties: lowest index first), out_val [m][n] the sorted values (may be NULL).  Replaces
+ * torch.argsort(distmat, dim=1) of the hard-negative mining samplers
+ * (ibl/utils/data/sampler.py:46-54, 126-135) and serves evaluate_all when more than 1024 ranks per
+ * query are needed (np.argsort, ibl/evaluators.py:143).  Per-row radix sort, any n. */
+size_t oibl_row_argsort_workspace_bytes(int m, int n);
+int oibl_row_argsort(const float* vals, int m, int n, size_t ld, int32_t* out_idx, float* out_val,
+                     void* ws, size_t ws_bytes, void* stream);
+
 /* ---- recall counting ---------------------------------------------------------------- *
  * Replaces the per-query Python loop of evaluate_all and spatial_nms
  * (ibl/evaluators.py:132-140, 149-160).  For every query, the rank (0-based, inside the

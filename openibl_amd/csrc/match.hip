@@ -573,6 +573,121 @@ static void launch_row_topk(const float* vals, const int32_t* idx_in, int m, int
 }
 
 // ---------------------------------------------------------------------------------------------
+// Full-row ranking (torch.argsort(distmat, dim=1) of the hard-negative mining samplers,
+// ibl/utils/data/sampler.py:46-54, 126-135, and the unbounded prefix evaluate_all may ask for):
+// stable ascending argsort of every row.  One workgroup (16 waves) per row, least-significant-digit
+// radix sort over the order-preserving 32-bit image of the value, 8 bits per pass, index payload;
+// stability + initial index order = ties broken by lowest index, like the top-k kernels.
+// Per pass: digit histogram of the row -> bin bases; then the row is scattered chunk by chunk
+// (1024 elements) in order: inside a wave the lanes holding the same digit find each other with
+// eight ballots (rank = popcount of the peers below, one leader per digit publishes the count),
+// a per-digit prefix over the 16 waves orders the waves, the bin base orders the chunks.
+// Rows are a few hundred KB: the ping-pong buffers stay in L2.
+// ---------------------------------------------------------------------------------------------
+constexpr int SORT_THREADS = 1024, SORT_WAVES = SORT_THREADS / 64;
+
+struct RowSortParams {
+  const float* vals;
+  size_t ld;
+  int n;
+  uint32_t* key[2];  // [rows][n] ping-pong
+  int32_t* idx[2];
+  int32_t* out_idx;  // [rows][n]
+  float* out_val;    // [rows][n] or nullptr
+};
+
+__global__ __launch_bounds__(SORT_THREADS) void row_radix_sort_kernel(RowSortParams p) {
+  __shared__ unsigned wave_cnt[SORT_WAVES][256];
+  __shared__ unsigned bin_base[256], chunk_base[256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t row = blockIdx.x;
+  const int n = p.n;
+  const float* vr = p.vals + row * p.ld;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 8 * pass;
+    const uint32_t* sk = pass == 0 ? nullptr : p.key[(pass - 1) & 1] + row * n;
+    const int32_t* si = pass == 0 ? nullptr : p.idx[(pass - 1) & 1] + row * n;
+    uint32_t* dk = p.key[pass & 1] + row * n;
+    int32_t* di = pass == 3 ? p.out_idx + row * n : p.idx[pass & 1] + row * n;
+    // ---- histogram -> exclusive bin bases
+    if (tid < 256) bin_base[tid] = 0;
+    __syncthreads();
+    for (int j = tid; j < n; j += SORT_THREADS) {
+      const uint32_t k = pass == 0 ? ordered_bits(vr[j]) : sk[j];
+      atomicAdd(&bin_base[(k >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (wave == 0) {  // 256 bins, 4 per lane: wave-level exclusive scan
+      unsigned c[4], s = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        c[q] = bin_base[4 * lane + q];
+        s += c[q];
+      }
+      unsigned incl = s;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+      }
+      unsigned run = incl - s;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        bin_base[4 * lane + q] = run;
+        run += c[q];
+      }
+    }
+    __syncthreads();
+    // ---- ordered scatter, 1024 elements at a time
+    for (int j0 = 0; j0 < n; j0 += SORT_THREADS) {
+      for (int i = tid; i < SORT_WAVES * 256; i += SORT_THREADS) (&wave_cnt[0][0])[i] = 0;
+      __syncthreads();
+      const int j = j0 + tid;
+      const bool act = j < n;
+      uint32_t k = 0;
+      int32_t id = 0;
+      if (act) {
+        k = pass == 0 ? ordered_bits(vr[j]) : sk[j];
+        id = pass == 0 ? j : si[j];
+      }
+      const unsigned dg = (k >> shift) & 255u;
+      unsigned long long peers = __ballot(act);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const unsigned long long m = __ballot(act && ((dg >> b) & 1u));
+        peers &= ((dg >> b) & 1u) ? m : ~m;
+      }
+      const unsigned long long below = peers & ((1ull << lane) - 1ull);
+      const unsigned rank = (unsigned)__popcll(below);
+      if (act && below == 0) wave_cnt[wave][dg] = (unsigned)__popcll(peers);
+      __syncthreads();
+      if (tid < 256) {
+        unsigned run = 0;
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) {
+          const unsigned c = wave_cnt[w][tid];
+          wave_cnt[w][tid] = run;
+          run += c;
+        }
+        chunk_base[tid] = bin_base[tid];
+        bin_base[tid] += run;
+      }
+      __syncthreads();
+      if (act) {
+        const unsigned pos = chunk_base[dg] + wave_cnt[wave][dg] + rank;
+        di[pos] = id;
+        if (pass < 3)
+          dk[pos] = k;
+        else if (p.out_val)
+          p.out_val[row * n + pos] = from_ordered_bits(k);
+      }
+      __syncthreads();
+    }
+    __threadfence_block();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Recall counting on the device (evaluate_all / spatial_nms, ibl/evaluators.py:132-160).
 // Per query: the rank, inside the prediction list the reference would build, of the first
 // prediction that is a ground-truth neighbour (-1: none).  Recall@N for every N follows on the
@@ -1067,6 +1182,38 @@ int oibl_first_hit_rank(const int32_t* topk_idx, int m, int k, const int32_t* gt
   OIBL_REQUIRE(!gallery_pids || nms_window >= 1, "first_hit_rank: nms_window must be >= 1");
   hipLaunchKernelGGL(first_hit_rank_kernel, dim3((m + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                      topk_idx, m, k, gt_offsets, gt_values, gallery_pids, nms_window, out_rank);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
+
+size_t oibl_row_argsort_workspace_bytes(int m, int n) {
+  if (m <= 0 || n <= 0) return 0;
+  return 4 * align_up((size_t)m * n * 4, 256);
+}
+
+int oibl_row_argsort(const float* vals, int m, int n, size_t ld, int32_t* out_idx, float* out_val,
+                     void* ws, size_t ws_bytes, void* stream) {
+  OIBL_REQUIRE(vals && out_idx && ws, "row_argsort: null pointer");
+  OIBL_REQUIRE(m > 0 && n > 0 && ld >= (size_t)n, "row_argsort: bad shape m=%d n=%d ld=%zu", m, n, ld);
+  OIBL_REQUIRE((uintptr_t)ws % 256 == 0, "row_argsort: workspace must be 256-byte aligned");
+  const size_t need = oibl_row_argsort_workspace_bytes(m, n);
+  if (ws_bytes < need) {
+    set_error("row_argsort: workspace %zu < required %zu bytes", ws_bytes, need);
+    return OIBL_E_WORKSPACE;
+  }
+  const size_t part = align_up((size_t)m * n * 4, 256);
+  char* w = (char*)ws;
+  RowSortParams p;
+  p.vals = vals;
+  p.ld = ld;
+  p.n = n;
+  p.key[0] = (uint32_t*)w;
+  p.key[1] = (uint32_t*)(w + part);
+  p.idx[0] = (int32_t*)(w + 2 * part);
+  p.idx[1] = (int32_t*)(w + 3 * part);
+  p.out_idx = out_idx;
+  p.out_val = out_val;
+  hipLaunchKernelGGL(row_radix_sort_kernel, dim3((unsigned)m), dim3(SORT_THREADS), 0, (hipStream_t)stream, p);
   OIBL_LAUNCH_CHECK();
   return OIBL_OK;
 }

@@ -277,12 +277,17 @@ def evaluate_all(distmat, gt, gallery, recall_topk=[1, 5, 10], nms=False):
     rank, _ = _rank_world()
     d = _to_tensor(distmat).float()
     k = min(max(recall_topk) * (12 if nms else 1), d.shape[1])
-    _check_prefix(k)
     dev = _device()
-    _, idx = ops.row_topk(d.to(dev).contiguous(), k)
     if rank == 0:
         print("===> Start calculating recalls")
-    recalls = recalls_from_topk_device(idx, gt, [g[1] for g in gallery], recall_topk, nms)
+    if k <= MAX_RANK_PREFIX:
+        _, idx = ops.row_topk(d.to(dev).contiguous(), k)
+        recalls = recalls_from_topk_device(idx, gt, [g[1] for g in gallery], recall_topk, nms)
+    else:
+        # more ranks than the selection kernels keep: full-row ranking on the device
+        # (oibl_row_argsort), counting with the host loop of the reference
+        idx = ops.row_argsort(d.to(dev).contiguous())[:, :k].cpu().numpy()
+        recalls = recalls_from_topk(idx, gt, [g[1] for g in gallery], recall_topk, nms)
     if rank == 0:
         _print_recalls(recalls, recall_topk)
     return recalls

@@ -526,6 +526,30 @@ def row_topk(vals: torch.Tensor, k: int, index_base: int = 0,
     return ov, oi
 
 
+def row_argsort(vals: torch.Tensor, want_values: bool = False, max_ws_bytes: int = 1 << 31):
+    """Stable ascending argsort of every row of a float32 [m][n] device matrix -> int32 [m][n]
+    (and the sorted values): torch.argsort(vals, dim=1, stable=True) on the GPU (oibl_row_argsort).
+    Rows are sorted in groups so that the ping-pong workspace (16 bytes per element) stays below
+    `max_ws_bytes`."""
+    dev = _need_cuda(vals)
+    if vals.dtype != torch.float32 or vals.dim() != 2 or vals.stride(1) != 1:
+        raise ValueError("row_argsort expects a float32 [m][n] tensor with unit column stride")
+    m, n = map(int, vals.shape)
+    idx = torch.empty((m, n), dtype=torch.int32, device=dev)
+    sv = torch.empty((m, n), dtype=torch.float32, device=dev) if want_values else None
+    if m == 0 or n == 0:
+        return (idx, sv) if want_values else idx
+    lib = _lib.load()
+    rows = max(1, min(m, int(max_ws_bytes // (16 * n + 1024))))
+    ws = workspace(lib.oibl_row_argsort_workspace_bytes(rows, n), dev, "argsort")
+    for r0 in range(0, m, rows):
+        r = min(rows, m - r0)
+        _lib.check(lib.oibl_row_argsort(vals[r0:].data_ptr(), r, n, int(vals.stride(0)),
+                                        idx[r0:].data_ptr(), None if sv is None else sv[r0:].data_ptr(),
+                                        _ptr(ws), ws.numel(), _stream(dev)), "row_argsort")
+    return (idx, sv) if want_values else idx
+
+
 def first_hit_rank(topk_idx: torch.Tensor, gt_offsets: torch.Tensor, gt_values: torch.Tensor,
                    gallery_pids: Optional[torch.Tensor] = None, nms_window: int = 120) -> torch.Tensor:
     """Per query: rank of the first prediction that is a ground-truth neighbour (-1: none), with

@@ -156,3 +156,13 @@ def retrieval_problem(num_query: int, num_gallery: int, dim: int = PCA_DIM, seed
         gt.append(sorted(int(j) for j in slots[i]))
     pids = [int(j // views_per_place) for j in range(num_gallery)]
     return torch.from_numpy(q), torch.from_numpy(g), gt, pids
+
+
+def tie_free_matrix(rows: int, cols: int, seed: int = 41, scale: float = 4.0) -> torch.Tensor:
+    """float32 [rows][cols] "distance" matrix whose rows are jittered permutations: every row holds
+    distinct values in [0, scale), so its argsort is unique (the mining samplers' torch.argsort and
+    np.argsort leave the order of ties unspecified)."""
+    rng = np.random.default_rng([seed, 9])
+    m = np.stack([(rng.permutation(cols) + rng.uniform(0.0, 0.4, size=cols)) * (scale / cols)
+                  for _ in range(rows)]).astype(np.float32)
+    return torch.from_numpy(m)

@@ -10,6 +10,7 @@ What is exercised, all through the reference's own code objects:
   ibl.evaluators.extract_cnn_feature                                 (evaluators.py:22-34)
   ibl.pca.PCA.load / PCA.infer                                       (pca.py:86-123)
   ibl.evaluators.pairwise_distance / evaluate_all / spatial_nms      (evaluators.py:105-167)
+  ibl.utils.data.sampler.DistributedRandomTupleSampler.sort_gallery  (sampler.py:46-54)
 Two things have to be faked for the reference to run on a CPU-only box without h5py: `Tensor.cuda`
 is patched to the identity, and `h5py.File` is served from an in-memory dict.
 """
@@ -182,6 +183,20 @@ def main():
         np.savez_compressed(OUT / f"{name}.npz", Q=Q, G=G, dim=dim, seed=seed, **outs)
         print(name, {k: v.shape for k, v in outs.items()})
 
+    def run_sort_gallery(name, Q, G, seed):
+        """DistributedRandomTupleSampler.sort_gallery (ibl/utils/data/sampler.py:46-54): the full-row
+        torch.argsort the hard-negative mining consumes, on a tie-free seeded matrix."""
+        from ibl.utils.data.sampler import DistributedRandomTupleSampler
+        distmat = synth.tie_free_matrix(Q, G, seed)    # a jittered permutation per row
+        assert all(len(np.unique(r)) == G for r in distmat.numpy()), "ties: argsort order unspecified"
+        smp = DistributedRandomTupleSampler(list(range(Q)), list(range(G)), [[0]] * Q, [[0]] * Q,
+                                            num_replicas=1, rank=0)
+        smp.sort_gallery(distmat, list(range(Q)))
+        np.savez_compressed(OUT / f"{name}.npz", Q=Q, G=G, seed=seed,
+                            sort_idx=smp.sort_idx.numpy().astype(np.int16))
+        print(name, tuple(smp.sort_idx.shape))
+
+    run_sort_gallery("sort_gallery", 10, 2500, seed=41)
     run_rerank("rerank_small", 24, 90, seed=31)
     run_matching("match_small", 48, 300, seed=21, views_per_place=1)
     run_matching("match_nms", 40, 360, seed=22, views_per_place=12)

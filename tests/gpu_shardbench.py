@@ -29,11 +29,13 @@ def timed(fn, iters=10, warm=3):
 
 
 worlds = [int(w) for w in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1, 2, 4, 8]
+prec = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 base = None
+print(f"precision {prec}; the gallery shard is resident (ops.PreparedRows), the queries are prepared per call")
 for world in worlds:
     n = G // world
-    shard = gal[:n].contiguous()
-    t = timed(lambda: ops.sqdist_topk(q, shard, K, precision="bf16", defer_check=True))   # as sharded.py
+    shard = ops.PreparedRows(gal[:n].contiguous(), prec)
+    t = timed(lambda: ops.sqdist_topk_prepared(ops.PreparedRows(q, prec), shard, K, defer_check=True))  # as sharded.py
     vals = torch.randn((Q, world * K), device=dev)
     idx = torch.randint(0, G, (Q, world * K), device=dev, dtype=torch.int32)
     tm = timed(lambda: ops.row_topk(vals, K, idx_in=idx)) if world > 1 else 0.0

@@ -262,3 +262,44 @@ def test_prepared_rows_equal_direct_call(dev, precision, store):
     sv, si = ops.sqdist_topk_prepared(qp, small, 10)
     wv, wi = ops.sqdist_topk(qd, gd[:100].contiguous(), 10, precision=precision)
     assert torch.equal(sv, wv) and torch.equal(si, wi)
+
+
+def test_row_argsort_matches_reference_sort_gallery(dev):
+    """oibl_row_argsort == the ranking the reference's sampler builds (golden from the reference's own
+    sort_gallery), plus: stability on ties, sorted values, ragged sizes, strided input, chunked rows."""
+    g = load_golden("sort_gallery")
+    d = synth.tie_free_matrix(int(g["Q"]), int(g["G"]), int(g["seed"]))
+    idx, vals = ops.row_argsort(d.to(dev), want_values=True)
+    assert np.array_equal(idx.cpu().numpy(), g["sort_idx"].astype(np.int32))
+    assert torch.equal(vals.cpu(), torch.sort(d, dim=1).values)
+    rng = np.random.default_rng(0)
+    for m, n in ((3, 1), (5, 63), (4, 1024), (2, 1025), (3, 5000), (1, 100003), (70, 777)):
+        # few distinct values (many ties), negatives, +-0, inf
+        x = torch.from_numpy(rng.integers(-3, 4, size=(m, n)).astype(np.float32) * 0.5)
+        if n > 4:
+            x[0, 1], x[0, 2], x[0, 3] = float("inf"), -0.0, float("-inf")
+        want = torch.argsort(x, dim=1, stable=True)
+        got = ops.row_argsort(x.to(dev), max_ws_bytes=(1 << 20) if m == 70 else (1 << 31))
+        # -0.0 and +0.0 compare equal in torch; the kernel orders bit patterns (-0.0 first): compare
+        # through the values, and exactly where no signed zero is involved
+        assert torch.equal(torch.gather(x, 1, got.cpu().long()), torch.gather(x, 1, want))
+        xz = x.clone()
+        xz[xz == 0] = 0.0
+        got2 = ops.row_argsort(xz.to(dev))
+        assert torch.equal(got2.cpu().long(), torch.argsort(xz, dim=1, stable=True))
+    big = torch.from_numpy(rng.standard_normal((6, 300)).astype(np.float32)).to(dev)
+    view = big[:, :200]                                   # row stride 300, 200 columns
+    assert torch.equal(ops.row_argsort(view).cpu().long(), torch.argsort(view.cpu(), dim=1, stable=True))
+
+
+def test_evaluate_all_beyond_1024_ranks(dev):
+    """recall_topk whose prefix exceeds the selection kernels' 1024 ranks: full-row device ranking,
+    same numbers as the oracle's restatement of evaluators.py:142-167."""
+    from ibl.evaluators import evaluate_all
+    q, gal, gt, pids = synth.retrieval_problem(40, 3000, dim=256, seed=5, views_per_place=12)
+    d = om.pairwise_distance(q, gal)
+    gallery = [(f"g{j}", pids[j], 0.0, 0.0) for j in range(len(gal))]
+    for topk, nms in (((1, 10, 100), True), ((1, 5, 1500), False)):
+        got = evaluate_all(d, gt, gallery, recall_topk=list(topk), nms=nms)
+        want = om.evaluate_all(d.numpy(), gt, pids, recall_topk=topk, nms=nms)
+        np.testing.assert_array_equal(got, want)

@@ -84,3 +84,12 @@ def test_matching_matches_reference(name):
     for i, row in enumerate(g["nms_rows"]):
         want = [int(v) for v in row if v >= 0]
         assert om.spatial_nms(order[i].tolist(), pids, 120) == want
+
+
+def test_full_row_ranking_matches_reference_sort_gallery():
+    """oracle.matching.ranking == the sort_idx the reference's DistributedRandomTupleSampler
+    .sort_gallery produced (torch.argsort, ibl/utils/data/sampler.py:46-54) on a tie-free matrix."""
+    g = load_golden("sort_gallery")
+    d = synth.tie_free_matrix(int(g["Q"]), int(g["G"]), int(g["seed"]))
+    assert all(len(np.unique(r)) == d.shape[1] for r in d.numpy())
+    assert np.array_equal(om.ranking(d.numpy()), g["sort_idx"].astype(np.int64))
