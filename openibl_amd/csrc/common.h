@@ -184,4 +184,29 @@ __device__ static inline unsigned xcd_remap(unsigned bid, unsigned nblk) {
   return start + idx;
 }
 
+// XCD-aware tile rasterisation for a tiles_m x tiles_n grid of output tiles (block b runs on XCD
+// b % 8, each XCD has its own 4 MiB L2).
+//   raster 0: every XCD gets a contiguous range of tile ids, N-tile fastest — the tiles of an XCD
+//             share their M panels (activations) but cycle through ALL N panels (weights);
+//   raster 1 (tiles_n divides 8): an XCD serves ONE N-tile — its weight panel (2.36 MB for a
+//             512-channel layer at BN = 256) stays resident in that L2 next to a contiguous range of
+//             M panels; an M panel is then fetched by tiles_n XCDs instead of one.
+// Both are bijections between blocks and tiles (the per-XCD block counts of the hardware's
+// round-robin deal equal the per-XCD tile counts of the split: nblk = tiles_m * tiles_n,
+// 8 = G * tiles_n  =>  nblk / 8 = tiles_m / G and nblk % 8 = (tiles_m % G) * tiles_n).
+__device__ static inline void xcd_tile(unsigned bid, unsigned tiles_m, unsigned tiles_n, int raster,
+                                       int& tm, int& tn) {
+  if (raster == 1 && tiles_n > 1 && tiles_n <= 8 && (8u % tiles_n) == 0u) {
+    const unsigned xcd = bid & 7u, idx = bid >> 3;
+    const unsigned G = 8u / tiles_n, g = xcd / tiles_n;
+    const unsigned q = tiles_m / G, r = tiles_m % G;
+    tn = (int)(xcd % tiles_n);
+    tm = (int)(g * q + (g < r ? g : r) + idx);
+    return;
+  }
+  const unsigned tile = xcd_remap(bid, tiles_m * tiles_n);
+  tn = (int)(tile % tiles_n);
+  tm = (int)(tile / tiles_n);
+}
+
 }  // namespace oibl

@@ -492,6 +492,7 @@ static int launch_conv_cfg(const ConvParams& p, hipStream_t st) {
                     : launch_conv_kernel<Cfg, POOL, true>(q, grid, st);
 }
 
+static int g_ring_raster = 0;                     // test hook: xcd_tile() mode of the ring kernels
 static unsigned long long* g_prof_buf = nullptr;  // test hook: phase profile of block 0
 static int g_ring_ablate = 0;                     // test hook: see RingParams::ablate
 
@@ -526,6 +527,8 @@ static int launch_conv_ring_impl(const ConvParams& p, hipStream_t st) {
   }
   const long tiles_m = (p.m_total + G::BM - 1) / G::BM;
   const long grid = tiles_m * q.tiles_n;
+  q.tiles_m = (int)tiles_m;
+  q.raster = g_ring_raster;
   constexpr int lds = ring_lds_bytes<WM, POOL, X3>();
   auto kern = conv3x3_ring_kernel<WM, POOL, ODD, X3>;
   OIBL_SET_MAX_LDS(kern, lds);
@@ -1524,6 +1527,11 @@ int oibl_debug_set_conv_ablate(int mode) {
 
 int oibl_debug_set_ring_ablate(int mode) {
   g_ring_ablate = mode;
+  return OIBL_OK;
+}
+
+int oibl_debug_set_ring_raster(int mode) {
+  g_ring_raster = mode;
   return OIBL_OK;
 }
 

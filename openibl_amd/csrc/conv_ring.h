@@ -39,6 +39,8 @@ struct RingParams {
   int ablate;  // timing experiments only (WRONG results): 1 = pixel loads of taps != 0 all hit one
                // line, 2 = weight loads after the first K-tile all hit one line, 3 = both
   int out_f32;  // X3, !POOL only: write plain fp32 NHWC instead of the (hi, lo) groups
+  int tiles_m;
+  int raster;   // xcd_tile() mode
 };
 
 // mul, sh with floor(m / d) == (m * mul) >> sh for every m < 2^31 (d >= 1):  sh = 31 + ceil(log2 d),
@@ -199,8 +201,8 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
   const int wm = wave / G::WN, wn = wave % G::WN;
   const bool prof = p.prof != nullptr && blockIdx.x == 0 && wave == 0;
   const unsigned long long t_start = prof ? __builtin_amdgcn_s_memtime() : 0;
-  const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+  int tm, tn;
+  xcd_tile(blockIdx.x, (unsigned)p.tiles_m, (unsigned)p.tiles_n, p.raster, tm, tn);
   const int m0 = tm * G::BM, n0 = tn * G::BN;
   const int nsteps = 9 * (p.cin >> (X3 ? 5 : 6));
 

@@ -156,6 +156,12 @@ def set_conv_tile(mode: int) -> None:
     _lib.load().oibl_debug_set_conv_tile(int(mode))
 
 
+def set_ring_raster(mode: int) -> None:
+    """Test hook: tile rasterisation of the ring convolutions (0 = contiguous ids per XCD, 1 = one
+    N-tile per XCD, see xcd_tile in csrc/common.h).  Results do not depend on it."""
+    _lib.load().oibl_debug_set_ring_raster(int(mode))
+
+
 def set_conv_c64(on) -> None:
     """Test hook: resident-weights kernel for Cin = 64 layers (bf16): False/0 = never, True/1 = auto
     (Cout = 64 only; wider layers go to the ring kernel), 2 = every Cin = 64 layer."""
@@ -531,8 +537,10 @@ def row_argsort(vals: torch.Tensor, want_values: bool = False, max_ws_bytes: int
     (and the sorted values): torch.argsort(vals, dim=1, stable=True) on the GPU (oibl_row_argsort).
     Rows are sorted in groups so that the ping-pong workspace (16 bytes per element) stays below
     `max_ws_bytes`."""
-    dev = _need_cuda(vals)
-    if vals.dtype != torch.float32 or vals.dim() != 2 or vals.stride(1) != 1:
+    if not vals.is_cuda:
+        raise _lib.OpenIBLAmdError("openibl_amd: row_argsort runs only on an AMD GPU (there is no CPU fallback)")
+    dev = vals.device
+    if vals.dtype != torch.float32 or vals.dim() != 2 or (vals.shape[1] > 1 and vals.stride(1) != 1):
         raise ValueError("row_argsort expects a float32 [m][n] tensor with unit column stride")
     m, n = map(int, vals.shape)
     idx = torch.empty((m, n), dtype=torch.int32, device=dev)

@@ -208,3 +208,28 @@ def test_vgg16_backbone_stem_toggle(dev):
     finally:
         ops.set_stem_fused(True)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("N,H,W,cin,cout,relu,pool", [
+    (5, 21, 19, 128, 512, True, False),    # 8 M tiles x 2 N tiles
+    (3, 33, 21, 256, 512, True, True),     # ragged: 9 x 2
+    (7, 30, 40, 512, 512, False, False),   # conv5 shape, 33 x 2 tiles (odd count per N-tile group)
+    (2, 40, 30, 256, 256, True, False),    # one N-tile: raster 1 == raster 0 mapping
+])
+def test_ring_raster_modes_agree(dev, N, H, W, cin, cout, relu, pool, precision):
+    """One N-tile per XCD (raster 1) is a permutation of the tile order: same tensor, bit for bit."""
+    x, w, b = _case(N, H, W, cin, cout, seed=7 + H)
+    xd = ops.nchw_f32_to_nhwc(x.to(dev), "fp32" if precision == "bf16x3" else precision)
+    if precision == "bf16x3":
+        xd = ops.x3_split(xd)
+    wp = ops.pack_conv3x3(w.to(dev), precision)
+    ops.set_conv_tile(4)
+    try:
+        ref = ops.conv3x3_nhwc(xd, wp, b.to(dev), relu, pool, precision)
+        ops.set_ring_raster(1)
+        y = ops.conv3x3_nhwc(xd, wp, b.to(dev), relu, pool, precision)
+    finally:
+        ops.set_ring_raster(0)
+        ops.set_conv_tile(0)
+    assert torch.equal(y, ref)

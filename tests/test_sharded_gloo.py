@@ -24,6 +24,22 @@ def _oracle_local_topk(q, g, k, index_base, precision):
     return vals, idx
 
 
+class _ResidentShard:
+    """CPU stand-in for ops.PreparedRows (the gallery shard prepared once: operand rows + norms):
+    sharded_topk must hand whatever object represents the resident shard to the local step as is."""
+
+    def __init__(self, rows):
+        self.rows, self.shape = rows, tuple(rows.shape)
+        self.norms = (rows.double() ** 2).sum(1).float()
+        self.uses = 0
+
+
+def _resident_local_topk(q, shard, k, index_base, precision):
+    assert isinstance(shard, _ResidentShard)
+    shard.uses += 1
+    return _oracle_local_topk(q, shard.rows, k, index_base, precision)
+
+
 def _overflowing_local_topk(q, g, k, index_base, precision, exact=False):
     """Stand-in for the fused GPU path: rank 1's first (non-exact) attempt overflows and returns
     garbage lists with the flag raised; the exact repeat is correct on every rank."""
@@ -64,6 +80,13 @@ def _worker(rank, world, port, G, ret):
                                       local_topk_fn=_overflowing_local_topk, merge_fn=_oracle_merge)
         ok_topk = ok_topk and _overflowing_local_topk.calls == [False, True] and \
             bool(np.array_equal(i2.numpy(), wi) and np.allclose(v2.numpy(), wv))
+        # the resident-shard object (prepared once, matched against several query batches)
+        shard = _ResidentShard(g[start:start + n_valid])
+        for qs in (q, q[:7]):
+            v3, i3 = sharded.sharded_topk(qs, shard, 10, start, local_topk_fn=_resident_local_topk,
+                                          merge_fn=_oracle_merge)
+            ok_topk = ok_topk and bool(np.array_equal(i3.numpy(), wi[: len(qs)]))
+        ok_topk = ok_topk and shard.uses == 2
         rec = evaluators.recalls_from_topk(idx.numpy(), gt)
         ok_rec = bool(np.array_equal(rec, om.evaluate_all(d, gt, pids)))
 

@@ -63,7 +63,8 @@ def main():
                     "--steps 10 --warmup 2 (RCCL group with one rank)\n"
                     + "\n".join(l for l in (d / "bench_torchrun.json").read_text().splitlines()
                                 if l.startswith("{")) + "\n\n")
-        for n in ("gpu.txt", "timing_bf16.log", "timing_fp32.log", "pcie.log", "convbench.log", "shardbench.log"):
+        for n in ("gpu.txt", "timing_bf16x3.log", "timing_bf16.log", "timing_bf16x3_raster1.log",
+                  "timing_bf16_raster1.log", "timing_fp32.log", "pcie.log", "convbench.log", "shardbench.log"):
             if (d / n).exists():
                 f.write(f"==== {n}\n" + (d / n).read_text() + "\n")
         if (d / "pytest_gpu.log").exists():
@@ -71,19 +72,68 @@ def main():
                     + "\n".join((d / "pytest_gpu.log").read_text().splitlines()[-4:]) + "\n")
         if (d / "smoke.log").exists():
             f.write("==== smoke\n" + "\n".join((d / "smoke.log").read_text().splitlines()[-2:]) + "\n")
-    for sub, title in (
-            ("prof_stats", "python bench.py --steps 40 --warmup 5 --skip-matching --skip-cpu-baseline"),
-            ("prof_match", "python bench.py --steps 2 --warmup 1 --skip-cpu-baseline (with matching)")):
+    if (d / "latency.md").exists():
+        (prof / f"{tag}_latency.md").write_text(
+            f"# {tag}: single-image latency (tests/gpu_latency.py; medians / minima over 40 device-synchronised calls)\n\n"
+            + (d / "latency.md").read_text())
+    sustain_md(d, prof, tag)
+    skip = "--skip-matching --skip-cpu-baseline --skip-api --skip-fast-mode"
+    for sub, name, title in (
+            ("prof_stats", f"{tag}_kernel_stats.md", "python bench.py --steps 40 --warmup 5 --skip-matching --skip-cpu-baseline"),
+            ("prof_stats_bf16x3", f"{tag}_kernel_stats_bf16x3.md", f"python bench.py --precision bf16x3 --steps 40 --warmup 5 {skip}"),
+            ("prof_stats_bf16", f"{tag}_kernel_stats_bf16.md", f"python bench.py --precision bf16 --steps 40 --warmup 5 {skip}"),
+            ("prof_match", f"{tag}_kernel_stats_matching.md", "python bench.py --steps 2 --warmup 1 --skip-cpu-baseline --skip-api (with matching, both modes)")):
         p = d / sub / "bench_kernel_stats.csv"
         if p.exists():
             lines = [f"# {tag}: rocprofv3 --kernel-trace --stats -- {title}", "", a.note, ""] + kernel_stats(p)
-            name = f"{tag}_kernel_stats.md" if sub == "prof_stats" else f"{tag}_kernel_stats_matching.md"
             (prof / name).write_text("\n".join(lines) + "\n")
-    fp = d / "prof_fetch" / "bench_counter_collection.csv"
-    wp = d / "prof_write" / "bench_counter_collection.csv"
-    if fp.exists() and wp.exists():
+    digest = {}
+    for prec in ("", "bf16x3", "bf16"):
+        sfx = f"_{prec}" if prec else ""
+        fp = d / f"prof_fetch{sfx}" / "bench_counter_collection.csv"
+        wp = d / f"prof_write{sfx}" / "bench_counter_collection.csv"
+        if fp.exists() and wp.exists():
+            ent = traffic_table(fp, wp, prof, tag, prec)
+            if ent:
+                digest[prec or "bf16"] = ent
+    if digest:
+        import json
+        (prof / "hbm_traffic_latest.json").write_text(json.dumps(digest, indent=1) + "\n")
+    print("wrote", sorted(p.name for p in prof.glob(f"{tag}_*")))
+
+
+def sustain_md(d, prof, tag):
+    import json
+    out = []
+    for prec in ("bf16x3", "bf16"):
+        p = d / f"sustain_{prec}.json"
+        if not p.exists():
+            continue
+        try:
+            s = json.loads([l for l in p.read_text().splitlines() if l.startswith("{")][-1])
+        except Exception:
+            continue
+        out += [f"## {prec}: `python bench.py --sustain 12 --precision {prec}` — {s['seconds']} s of back-to-back "
+                f"pipelined replays of the timed step (batch 32, 480x640)", "",
+                f"images/s per ~1 s chunk: min {s['min']}, mean {s['mean']}, max {s['max']}", "",
+                "| t (s) | images/s |", "|---|---|"]
+        out += [f"| {t} | {r} |" for t, r in s["images_per_s_per_chunk"]]
+        out += ["", "| t (s) | sclk | socket power (W) | junction temp (C) |", "|---|---|---|---|"]
+        for r in s["rocm_smi"]:
+            out.append(f"| {r.get('t')} | {r.get('sclk clock speed:', '')} | "
+                       f"{r.get('Current Socket Graphics Package Power (W)', '')} | "
+                       f"{r.get('Temperature (Sensor junction) (C)', '')} |")
+        out.append("")
+    if out:
+        (prof / f"{tag}_sustain.md").write_text(
+            f"# {tag}: sustained throughput with GPU clock / power (rocm-smi sampled once per second)\n\n"
+            + "\n".join(out) + "\n")
+
+
+def traffic_table(fp, wp, prof, tag, prec):
+    if True:
         fe, wr = counter_avg(fp, "FETCH_SIZE"), counter_avg(wp, "WRITE_SIZE")
-        lines = [f"# {tag}: HBM traffic per launch (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)",
+        lines = [f"# {tag} {prec}: HBM traffic per launch (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)",
                  "",
                  "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of a wide coalesced read); "
                  "MB = 1e6 bytes; GB/s over the kernel's own duration in the FETCH pass.", "",
@@ -99,10 +149,9 @@ def main():
             us = t / n / 1e3
             lines.append(f"| `{short(k)}` | {n} | {f_raw:.1f} | {2 * f_raw:.1f} | {w_mb:.1f} | {us:.1f} | "
                          f"{(2 * f_raw + w_mb) / us * 1e3:.0f} |")
-        (prof / f"{tag}_hbm_traffic.md").write_text("\n".join(lines) + "\n")
+        (prof / (f"{tag}_hbm_traffic_{prec}.md" if prec else f"{tag}_hbm_traffic.md")).write_text("\n".join(lines) + "\n")
         # machine-readable digest for bench.py's roofline.traffic: corrected HBM bytes of the
         # matrix-core convolution launches, averaged per launch
-        import json
         tot_b, tot_n = 0.0, 0
         for k, (n, v, t) in fe.items():
             if not any(tag_ in k for tag_ in ("conv3x3_ring_kernel", "vgg_stem_kernel", "conv3x3_igemm_kernel",
@@ -112,11 +161,11 @@ def main():
             tot_b += 2 * v * 1024 + w[1] * 1024 * (n / max(w[0], 1))
             tot_n += n
         if tot_n:
-            (prof / "hbm_traffic_latest.json").write_text(json.dumps({
-                "source": f"profiles/{tag}_hbm_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
-                          "FETCH doubled per MI355X_MICROARCH.md; counts Infinity-Cache hits)",
-                "conv_launches": tot_n, "bytes_per_launch": tot_b / tot_n}, indent=1) + "\n")
-    print("wrote", sorted(p.name for p in prof.glob(f"{tag}_*")))
+            name = f"{tag}_hbm_traffic_{prec}.md" if prec else f"{tag}_hbm_traffic.md"
+            return {"source": f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                              "FETCH doubled per MI355X_MICROARCH.md; counts Infinity-Cache hits)",
+                    "conv_launches": tot_n, "bytes_per_launch": tot_b / tot_n}
+    return None
 
 
 if __name__ == "__main__":
