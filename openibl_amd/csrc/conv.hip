@@ -252,9 +252,10 @@ __global__ __launch_bounds__(256) void conv1_1_mfma_kernel(const float* __restri
 
 // ---------------------------------------------------------------------------------------------
 // implicit-GEMM 3x3 convolution
-//   M = output pixels, N = Cout, K = 9 * Cin ordered (tap, cin).  A K-step is one tap x one
-//   128-byte run of input channels of each pixel, fetched straight from the NHWC tensor (or from a
-//   zero line when the tap falls outside the image).
+//   M = output pixels, N = Cout, K = 9 * Cin ordered (128-byte channel chunk, tap, channel).  A
+//   K-step is one tap x one 128-byte run of input channels of each pixel, fetched straight from the
+//   NHWC tensor (or from a zero line when the tap falls outside the image); the nine taps of a chunk
+//   are consecutive K-steps so that horizontally adjacent taps find their lines in L2.
 //   POOL: pixels are enumerated quad-major (m = 4*quad + 2*dy + dx over the floor(H/2) x floor(W/2)
 //   pooled grid), so that the four members of a 2x2 window are 4 consecutive GEMM rows = registers
 //   4g..4g+3 of one lane in the 32x32 accumulator layout: the pool is an in-register max and the
@@ -341,12 +342,13 @@ struct ConvALoader {
     return ((mask[j] >> tap) & 1u) ? base[j] + tap_off + cc * 128 : zero;
   }
   __device__ inline bool active() const { return !((ablate & 1) && tap != 0); }
+  // K order: channel chunk outer, tap inner (see ConvRingALoader::begin_tile)
   __device__ inline void next() {
-    if (++cc == cchunks) {
-      cc = 0;
-      if (++tap == 9) tap = 0;
-      tap_off = (long)((tap / 3 - 1) * W + (tap % 3 - 1)) * pix_bytes;
+    if (++tap == 9) {
+      tap = 0;
+      ++cc;
     }
+    tap_off = (long)((tap / 3 - 1) * W + (tap % 3 - 1)) * pix_bytes;
   }
 };
 
@@ -375,9 +377,9 @@ struct ConvBLoader {
   __device__ inline const char* src(int j) const { return p0[j] + off; }
   __device__ inline void next() {
     ++step;
-    if (++cc == cchunks) {
-      cc = 0;
-      if (++tap == 9) tap = 0;
+    if (++tap == 9) {
+      tap = 0;
+      ++cc;
     }
     off = tap * tap_stride + cc * 128;
   }
@@ -402,11 +404,8 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void conv3x3_igemm_kernel(ConvParams
 
   ConvALoader<Cfg, POOL> la;
   ConvBLoader<Cfg> lb;
-  // ablate bit 2 (experiment): start the tap loop at a per-tile offset so that concurrently
-  // running workgroups do not all stream the same weight lines at the same time
-  const int tap0 = (p.ablate & 4) ? (tm % 9) : 0;
-  la.init(c, p, m0, tap0);
-  lb.init(c, p, n0, tap0);
+  la.init(c, p, m0, 0);
+  lb.init(c, p, n0, 0);
 
   // accumulators start at the bias (every kernel of this file orders the sum that way, so that
   // all variants of a layer produce identical bits)

@@ -2,8 +2,9 @@
 // (Cout % 256 == 0) or 512 x 128 tile (Cout % 128 == 0).
 //
 // Same contraction and the same summation order as conv3x3_igemm_kernel (conv.hip): M = output
-// pixels, N = Cout, K = 9 * Cin ordered (tap, cin), one K-tile = 64 bf16 = one 128-byte line per
-// row, so the results are bit-identical to the generic kernel's.
+// pixels, N = Cout, K = 9 * Cin ordered (128-byte channel chunk, tap, channel inside the chunk),
+// one K-tile = 64 bf16 = one 128-byte line per row, so the results are bit-identical to the
+// generic kernel's.
 //
 // Addressing: the per-lane part of an operand address is a 32-bit buffer offset that is constant
 // for the whole kernel (weights) or for one tap (pixels); the per-K-tile part is a scalar offset.
@@ -78,8 +79,8 @@ struct ConvRingALoader {
     pix_bytes = p.cin * (X3 ? 4 : 2);
     cchunks = p.cin >> (X3 ? 5 : 6);
     W = p.W;
-    tap = 0;
-    cc = -1;
+    tap = -1;
+    cc = 0;
     soff = 0;
     ablate = p.ablate & 1;
     abl_piece = (unsigned)piece;
@@ -111,13 +112,18 @@ struct ConvRingALoader {
       cur[j] = RG_OOB;
     }
   }
+  // K order: channel chunk outer, tap inner.  The nine taps of one 128-byte channel chunk are nine
+  // CONSECUTIVE K-tiles, so the three horizontal taps of an image row re-read the lines their
+  // neighbour fetched one K-tile earlier while those are still in the XCD's L2 (with the tap outer,
+  // a line was re-read Cin/64 K-tiles later — tens of MB of other traffic in between — and every tap
+  // missed: 9x the input per launch on conv2_2, profiles/r02_a_hbm_traffic_*.md).
   __device__ inline void begin_tile() {
-    ++cc;
-    if (cc == cchunks) {
-      cc = 0;
-      ++tap;
+    ++tap;
+    if (tap == 9) {
+      tap = 0;
+      ++cc;
     }
-    if (cc == 0) {
+    {
       const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
       const int toff = ((ky - 1) * W + (kx - 1)) * pix_bytes;
 #pragma unroll
@@ -149,19 +155,19 @@ struct ConvRingBLoader {
     const unsigned pix_bytes = (unsigned)p.cin * (X3 ? 4u : 2u);
     cchunks = p.cin >> (X3 ? 5 : 6);
     tap_stride = (unsigned)p.cout * pix_bytes;
-    tap = 0;
-    cc = -1;
+    tap = -1;
+    cc = 0;
     soff = 0;
     ablate = p.ablate & 2;
     abl_piece = (unsigned)piece;
 #pragma unroll
     for (int j = 0; j < 2 * NB; ++j) off[j] = (unsigned)(n0 + tile_row[j]) * pix_bytes + piece;
   }
-  __device__ inline void begin_tile() {
-    ++cc;
-    if (cc == cchunks) {
-      cc = 0;
-      ++tap;
+  __device__ inline void begin_tile() {  // same K order as the A loader
+    ++tap;
+    if (tap == 9) {
+      tap = 0;
+      ++cc;
     }
     soff = (unsigned)tap * tap_stride + (unsigned)cc * 128u;
     if (ablate && (tap != 0 || cc != 0)) {

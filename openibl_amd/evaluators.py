@@ -349,9 +349,11 @@ class Evaluator(object):
                     f"yielded {local.shape[0]} items, DistributedSliceSampler would yield {per}; "
                     "use DistributedSliceSampler(dataset) without drop_last, or pass "
                     "device_resident=False for the reference's host flow")
-        q_all = sharded.all_gather_rows(q_local)[: len(query)].contiguous()
+        # queries: prepared where they were extracted, exchanged in prepared form; gallery shard:
+        # prepared once and resident
+        q_all = sharded.gather_prepared_queries(q_local, len(query), prec)
         start, _, n_valid = sharded.slice_bounds(len(gallery), rank, world)
-        g_local = g_local[:n_valid].contiguous()
+        g_local = ops.PreparedRows(g_local[:n_valid].contiguous(), prec)
         k = min(max(recall_topk) * (12 if nms else 1), len(gallery))
         _check_prefix(k)
         if rank == 0:

@@ -650,6 +650,7 @@ class PreparedRows:
         x = _pad_dim(x.contiguous())
         st = storage_code(x)
         rows, d = map(int, x.shape)
+        rows, d = map(int, x.shape)
         self.precision, self.shape, self.device = p, (rows, d), dev
         self.norms = torch.empty((rows,), dtype=torch.float32, device=dev)
         self.operand = x
@@ -663,6 +664,27 @@ class PreparedRows:
         self._source = x          # read in place when there is no operand copy
         if buf is not None:
             self.operand = buf
+
+    def operand_rows(self) -> torch.Tensor:
+        """The operand as a [rows][bytes per row] uint8 matrix (a view): what travels when prepared
+        queries are exchanged between ranks instead of fp32 rows."""
+        rows = self.shape[0]
+        per = self.shape[1] * (2 if self.precision == BF16 else 4)
+        flat = self.operand.contiguous().view(torch.uint8).reshape(-1)
+        return flat[: rows * per].view(rows, per)
+
+    @classmethod
+    def from_parts(cls, operand_rows: torch.Tensor, norms: torch.Tensor, d: int, precision) -> "PreparedRows":
+        """Re-assemble prepared rows from their exchanged parts (operand_rows() and .norms of one or
+        several PreparedRows of the same precision, concatenated along dim 0)."""
+        self = cls.__new__(cls)
+        self.precision = precision_code(precision)
+        self.device = operand_rows.device
+        self.shape = (int(operand_rows.shape[0]), int(d) + (-int(d)) % 64)
+        self.operand = operand_rows.contiguous()
+        self.norms = norms.contiguous()
+        self._source = None
+        return self
 
 
 def sqdist_topk_prepared(x: "PreparedRows", y: "PreparedRows", k: int, index_base: int = 0,

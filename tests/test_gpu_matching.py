@@ -258,6 +258,11 @@ def test_prepared_rows_equal_direct_call(dev, precision, store):
     assert torch.equal(v, want_v) and torch.equal(i, want_i)
     v, i = sharded.sharded_topk(qd, gp, 10, 7, precision)
     assert torch.equal(v, want_v) and torch.equal(i, want_i)
+    # prepared queries re-assembled from their exchanged parts (what gather_prepared_queries ships)
+    qx = sharded.gather_prepared_queries(torch.cat([qd, qd[:5]]), 300, precision)
+    assert qx.shape == qp.shape and torch.equal(qx.norms, qp.norms)
+    v, i = ops.sqdist_topk_prepared(qx, gp, 10, index_base=7)
+    assert torch.equal(v, want_v) and torch.equal(i, want_i)
     small = ops.PreparedRows(gd[:100].contiguous(), precision)       # below every fused threshold
     sv, si = ops.sqdist_topk_prepared(qp, small, 10)
     wv, wi = ops.sqdist_topk(qd, gd[:100].contiguous(), 10, precision=precision)

@@ -40,6 +40,31 @@ def _resident_local_topk(q, shard, k, index_base, precision):
     return _oracle_local_topk(q, shard.rows, k, index_base, precision)
 
 
+class _CpuPrepared:
+    """CPU stand-in with the protocol of ops.PreparedRows that gather_prepared_queries relies on:
+    operand_rows(), .norms, from_parts()."""
+
+    def __init__(self, x):
+        self.x = x.clone()
+        self.norms = (x.double() ** 2).sum(1).float()
+        self.shape = tuple(x.shape)
+
+    def operand_rows(self):
+        return self.x.contiguous().view(torch.uint8).reshape(self.x.shape[0], -1)
+
+    @classmethod
+    def from_parts(cls, rows, norms, d, precision):
+        self = cls.__new__(cls)
+        self.x = rows.contiguous().view(torch.float32).reshape(rows.shape[0], d)
+        self.norms, self.shape = norms, (rows.shape[0], d)
+        return self
+
+
+def _prepared_local_topk(qp, g, k, index_base, precision):
+    assert isinstance(qp, _CpuPrepared)
+    return _oracle_local_topk(qp.x, g, k, index_base, precision)
+
+
 def _overflowing_local_topk(q, g, k, index_base, precision, exact=False):
     """Stand-in for the fused GPU path: rank 1's first (non-exact) attempt overflows and returns
     garbage lists with the flag raised; the exact repeat is correct on every rank."""
@@ -87,6 +112,16 @@ def _worker(rank, world, port, G, ret):
                                           merge_fn=_oracle_merge)
             ok_topk = ok_topk and bool(np.array_equal(i3.numpy(), wi[: len(qs)]))
         ok_topk = ok_topk and shard.uses == 2
+        # queries prepared where they were "extracted" and exchanged in prepared form (wrapped
+        # slices, padding dropped after the gather)
+        Qn = q.shape[0]
+        qs, qper, _ = sharded.slice_bounds(Qn, rank, world)
+        q_loc = torch.stack([q[(qs + i) % Qn] for i in range(qper)])
+        qp = sharded.gather_prepared_queries(q_loc, Qn, "fp32", prepare_fn=_CpuPrepared)
+        ok_topk = ok_topk and torch.equal(qp.x, q) and torch.allclose(qp.norms, (q ** 2).sum(1))
+        v4, i4 = sharded.sharded_topk(qp, g[start:start + n_valid], 10, start,
+                                      local_topk_fn=_prepared_local_topk, merge_fn=_oracle_merge)
+        ok_topk = ok_topk and bool(np.array_equal(i4.numpy(), wi))
         rec = evaluators.recalls_from_topk(idx.numpy(), gt)
         ok_rec = bool(np.array_equal(rec, om.evaluate_all(d, gt, pids)))
 
