@@ -252,10 +252,9 @@ __global__ __launch_bounds__(256) void conv1_1_mfma_kernel(const float* __restri
 
 // ---------------------------------------------------------------------------------------------
 // implicit-GEMM 3x3 convolution
-//   M = output pixels, N = Cout, K = 9 * Cin ordered (128-byte channel chunk, tap, channel).  A
-//   K-step is one tap x one 128-byte run of input channels of each pixel, fetched straight from the
-//   NHWC tensor (or from a zero line when the tap falls outside the image); the nine taps of a chunk
-//   are consecutive K-steps so that horizontally adjacent taps find their lines in L2.
+//   M = output pixels, N = Cout, K = 9 * Cin ordered (tap, cin).  A K-step is one tap x one
+//   128-byte run of input channels of each pixel, fetched straight from the NHWC tensor (or from a
+//   zero line when the tap falls outside the image).
 //   POOL: pixels are enumerated quad-major (m = 4*quad + 2*dy + dx over the floor(H/2) x floor(W/2)
 //   pooled grid), so that the four members of a 2x2 window are 4 consecutive GEMM rows = registers
 //   4g..4g+3 of one lane in the 32x32 accumulator layout: the pool is an in-register max and the
@@ -275,6 +274,7 @@ struct ConvParams {
   int ablate;  // timing experiments only (wrong results): 1 = A loads only at tap 0, 2 = B loads
                // only at the first step, 3 = both
   int out_f32;  // bf16x3 only: the output is written as plain fp32 NHWC (the layer feeding the head)
+  int korder;   // K order of the implicit GEMM (test hook, see ConvRingALoader::begin_tile)
 };
 
 // one output element into the staged tile row (row-major [BN] of T; bf16x3: (hi, lo) groups or fp32)
@@ -296,7 +296,7 @@ struct ConvALoader {
   unsigned mask[Cfg::A_LOADS];
   const char* zero;
   long tap_off;
-  int tap, cc, cchunks, W, ablate;
+  int tap, cc, cchunks, W, ablate, korder;
   long pix_bytes;
 
   __device__ inline void init(const WaveCoord& c, const ConvParams& p, long m0, int tap0) {
@@ -305,6 +305,7 @@ struct ConvALoader {
     pix_bytes = (long)p.cin * sizeof(T);
     W = p.W;
     ablate = p.ablate;
+    korder = p.korder;
     cchunks = p.cin / Cfg::BK;
     zero = reinterpret_cast<const char*>(p.zero) + (c.lane & 7) * 16;
     const int Hq = POOL ? (p.H >> 1) : p.H, Wq = POOL ? (p.W >> 1) : p.W;
@@ -342,13 +343,21 @@ struct ConvALoader {
     return ((mask[j] >> tap) & 1u) ? base[j] + tap_off + cc * 128 : zero;
   }
   __device__ inline bool active() const { return !((ablate & 1) && tap != 0); }
-  // K order: channel chunk outer, tap inner (see ConvRingALoader::begin_tile)
+  // K order as in ConvRingALoader::begin_tile: 0 = (tap, chunk), 1 = (chunk, tap; test hook)
   __device__ inline void next() {
-    if (++tap == 9) {
-      tap = 0;
-      ++cc;
+    if (korder == 0) {
+      if (++cc == cchunks) {
+        cc = 0;
+        ++tap;
+        tap_off = (long)((tap / 3 - 1) * W + (tap % 3 - 1)) * pix_bytes;
+      }
+    } else {
+      if (++tap == 9) {
+        tap = 0;
+        ++cc;
+      }
+      tap_off = (long)((tap / 3 - 1) * W + (tap % 3 - 1)) * pix_bytes;
     }
-    tap_off = (long)((tap / 3 - 1) * W + (tap % 3 - 1)) * pix_bytes;
   }
 };
 
@@ -356,7 +365,7 @@ template <typename Cfg>
 struct ConvBLoader {
   const char* p0[Cfg::B_LOADS];  // row pointers at (tap 0, channel chunk 0)
   long tap_stride, off;
-  int tap, cc, cchunks, ablate, step;
+  int tap, cc, cchunks, ablate, step, korder;
   __device__ inline bool active() const { return !((ablate & 2) && step != 0); }
   __device__ inline void init(const WaveCoord& c, const ConvParams& prm, long n0, int tap0) {
     using T = typename Cfg::T;
@@ -365,6 +374,7 @@ struct ConvBLoader {
     cc = 0;
     tap = tap0;
     ablate = prm.ablate;
+    korder = prm.korder;
     step = 0;
     tap_stride = (long)prm.cin * sizeof(T) * prm.cout;
     off = tap * tap_stride;
@@ -377,7 +387,12 @@ struct ConvBLoader {
   __device__ inline const char* src(int j) const { return p0[j] + off; }
   __device__ inline void next() {
     ++step;
-    if (++tap == 9) {
+    if (korder == 0) {
+      if (++cc == cchunks) {
+        cc = 0;
+        ++tap;
+      }
+    } else if (++tap == 9) {
       tap = 0;
       ++cc;
     }
@@ -492,6 +507,7 @@ static int launch_conv_cfg(const ConvParams& p, hipStream_t st) {
 }
 
 static int g_ring_raster = 0;                     // test hook: xcd_tile() mode of the ring kernels
+static int g_conv_korder = 0;                     // test hook: K order of every implicit-GEMM convolution
 static unsigned long long* g_prof_buf = nullptr;  // test hook: phase profile of block 0
 static int g_ring_ablate = 0;                     // test hook: see RingParams::ablate
 
@@ -528,6 +544,7 @@ static int launch_conv_ring_impl(const ConvParams& p, hipStream_t st) {
   const long grid = tiles_m * q.tiles_n;
   q.tiles_m = (int)tiles_m;
   q.raster = g_ring_raster;
+  q.korder = p.korder;
   constexpr int lds = ring_lds_bytes<WM, POOL, X3>();
   auto kern = conv3x3_ring_kernel<WM, POOL, ODD, X3>;
   OIBL_SET_MAX_LDS(kern, lds);
@@ -1474,6 +1491,7 @@ static int conv3x3_impl(const void* in, int N, int H, int W, int cin, const void
   p.relu = relu;
   p.ablate = g_conv_ablate;
   p.out_f32 = precision == OIBL_BF16X3 ? out_f32 : 0;
+  p.korder = g_conv_korder;
   p.tiles_n = 0;
   if (pool) {
     p.out_rows = (long)N * (H / 2) * (W / 2);
@@ -1526,6 +1544,11 @@ int oibl_debug_set_conv_ablate(int mode) {
 
 int oibl_debug_set_ring_ablate(int mode) {
   g_ring_ablate = mode;
+  return OIBL_OK;
+}
+
+int oibl_debug_set_conv_korder(int mode) {
+  g_conv_korder = mode ? 1 : 0;
   return OIBL_OK;
 }
 

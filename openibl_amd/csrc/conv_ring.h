@@ -2,9 +2,8 @@
 // (Cout % 256 == 0) or 512 x 128 tile (Cout % 128 == 0).
 //
 // Same contraction and the same summation order as conv3x3_igemm_kernel (conv.hip): M = output
-// pixels, N = Cout, K = 9 * Cin ordered (128-byte channel chunk, tap, channel inside the chunk),
-// one K-tile = 64 bf16 = one 128-byte line per row, so the results are bit-identical to the
-// generic kernel's.
+// pixels, N = Cout, K = 9 * Cin ordered (tap, cin), one K-tile = 64 bf16 = one 128-byte line per
+// row, so the results are bit-identical to the generic kernel's.
 //
 // Addressing: the per-lane part of an operand address is a 32-bit buffer offset that is constant
 // for the whole kernel (weights) or for one tap (pixels); the per-K-tile part is a scalar offset.
@@ -42,6 +41,7 @@ struct RingParams {
   int out_f32;  // X3, !POOL only: write plain fp32 NHWC instead of the (hi, lo) groups
   int tiles_m;
   int raster;   // xcd_tile() mode
+  int korder;   // 0 = (tap, channel chunk), 1 = (channel chunk, tap): see ConvRingALoader::begin_tile
 };
 
 // mul, sh with floor(m / d) == (m * mul) >> sh for every m < 2^31 (d >= 1):  sh = 31 + ceil(log2 d),
@@ -73,14 +73,15 @@ struct ConvRingALoader {
   __amdgpu_buffer_rsrc_t rsrc;
   unsigned base[2 * NA], mask[2 * NA], cur[2 * NA];
   unsigned soff, abl_piece;
-  int tap, cc, cchunks, W, pix_bytes, ablate;
+  int tap, cc, cchunks, W, pix_bytes, ablate, korder;
   __device__ inline void init(const RingParams& p, int m0, const int (&tile_row)[2 * NA], int piece) {
+    korder = p.korder;
     rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
     pix_bytes = p.cin * (X3 ? 4 : 2);
     cchunks = p.cin >> (X3 ? 5 : 6);
     W = p.W;
-    tap = -1;
-    cc = 0;
+    tap = korder ? -1 : 0;
+    cc = korder ? 0 : -1;
     soff = 0;
     ablate = p.ablate & 1;
     abl_piece = (unsigned)piece;
@@ -112,18 +113,32 @@ struct ConvRingALoader {
       cur[j] = RG_OOB;
     }
   }
-  // K order: channel chunk outer, tap inner.  The nine taps of one 128-byte channel chunk are nine
-  // CONSECUTIVE K-tiles, so the three horizontal taps of an image row re-read the lines their
-  // neighbour fetched one K-tile earlier while those are still in the XCD's L2 (with the tap outer,
-  // a line was re-read Cin/64 K-tiles later — tens of MB of other traffic in between — and every tap
-  // missed: 9x the input per launch on conv2_2, profiles/r02_a_hbm_traffic_*.md).
+  // K order.  korder 0 (default): tap outer, channel chunk inner — per K-tile only the scalar chunk
+  // offset changes, the per-lane offsets change once per tap.  korder 1 (test hook): chunk outer,
+  // tap inner — the nine taps of one 128-byte chunk are consecutive K-tiles, so horizontally
+  // adjacent taps re-read their lines from the XCD's L2.  Measured (profiles/r02_*): korder 1 cuts
+  // the fetched bytes 3-8x (every tap of korder 0 misses L2 once 32 workgroups x 9 taps of
+  // footprint exceed 4 MiB) and is nevertheless 3-12 % SLOWER in bf16 and 2-5 % slower in bf16x3
+  // on all layers but one: the kernels are not bound by fetch volume (Infinity-Cache hits are
+  // cheap), while korder 0 streams each pixel's channel run as consecutive lines.
   __device__ inline void begin_tile() {
-    ++tap;
-    if (tap == 9) {
-      tap = 0;
+    bool new_tap;
+    if (korder == 0) {
       ++cc;
+      if (cc == cchunks) {
+        cc = 0;
+        ++tap;
+      }
+      new_tap = cc == 0;
+    } else {
+      ++tap;
+      if (tap == 9) {
+        tap = 0;
+        ++cc;
+      }
+      new_tap = true;
     }
-    {
+    if (new_tap) {
       const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
       const int toff = ((ky - 1) * W + (kx - 1)) * pix_bytes;
 #pragma unroll
@@ -149,14 +164,15 @@ struct ConvRingBLoader {
   __amdgpu_buffer_rsrc_t rsrc;
   unsigned off[2 * NB];
   unsigned soff, tap_stride, abl_piece;
-  int tap, cc, cchunks, ablate;
+  int tap, cc, cchunks, ablate, korder;
   __device__ inline void init(const RingParams& p, int n0, const int (&tile_row)[2 * NB], int piece) {
+    korder = p.korder;
     rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
     const unsigned pix_bytes = (unsigned)p.cin * (X3 ? 4u : 2u);
     cchunks = p.cin >> (X3 ? 5 : 6);
     tap_stride = (unsigned)p.cout * pix_bytes;
-    tap = -1;
-    cc = 0;
+    tap = korder ? -1 : 0;
+    cc = korder ? 0 : -1;
     soff = 0;
     ablate = p.ablate & 2;
     abl_piece = (unsigned)piece;
@@ -164,10 +180,18 @@ struct ConvRingBLoader {
     for (int j = 0; j < 2 * NB; ++j) off[j] = (unsigned)(n0 + tile_row[j]) * pix_bytes + piece;
   }
   __device__ inline void begin_tile() {  // same K order as the A loader
-    ++tap;
-    if (tap == 9) {
-      tap = 0;
+    if (korder == 0) {
       ++cc;
+      if (cc == cchunks) {
+        cc = 0;
+        ++tap;
+      }
+    } else {
+      ++tap;
+      if (tap == 9) {
+        tap = 0;
+        ++cc;
+      }
     }
     soff = (unsigned)tap * tap_stride + (unsigned)cc * 128u;
     if (ablate && (tap != 0 || cc != 0)) {

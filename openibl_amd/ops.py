@@ -162,6 +162,12 @@ def set_ring_raster(mode: int) -> None:
     _lib.load().oibl_debug_set_ring_raster(int(mode))
 
 
+def set_conv_korder(mode: int) -> None:
+    """Test hook: K order of the implicit-GEMM convolutions, 0 = (tap, channel chunk) [default],
+    1 = (channel chunk, tap): 3-8x fewer fetched bytes, slower (see conv_ring.h)."""
+    _lib.load().oibl_debug_set_conv_korder(int(mode))
+
+
 def set_conv_c64(on) -> None:
     """Test hook: resident-weights kernel for Cin = 64 layers (bf16): False/0 = never, True/1 = auto
     (Cout = 64 only; wider layers go to the ring kernel), 2 = every Cin = 64 layer."""

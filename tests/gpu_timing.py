@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--ablate", type=int, default=0)
     ap.add_argument("--c64", type=int, default=1)
     ap.add_argument("--raster", type=int, default=0)
+    ap.add_argument("--korder", type=int, default=0)
     ap.add_argument("--layers", type=int, default=13, help="time conv1_1 and the first LAYERS-1 3x3 layers only")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -46,6 +47,7 @@ def main():
     ops.set_conv_tile(a.tile)
     ops.set_conv_c64(bool(a.c64))
     ops.set_ring_raster(a.raster)
+    ops.set_conv_korder(a.korder)
     from openibl_amd import lib as _l
     _l.load().oibl_debug_set_conv_ablate(a.ablate)
     sd = synth.embednetpca_state(0)
@@ -92,7 +94,7 @@ def main():
     if "stem fused (conv1_1+conv01)" in named:
         tot_f = tot - rows[0][1] - rows[1][1] + named["stem fused (conv1_1+conv01)"]
         print(f"  (with the fused stem: {tot_f:.3f} ms -> {N / tot_f * 1e3:.1f} img/s)")
-    print(f"precision={p} batch={N} {H}x{W} regstage={a.regstage} tile={a.tile} ablate={a.ablate} raster={a.raster}")
+    print(f"precision={p} batch={N} {H}x{W} regstage={a.regstage} tile={a.tile} ablate={a.ablate} raster={a.raster} korder={a.korder}")
     for name, ms, fl in rows:
         print(f"  {name:34s} {ms:9.3f} ms  {fl / ms / 1e9:9.1f} TFLOP/s")
     print(f"  sum of stages {tot:.3f} ms -> {N / tot * 1e3:.1f} img/s")

@@ -233,3 +233,30 @@ def test_ring_raster_modes_agree(dev, N, H, W, cin, cout, relu, pool, precision)
         ops.set_ring_raster(0)
         ops.set_conv_tile(0)
     assert torch.equal(y, ref)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3", "fp32"])
+def test_chunk_major_k_order_hook(dev, precision):
+    """K order (channel chunk, tap) — the fetch-volume experiment of conv_ring.h — computes the same
+    convolution (other summation order: equal to rounding), and ring == generic bit for bit in it."""
+    N, H, W, cin, cout = 3, 20, 24, 256, 256
+    x, w, b = _case(N, H, W, cin, cout, seed=77)
+    xd = ops.nchw_f32_to_nhwc(x.to(dev), "fp32" if precision == "bf16x3" else precision)
+    if precision == "bf16x3":
+        xd = ops.x3_split(xd)
+    wp = ops.pack_conv3x3(w.to(dev), precision)
+    ref = ops.conv3x3_nhwc(xd, wp, b.to(dev), True, False, precision)
+    ops.set_conv_korder(1)
+    try:
+        y = ops.conv3x3_nhwc(xd, wp, b.to(dev), True, False, precision)
+        ops.set_conv_tile(1)
+        y1 = ops.conv3x3_nhwc(xd, wp, b.to(dev), True, False, precision)
+    finally:
+        ops.set_conv_tile(0)
+        ops.set_conv_korder(0)
+    assert torch.equal(y, y1)
+    f = (lambda t: ops.nhwc_to_nchw_f32(ops.x3_join(t) if precision == "bf16x3" else t).cpu())
+    want = _host_conv(x, w, b, True, False, "bf16" if precision == "bf16" else "fp32")
+    tol = {"bf16": 4e-3, "bf16x3": 2e-5, "fp32": 2e-6}[precision]
+    assert_rel_l2(f"korder 1 {precision}", f(y), want, tol)
+    assert_rel_l2(f"korder 1 vs 0 {precision}", f(y), f(ref), tol)
