@@ -178,6 +178,15 @@ struct PairRingParams {
   int* cand_cnt;
   int cap, index_base, index_stride;  // global index of column c = index_base + c * index_stride
   int group_m;                        // query tiles per ordering group (see above)
+  // 2-way split-K (threshold sample only, gridDim.y = 2): block (., h) contracts K-half h and writes
+  // dist + h * part_stride; the norms enter half 0 only, so the two halves ADD UP to the distances
+  // (in another summation order than the one-pass kernel: see thr_slack).
+  size_t part_stride;
+  // !FILTER: optional, max over the launch's columns of yn (bit pattern of a non-negative float,
+  // atomicMax).  FILTER: optional, read back — the threshold of row i is widened by
+  // thr_slack * (xn[i] + *yn_max) / 2, a bound on what the other summation order can move a distance.
+  unsigned* yn_max;
+  float thr_slack;
 };
 
 template <bool FILTER, bool X3 = false>
@@ -205,9 +214,14 @@ __global__ __launch_bounds__(512) void pairwise_ring_kernel(PairRingParams p) {
       rows_a[2 * h + i] = ring_a_row<2>(wave, lane, h, i);
       rows_b[2 * h + i] = ring_b_row<2>(wave, lane, h, i);
     }
+  // split-K: this block's K-half starts kh * d/2 elements into every row
+  const int ksplit = (int)gridDim.y, kh = (int)blockIdx.y;
+  const int d_part = p.d / ksplit;
+  const unsigned koff = (unsigned)kh * (unsigned)d_part * (X3 ? 4u : 2u);
   RingRowLoader<2> la, lb;
-  la.init(p.x, p.x_bytes, m0, p.m, (long)p.d * (X3 ? 4 : 2), rows_a, piece);
-  lb.init(p.y, p.y_bytes, n0, p.n, p.y_row_bytes, rows_b, piece);
+  la.init(static_cast<const char*>(p.x) + koff, p.x_bytes - koff, m0, p.m, (long)p.d * (X3 ? 4 : 2), rows_a,
+          piece);
+  lb.init(static_cast<const char*>(p.y) + koff, p.y_bytes - koff, n0, p.n, p.y_row_bytes, rows_b, piece);
 
   f32x16_t acc[4][2];
 #pragma unroll
@@ -217,7 +231,7 @@ __global__ __launch_bounds__(512) void pairwise_ring_kernel(PairRingParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  ring_mainloop<2, false, false, X3>(acc, smem, wave, lane, la, lb, p.d >> (X3 ? 5 : 6));
+  ring_mainloop<2, false, false, X3>(acc, smem, wave, lane, la, lb, d_part >> (X3 ? 5 : 6));
 
   // norms (and thresholds) of the tile's rows / columns -> LDS; out-of-range rows/columns are
   // clamped here and masked at the store
@@ -227,12 +241,22 @@ __global__ __launch_bounds__(512) void pairwise_ring_kernel(PairRingParams p) {
   if (threadIdx.x < 256) {
     int r = m0 + (int)threadIdx.x;
     if (r > p.m - 1) r = p.m - 1;
-    xn_s[threadIdx.x] = p.xn[r];
-    if (FILTER) th_s[threadIdx.x] = p.thr[(long)r * p.thr_stride];
+    const float xn = p.xn[r];
+    xn_s[threadIdx.x] = kh == 0 ? xn : 0.f;
+    if (FILTER) {
+      float th = p.thr[(long)r * p.thr_stride];
+      if (p.yn_max) th += p.thr_slack * 0.5f * (xn + __uint_as_float(*p.yn_max));
+      th_s[threadIdx.x] = th;
+    }
   } else {
     int c = n0 + (int)threadIdx.x - 256;
     if (c > p.n - 1) c = p.n - 1;
-    yn_s[threadIdx.x - 256] = p.yn[(long)c * p.yn_stride];
+    const float yn = p.yn[(long)c * p.yn_stride];
+    yn_s[threadIdx.x - 256] = kh == 0 ? yn : 0.f;
+    if (!FILTER && p.yn_max && kh == 0 && tm == 0) {  // one column of tiles covers every column once
+      const float mx = wave_max(yn);                  // (norms are >= 0: their bit patterns order as integers)
+      if (lane == 0) atomicMax(p.yn_max, __float_as_uint(mx));
+    }
   }
   __syncthreads();
   // lane geometry: column col0 + 32 j, rows row0 + 32 i + (r & 3) + 8 (r >> 2)
@@ -241,7 +265,7 @@ __global__ __launch_bounds__(512) void pairwise_ring_kernel(PairRingParams p) {
     // stores go through a buffer descriptor based at the tile's first element: one 32-bit lane
     // offset, everything else is scalar (the host guarantees 256 * ldd * 4 < 2^31)
     const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(
-        p.dist + (size_t)m0 * p.ldd + n0, 0, 0x7fffffff, 0x00020000);
+        p.dist + (size_t)kh * p.part_stride + (size_t)m0 * p.ldd + n0, 0, 0x7fffffff, 0x00020000);
     const unsigned ldd4 = (unsigned)p.ldd * 4u;
     const unsigned voff = (unsigned)row0 * ldd4 + (unsigned)col0 * 4u;
     const int rows_left = p.m - m0 - row0;  // row r of this lane is valid iff its offset < rows_left
@@ -517,7 +541,8 @@ __global__ __launch_bounds__(256) void row_select_wave_kernel(const float* __res
                                                               int index_base,
                                                               float* __restrict__ out_val,
                                                               int32_t* __restrict__ out_idx,
-                                                              const int* __restrict__ row_n) {
+                                                              const int* __restrict__ row_n,
+                                                              const float* __restrict__ vals2) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= m) return;  // wave-uniform
@@ -527,6 +552,7 @@ __global__ __launch_bounds__(256) void row_select_wave_kernel(const float* __res
     if (n > 64 * NQ) return;
   }
   const float* vr = vals + (size_t)row * ld;
+  const float* vr2 = vals2 ? vals2 + (size_t)row * ld : nullptr;  // second addend (split-K halves)
   const int32_t* ir = idx_in ? idx_in + (size_t)row * ld : nullptr;
   unsigned long long mine[NQ];
 #pragma unroll
@@ -535,7 +561,8 @@ __global__ __launch_bounds__(256) void row_select_wave_kernel(const float* __res
     mine[q] = TOPK_INF;
     if (j < n) {
       const uint32_t id = ir ? (uint32_t)ir[j] : (uint32_t)(index_base + j);
-      mine[q] = ((unsigned long long)ordered_bits(vr[j]) << 32) | id;
+      const float v = vr2 ? vr[j] + vr2[j] : vr[j];
+      mine[q] = ((unsigned long long)ordered_bits(v) << 32) | id;
     }
   }
   unsigned long long res = TOPK_INF;
@@ -551,19 +578,21 @@ __global__ __launch_bounds__(256) void row_select_wave_kernel(const float* __res
 }
 
 // dispatch: wave-per-row selection for short rows, one workgroup per row for the rest
+// vals2 (optional, only on the wave-per-row paths: k <= 32, n <= 1024, no per-row lengths): a second
+// matrix added element-wise before selecting
 static void launch_row_topk(const float* vals, const int32_t* idx_in, int m, int n, size_t ld, int k,
                             int index_base, float* out_val, int32_t* out_idx, const int* row_n,
-                            int* overflow, hipStream_t st) {
+                            int* overflow, hipStream_t st, const float* vals2 = nullptr) {
   const dim3 wgrid((m + 3) / 4), block(256);
   int skip_le = -1;
   if (k <= SEL_MAX_K && !row_n && n <= 512) {
     hipLaunchKernelGGL(row_select_wave_kernel<8>, wgrid, block, 0, st, vals, idx_in, m, n, ld, k,
-                       index_base, out_val, out_idx, row_n);
+                       index_base, out_val, out_idx, row_n, vals2);
     return;
   }
   if (k <= SEL_MAX_K && (row_n || n <= 1024)) {
     hipLaunchKernelGGL(row_select_wave_kernel<16>, wgrid, block, 0, st, vals, idx_in, m, n, ld, k,
-                       index_base, out_val, out_idx, row_n);
+                       index_base, out_val, out_idx, row_n, vals2);
     if (!row_n) return;
     skip_le = 1024;  // per-row lengths: the workgroup kernel takes the rows above 1024 (and raises
                      // the overflow flag for rows beyond the capacity)
@@ -759,6 +788,12 @@ extern "C" {
 
 static int g_match_ring = 1;  // test hook: 0 = never, 1 = auto, 2 = whenever legal
 static int g_match_group = 4;  // test hook: query tiles per ordering group of the ring kernel
+static int g_match_splitk = 1;  // test hook: 0 = never split the threshold sample's contraction
+
+int oibl_debug_set_match_splitk(int on) {
+  g_match_splitk = on ? 1 : 0;
+  return OIBL_OK;
+}
 
 int oibl_debug_set_match_group(int g) {
   g_match_group = g < 1 ? 1 : g;
@@ -806,7 +841,7 @@ static bool pair_ring_wanted(int m, int n, int d, int es = 2) {
 
 extern "C++" {
 template <bool FILTER, bool X3 = false>
-static int launch_pairwise_ring(PairRingParams& p, hipStream_t st) {
+static int launch_pairwise_ring(PairRingParams& p, hipStream_t st, int ksplit = 1) {
   p.tiles_m = (p.m + 255) / 256;
   p.tiles_n = (p.n + 255) / 256;
   p.group_m = g_match_group;
@@ -815,7 +850,7 @@ static int launch_pairwise_ring(PairRingParams& p, hipStream_t st) {
   constexpr int lds = RingGeo<2>::MAIN_LDS;
   auto kern = pairwise_ring_kernel<FILTER, X3>;
   OIBL_SET_MAX_LDS(kern, lds);
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)ksplit), dim3(512), lds, st, p);
   OIBL_LAUNCH_CHECK();
   return OIBL_OK;
 }
@@ -968,6 +1003,7 @@ int oibl_pairwise_sqdist(const float* x, int m, const float* y, int n, int d, in
 //     with row_topk (the only path in fp32 mode; the fallback when a candidate list overflows).
 struct TopkPlan {
   bool fused;
+  int ksplit;  // 2: the threshold sample is contracted in two K-halves on twice the workgroups
   int S, stride, cap, chunk;
   size_t off_prep, off_sample, off_sval, off_sidx, off_cnt, off_cval, off_cidx, off_chunk, total;
 };
@@ -984,6 +1020,14 @@ static TopkPlan topk_plan(int m, int n, int d, int k, int precision, size_t prep
   t.fused = mfma16(precision) && g_match_ring && pair_ring_legal(m, n, d, opnd_es(precision)) && n >= 8 * S &&
             (long)((m + 255) / 256) * ((n + 255) / 256) >= 64;
   t.S = S;
+  // The sample pass is one 256 x 256 tile over the whole K per workgroup: with m/256 * S/256 <= 128
+  // tiles half of the CUs idle for its ~93 us.  Two K-halves on twice the workgroups halve that
+  // latency; the halves are added in the selection (wave-per-row paths only) and the thresholds get
+  // the slack that covers the changed summation order.
+  const int es_ = opnd_es(precision);
+  const int kt_half = d * es_ / 256;      // K-tiles per half
+  t.ksplit = (g_match_splitk && t.fused && k <= SEL_MAX_K && S <= 1024 && d % 128 == 0 &&
+              kt_half >= 4 && (kt_half & 1) == 0 && (long)((m + 255) / 256) * (S / 256) <= 128) ? 2 : 1;
   t.stride = n / S;                       // sample = gallery rows 0, stride, 2 stride, ...
   const long expect = (long)k * t.stride + k;  // ~ n k / S survivors per query
   long cap = 4096;
@@ -997,7 +1041,7 @@ static TopkPlan topk_plan(int m, int n, int d, int k, int precision, size_t prep
   t.off_prep = o;
   o += align_up(prep_bytes, 256);
   t.off_sample = o;
-  o += align_up((size_t)m * S * sizeof(float), 256);
+  o += align_up((size_t)m * S * sizeof(float), 256) * 2;   // two halves when the sample is split
   t.off_sval = o;
   o += align_up((size_t)m * k * sizeof(float), 256);
   t.off_sidx = o;
@@ -1059,13 +1103,24 @@ static int sqdist_topk_core(const void* xo, const float* xn, int m, const void* 
     q.m = m;
     q.n = t.S;
     q.d = d;
-    rc = x3 ? launch_pairwise_ring<false, true>(q, st) : launch_pairwise_ring<false>(q, st);
-    if (rc) return rc;
-    launch_row_topk(sample, nullptr, m, t.S, (size_t)t.S, k, 0, sval, sidx, nullptr, nullptr, st);
-    OIBL_LAUNCH_CHECK();
-    // 2. the full contraction, keeping only distances <= threshold
     int* cnt = (int*)(wsb + t.off_cnt);
-    OIBL_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)m * sizeof(int), st));
+    OIBL_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)(m + 1) * sizeof(int), st));  // counts + the yn_max slot
+    const size_t half = align_up((size_t)m * t.S * sizeof(float), 256) / sizeof(float);
+    if (t.ksplit == 2) {
+      q.part_stride = half;
+      q.yn_max = (unsigned*)(cnt + m);
+    }
+    rc = x3 ? launch_pairwise_ring<false, true>(q, st, t.ksplit) : launch_pairwise_ring<false>(q, st, t.ksplit);
+    if (rc) return rc;
+    launch_row_topk(sample, nullptr, m, t.S, (size_t)t.S, k, 0, sval, sidx, nullptr, nullptr, st,
+                    t.ksplit == 2 ? sample + half : nullptr);
+    OIBL_LAUNCH_CHECK();
+    // 2. the full contraction, keeping only distances <= threshold (+ the slack of a split sample:
+    //    a bound on what fp32 accumulation in another order can move a distance)
+    q.part_stride = 0;
+    // (each of the two orders is within K' 2^-24 |x||y| of the exact dot product, K' = d products —
+    //  3 d in bf16x3 — so they differ by at most twice that, and a distance by twice that again)
+    q.thr_slack = t.ksplit == 2 ? 4.0f * (float)d * (x3 ? 3.0f : 1.0f) * 5.9604645e-8f : 0.f;
     q.dist = nullptr;
     q.y_row_bytes = (long)d * es;
     q.yn_stride = 1;

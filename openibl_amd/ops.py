@@ -598,6 +598,11 @@ def set_match_ring(mode: int) -> None:
     _lib.load().oibl_debug_set_match_ring(int(mode))
 
 
+def set_match_splitk(on: bool) -> None:
+    """Test hook: allow / forbid the 2-way split-K contraction of the fused path's threshold sample."""
+    _lib.load().oibl_debug_set_match_splitk(1 if on else 0)
+
+
 def sqdist_topk(x: torch.Tensor, y: torch.Tensor, k: int, index_base: int = 0, precision=F32,
                 exact: bool = False, defer_check: bool = False):
     """k nearest rows of y (squared L2) for every row of x, without materialising the matrix:

@@ -31,11 +31,18 @@ def timed(fn, iters=10, warm=3):
 worlds = [int(w) for w in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1, 2, 4, 8]
 prec = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 base = None
-print(f"precision {prec}; the gallery shard is resident (ops.PreparedRows), the queries are prepared per call")
+print(f"precision {prec}; the gallery shard is resident (ops.PreparedRows); every rank prepares the Q / W "
+      f"queries it extracted (sharded.gather_prepared_queries), the exchange itself is not emulated")
+q_all = ops.PreparedRows(q, prec)
 for world in worlds:
     n = G // world
     shard = ops.PreparedRows(gal[:n].contiguous(), prec)
-    t = timed(lambda: ops.sqdist_topk_prepared(ops.PreparedRows(q, prec), shard, K, defer_check=True))  # as sharded.py
+    q_mine = q[: Q // world].contiguous()
+
+    def step():
+        ops.PreparedRows(q_mine, prec)                                      # this rank's share of the queries
+        return ops.sqdist_topk_prepared(q_all, shard, K, defer_check=True)  # as sharded.py
+    t = timed(step)
     vals = torch.randn((Q, world * K), device=dev)
     idx = torch.randint(0, G, (Q, world * K), device=dev, dtype=torch.int32)
     tm = timed(lambda: ops.row_topk(vals, K, idx_in=idx)) if world > 1 else 0.0

@@ -308,3 +308,27 @@ def test_evaluate_all_beyond_1024_ranks(dev):
         got = evaluate_all(d, gt, gallery, recall_topk=list(topk), nms=nms)
         want = om.evaluate_all(d.numpy(), gt, pids, recall_topk=topk, nms=nms)
         np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_split_k_threshold_sample_gives_the_same_lists(dev, precision):
+    """The fused path contracts its threshold sample in two K-halves when that fills the chip
+    (<= 128 sample tiles); thresholds then carry a slack for the changed summation order.  The lists
+    must equal the unsplit path's (and so the matrix path's) bit for bit — also with duplicates of
+    the k-th neighbour sitting exactly on the threshold."""
+    q, gal, gt, _ = synth.retrieval_problem(700, 20000, seed=14)
+    gal[5000:5010] = gal[3]            # ten exact duplicates: ties on and around thresholds
+    qd, gd = q.to(dev), gal.to(dev)
+    ops.set_match_splitk(False)
+    try:
+        v0, i0 = ops.sqdist_topk(qd, gd, 10, precision=precision)
+    finally:
+        ops.set_match_splitk(True)
+    v1, i1 = ops.sqdist_topk(qd, gd, 10, precision=precision)
+    assert torch.equal(v0, v1) and torch.equal(i0, i1)
+    wv, wi = ops.row_topk(ops.pairwise_sqdist(qd, gd, precision), 10)
+    assert torch.equal(v1, wv) and torch.equal(i1, wi)
+    # non-unit norms: the slack scales with |x||y|
+    v2, i2 = ops.sqdist_topk((qd * 37.0).contiguous(), (gd * 0.2).contiguous(), 10, precision=precision)
+    wv2, wi2 = ops.row_topk(ops.pairwise_sqdist((qd * 37.0).contiguous(), (gd * 0.2).contiguous(), precision), 10)
+    assert torch.equal(v2, wv2) and torch.equal(i2, wi2)
