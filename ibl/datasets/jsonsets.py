@@ -56,14 +56,14 @@ class _JsonDataset(Dataset):
 
 
 class Pittsburgh(_JsonDataset):
-    name = 'pitts'
+    name = registry_name = 'pitts'
 
     def __init__(self, root, scale='250k', verbose=True):
         super(Pittsburgh, self).__init__(root, scale=scale, verbose=verbose)
 
 
 class Tokyo(_JsonDataset):
-    name = 'tokyo'
+    name = registry_name = 'tokyo'
 
     def __init__(self, root, scale=None, verbose=True):
         super(Tokyo, self).__init__(root, scale=None, verbose=verbose)

@@ -12,6 +12,8 @@ from ..utils.data.dataset import Dataset, get_groundtruth
 
 
 class Synthetic(Dataset):
+    registry_name = 'synthetic'
+
     def __init__(self, root, scale=None, verbose=True, num_query=8, num_gallery=24, height=96,
                  width=128, seed=5):
         super(Synthetic, self).__init__(root)

@@ -119,3 +119,25 @@ def test_evaluator_extensions_16bit_storage_and_multiscale(group, state_dict, de
     want_ms = om.evaluate_all(om.pairwise_distance(desc_ms[:nq], desc_ms[nq:]).numpy(), gt, pids)
     print("multi-scale recalls", r_ms, want_ms)
     assert np.array_equal(r_ms, want_ms)
+
+
+def test_device_resident_flow_refuses_a_loader_it_cannot_index(group, state_dict, dev):
+    """The device-resident flow derives global gallery indices from DistributedSliceSampler's dealing;
+    a loader that yields another number of items (drop_last here) must be refused, not mis-indexed —
+    and the reference's host flow still takes it."""
+    import hubconf
+    from ibl.evaluators import Evaluator
+    from ibl.utils.data.sampler import DistributedSliceSampler
+    model = hubconf.vgg16_netvlad()
+    model.load_state_dict(state_dict)
+    model = model.to(dev).eval()
+    nq, ng = 4, 10
+    imgs = synth.images(nq + ng, 64, 96, seed=47)
+    query = [(f"q{i}.png", 1000 + i, 0.0, 0.0) for i in range(nq)]
+    gallery = [(f"g{j}.png", j, 0.0, 0.0) for j in range(ng)]
+    gt = [[i] for i in range(nq)]
+    qset, gset = _Records(imgs[:nq], query), _Records(imgs[nq:], gallery)
+    ql = torch.utils.data.DataLoader(qset, batch_size=4, sampler=DistributedSliceSampler(qset))
+    bad = torch.utils.data.DataLoader(gset, batch_size=4, sampler=DistributedSliceSampler(gset), drop_last=True)
+    with pytest.raises(ValueError, match="DistributedSliceSampler"):
+        Evaluator(model).evaluate(ql, query + gallery, query, gallery, gt, gallery_loader=bad)
