@@ -166,3 +166,15 @@ def tie_free_matrix(rows: int, cols: int, seed: int = 41, scale: float = 4.0) ->
     m = np.stack([(rng.permutation(cols) + rng.uniform(0.0, 0.4, size=cols)) * (scale / cols)
                   for _ in range(rows)]).astype(np.float32)
     return torch.from_numpy(m)
+
+
+def tuple_lists(num_query: int, num_gallery: int, seed: int = 41):
+    """Positive / exclusion lists for the mining-sampler tests: per query a few "positives" and a
+    larger "non-negative" zone around them (gallery positions), seeded."""
+    rng = np.random.default_rng([seed, 10])
+    pos, neg = [], []
+    for _ in range(num_query):
+        c = int(rng.integers(30, num_gallery - 30))
+        pos.append(sorted(int(v) for v in rng.choice(np.arange(c - 3, c + 4), size=3, replace=False)))
+        neg.append(list(range(c - 25, c + 26)))
+    return pos, neg

@@ -195,6 +195,20 @@ def main():
         np.savez_compressed(OUT / f"{name}.npz", Q=Q, G=G, seed=seed,
                             sort_idx=smp.sort_idx.numpy().astype(np.int16))
         print(name, tuple(smp.sort_idx.shape))
+        # the tuples the reference's sampler yields from that ranking (sampler.py:62-86), two epochs
+        # (the second one sees the first one's negative cache), seeded `random`, two replicas
+        import random
+        pos, neg = synth.tuple_lists(Q, G, seed)
+        tuples = {}
+        for r in range(2):
+            s2 = DistributedRandomTupleSampler(list(range(Q)), list(range(G)), pos, neg, neg_num=5, neg_pool=40,
+                                               num_replicas=2, rank=r)
+            random.seed(1000 + r)
+            for ep in range(2):
+                s2.sort_gallery(distmat, list(range(1, Q)))          # 9 anchors: padded for 2 replicas
+                tuples[f"r{r}_e{ep}"] = np.asarray(list(iter(s2)), dtype=np.int32)
+        np.savez_compressed(OUT / "tuple_sampler.npz", Q=Q, G=G, seed=seed, **tuples)
+        print("tuple_sampler", {k: v.shape for k, v in tuples.items()})
 
     run_sort_gallery("sort_gallery", 10, 2500, seed=41)
     run_rerank("rerank_small", 24, 90, seed=31)

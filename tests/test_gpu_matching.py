@@ -332,3 +332,11 @@ def test_split_k_threshold_sample_gives_the_same_lists(dev, precision):
     v2, i2 = ops.sqdist_topk((qd * 37.0).contiguous(), (gd * 0.2).contiguous(), 10, precision=precision)
     wv2, wi2 = ops.row_topk(ops.pairwise_sqdist((qd * 37.0).contiguous(), (gd * 0.2).contiguous(), precision), 10)
     assert torch.equal(v2, wv2) and torch.equal(i2, wi2)
+
+
+def test_tuple_sampler_on_the_device_ranking(dev):
+    """DistributedRandomTupleSampler.sort_gallery ranks on the GPU (oibl_row_argsort); the tuples equal
+    the ones the reference's sampler yields from its torch.argsort."""
+    from test_host_logic import _run_tuple_sampler
+    torch.cuda.set_device(dev)
+    _run_tuple_sampler(lambda smp, d, sub: smp.sort_gallery(d, sub))

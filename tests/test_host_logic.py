@@ -238,3 +238,32 @@ def test_recall_prefix_beyond_the_kernel_limit_is_an_error():
     ev._check_prefix(1024)
     with pytest.raises(ValueError):
         ev._check_prefix(1025)
+
+
+def _run_tuple_sampler(rank_rows):
+    import random
+    from ibl.utils.data.sampler import DistributedRandomTupleSampler
+    g = load_golden("tuple_sampler")
+    Q, G, seed = int(g["Q"]), int(g["G"]), int(g["seed"])
+    pos, neg = synth.tuple_lists(Q, G, seed)
+    d = synth.tie_free_matrix(Q, G, seed)
+    for r in range(2):
+        smp = DistributedRandomTupleSampler(list(range(Q)), list(range(G)), pos, neg, neg_num=5, neg_pool=40,
+                                            num_replicas=2, rank=r)
+        random.seed(1000 + r)
+        for ep in range(2):
+            rank_rows(smp, d, list(range(1, Q)))
+            assert len(smp) == 5
+            got = np.asarray(list(iter(smp)), dtype=np.int32)
+            np.testing.assert_array_equal(got, g[f"r{r}_e{ep}"])
+
+
+def test_tuple_sampler_yields_the_reference_tuples():
+    """The mining sampler's tuple bookkeeping (easiest positive, hardest negatives from a random pool
+    plus last epoch's cache, replica slicing with padding) against the tuples the reference's own
+    DistributedRandomTupleSampler yielded (tests/golden/tuple_sampler.npz) — with the ranking taken
+    from the oracle here (the device ranking is the GPU test's subject)."""
+    def rank_rows(smp, d, sub):
+        smp.sort_idx = torch.from_numpy(om.ranking(d.numpy()))
+        smp._set_subset(sub)
+    _run_tuple_sampler(rank_rows)
