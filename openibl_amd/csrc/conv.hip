@@ -275,6 +275,12 @@ struct ConvParams {
                // only at the first step, 3 = both
   int out_f32;  // bf16x3 only: the output is written as plain fp32 NHWC (the layer feeding the head)
   int korder;   // K order of the implicit GEMM (test hook, see ConvRingALoader::begin_tile)
+  // split-K (layers with too few tiles to fill the chip, e.g. conv5 of a single image: 40 tiles):
+  // gridDim.y = ksplit workgroups share a tile, each contracts steps/ksplit K-steps from zero and
+  // dumps its fp32 accumulators to partial[ks][m_total][cout]; conv_splitk_reduce_kernel adds them in
+  // a fixed order, then bias / ReLU / pool / store.
+  int ksplit;
+  float* partial;
 };
 
 // one output element into the staged tile row (row-major [BN] of T; bf16x3: (hi, lo) groups or fp32)
@@ -299,7 +305,8 @@ struct ConvALoader {
   int tap, cc, cchunks, W, ablate, korder;
   long pix_bytes;
 
-  __device__ inline void init(const WaveCoord& c, const ConvParams& p, long m0, int tap0) {
+  // step0: first K-step of this workgroup (split-K), in the loop's own order
+  __device__ inline void init(const WaveCoord& c, const ConvParams& p, long m0, int step0) {
     using T = typename Cfg::T;
     const int piece = load_piece_bytes<Cfg>(c);
     pix_bytes = (long)p.cin * sizeof(T);
@@ -335,8 +342,8 @@ struct ConvALoader {
       mask[j] = mk;
       base[j] = reinterpret_cast<const char*>(p.in) + off + piece;
     }
-    tap = tap0;
-    cc = 0;
+    tap = korder ? step0 % 9 : step0 / cchunks;
+    cc = korder ? step0 / 9 : step0 % cchunks;
     tap_off = (long)((tap / 3 - 1) * W + (tap % 3 - 1)) * pix_bytes;
   }
   __device__ inline const char* src(int j) const {
@@ -367,17 +374,17 @@ struct ConvBLoader {
   long tap_stride, off;
   int tap, cc, cchunks, ablate, step, korder;
   __device__ inline bool active() const { return !((ablate & 2) && step != 0); }
-  __device__ inline void init(const WaveCoord& c, const ConvParams& prm, long n0, int tap0) {
+  __device__ inline void init(const WaveCoord& c, const ConvParams& prm, long n0, int step0) {
     using T = typename Cfg::T;
     const int piece = load_piece_bytes<Cfg>(c);
     cchunks = prm.cin / Cfg::BK;
-    cc = 0;
-    tap = tap0;
     ablate = prm.ablate;
     korder = prm.korder;
+    tap = korder ? step0 % 9 : step0 / cchunks;
+    cc = korder ? step0 / 9 : step0 % cchunks;
     step = 0;
     tap_stride = (long)prm.cin * sizeof(T) * prm.cout;
-    off = tap * tap_stride;
+    off = tap * tap_stride + cc * 128;
 #pragma unroll
     for (int j = 0; j < Cfg::B_LOADS; ++j) {
       const long n = n0 + load_row<Cfg>(c, j);
@@ -407,7 +414,7 @@ constexpr int conv_lds_bytes() {
   return epi > Cfg::MAIN_LDS_BYTES ? epi : Cfg::MAIN_LDS_BYTES;
 }
 
-template <typename Cfg, bool POOL, bool GLDS>
+template <typename Cfg, bool POOL, bool GLDS, bool SPLITK = false>
 __global__ __launch_bounds__(Cfg::NTHREADS) void conv3x3_igemm_kernel(ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using T = typename Cfg::T;
@@ -416,18 +423,22 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void conv3x3_igemm_kernel(ConvParams
   const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
   const long m0 = (long)tm * Cfg::BM, n0 = (long)tn * Cfg::BN;
+  const int steps_all = 9 * (p.cin / Cfg::BK);
+  const int nsteps = SPLITK ? steps_all / p.ksplit : steps_all;
+  const int step0 = SPLITK ? (int)blockIdx.y * nsteps : 0;
 
   ConvALoader<Cfg, POOL> la;
   ConvBLoader<Cfg> lb;
-  la.init(c, p, m0, 0);
-  lb.init(c, p, n0, 0);
+  la.init(c, p, m0, step0);
+  lb.init(c, p, n0, step0);
 
   // accumulators start at the bias (every kernel of this file orders the sum that way, so that
-  // all variants of a layer produce identical bits)
+  // all variants of a layer produce identical bits); split-K parts start at zero, the bias is the
+  // first term of the reduction
   f32x16_t acc[TM][TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    float b = p.bias[n0 + (c.wn * TN + j) * 32 + (c.lane & 31)];
+    float b = SPLITK ? 0.f : p.bias[n0 + (c.wn * TN + j) * 32 + (c.lane & 31)];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -437,8 +448,24 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void conv3x3_igemm_kernel(ConvParams
       }
   }
 
-  gemm_nt_mainloop<Cfg, GLDS>(acc, smem, c, la, lb, 9 * (p.cin / Cfg::BK));
+  gemm_nt_mainloop<Cfg, GLDS>(acc, smem, c, la, lb, nsteps);
   // (the main loop ends on a workgroup barrier: the staging LDS is free for the epilogue)
+
+  if constexpr (SPLITK) {
+    float* part = p.partial + (size_t)blockIdx.y * (size_t)p.m_total * p.cout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const long n = n0 + (c.wn * TN + j) * 32 + (c.lane & 31);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long m = m0 + (c.wm * TM + i) * 32 + acc_row(r, c.lane);
+          if (m < p.m_total) part[m * p.cout + n] = acc[i][j][r];
+        }
+    }
+    return;
+  }
 
   constexpr int PITCH = Cfg::BN * (int)sizeof(T) + 16;
   constexpr int OUT_ROWS = POOL ? Cfg::BM / 4 : Cfg::BM;
@@ -482,6 +509,41 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void conv3x3_igemm_kernel(ConvParams
   }
 }
 
+// out[row][ch] = act(bias[ch] + sum_ks partial[ks][m][ch])  (POOL: max over the 4 GEMM rows of a quad
+// first) — the bias leads the sum like in the one-pass kernels, parts are added in ks order.
+template <typename T, bool POOL>
+__global__ void conv_splitk_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
+                                          char* __restrict__ out, long out_rows, long m_total, int cout,
+                                          int ksplit, int relu, int out_f32) {
+  const long total = out_rows * cout;
+  const size_t part = (size_t)m_total * cout;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / cout;
+    const int ch = (int)(i - row * cout);
+    float v = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < (POOL ? 4 : 1); ++q) {
+      const size_t m = POOL ? (size_t)row * 4 + q : (size_t)row;
+      float a = bias[ch];
+      for (int ks = 0; ks < ksplit; ++ks) a += partial[ks * part + m * cout + ch];
+      v = fmaxf(v, a);
+    }
+    if (relu) v = fmaxf(v, 0.f);
+    conv_stage_store<T>(out + (size_t)row * cout * sizeof(T), ch, v, out_f32);
+  }
+}
+
+// split factor for a layer whose tiling leaves most CUs idle (0 = none); shared by the launch and
+// by the workspace query.  128-row tiles; parts of >= 6 K-steps; up to 512 workgroups.
+static int conv_splitk_factor(long m_total, int cout, int steps) {
+  const long tiles = ((m_total + 127) / 128) * (cout / (cout % 128 == 0 ? 128 : 64));
+  if (tiles > 192 || steps < 12) return 0;
+  const int cands[] = {8, 6, 4, 3, 2};
+  for (int s : cands)
+    if (steps % s == 0 && steps / s >= 6 && tiles * s <= 512) return s;
+  return 0;
+}
+
 template <typename Cfg, bool POOL, bool GLDS>
 static int launch_conv_kernel(const ConvParams& q, long grid, hipStream_t st) {
   constexpr int lds = conv_lds_bytes<Cfg, POOL>();
@@ -504,6 +566,31 @@ static int launch_conv_cfg(const ConvParams& p, hipStream_t st) {
   }
   return g_regstage ? launch_conv_kernel<Cfg, POOL, false>(q, grid, st)
                     : launch_conv_kernel<Cfg, POOL, true>(q, grid, st);
+}
+
+// split-K launch: the partial pass of Cfg (128-row tiles) + the reduction
+template <typename Cfg, bool POOL>
+static int launch_conv_splitk(const ConvParams& p, hipStream_t st) {
+  using T = typename Cfg::T;
+  ConvParams q = p;
+  q.tiles_n = p.cout / Cfg::BN;
+  const long grid = ((p.m_total + Cfg::BM - 1) / Cfg::BM) * q.tiles_n;
+  auto launch = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)p.ksplit), dim3(Cfg::NTHREADS),
+                       Cfg::MAIN_LDS_BYTES, st, q);
+  };
+  if (g_regstage)
+    launch(conv3x3_igemm_kernel<Cfg, POOL, false, true>);
+  else
+    launch(conv3x3_igemm_kernel<Cfg, POOL, true, true>);
+  OIBL_LAUNCH_CHECK();
+  const long total = p.out_rows * p.cout;
+  unsigned blocks = (unsigned)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL((conv_splitk_reduce_kernel<T, POOL>), dim3(blocks), dim3(256), 0, st, p.partial, p.bias,
+                     (char*)p.out, p.out_rows, p.m_total, p.cout, p.ksplit, p.relu, p.out_f32);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
 }
 
 static int g_ring_raster = 0;                     // test hook: xcd_tile() mode of the ring kernels
@@ -590,6 +677,11 @@ static int launch_conv(const ConvParams& p, int pool, hipStream_t st) {
   using C128x64 = GemmCfg<T, 2, 2, 2, 1>;
 #define OIBL_CONV_DISPATCH(CFG) \
   return pool ? launch_conv_cfg<CFG, true>(p, st) : launch_conv_cfg<CFG, false>(p, st)
+  if (p.ksplit > 1 && p.partial && !p.ablate && g_conv_tile == 0) {
+    if (p.cout % 128 == 0)
+      return pool ? launch_conv_splitk<C128x128, true>(p, st) : launch_conv_splitk<C128x128, false>(p, st);
+    return pool ? launch_conv_splitk<C128x64, true>(p, st) : launch_conv_splitk<C128x64, false>(p, st);
+  }
   if constexpr (std::is_same<T, bf16x3_t>::value) {
     // ring kernels as in bf16 (pooled layers never write fp32); generic tiles whose staged output
     // (4 bytes per element) fits next to nothing else in LDS: 256 x {128, 64}, 128 x {128, 64}
@@ -1458,9 +1550,19 @@ static bool precision_ok(int precision) {
 }
 
 // out_f32 (bf16x3 only): write the output as plain fp32 NHWC
+static int g_conv_splitk = 1;  // test hook: 0 = never split K
+
+// splitk_ws (optional): scratch for the split-K partials of layers with too few tiles
+// (conv_splitk_bytes); without it every layer runs one-pass
+static size_t conv_splitk_bytes(long m_total, int cin, int cout, int precision) {
+  const int steps = 9 * (cin / (precision == OIBL_BF16 ? 64 : 32));
+  const int s = conv_splitk_factor(m_total, cout, steps);
+  return s ? align_up((size_t)s * m_total * cout * sizeof(float), 256) : 0;
+}
+
 static int conv3x3_impl(const void* in, int N, int H, int W, int cin, const void* packed_w,
                         const float* bias, int cout, int relu, int pool, int precision, void* out,
-                        hipStream_t st, int out_f32 = 0) {
+                        hipStream_t st, int out_f32 = 0, void* splitk_ws = nullptr) {
   OIBL_REQUIRE(in && packed_w && bias && out, "conv3x3: null pointer");
   OIBL_REQUIRE(precision_ok(precision), "conv3x3: bad precision %d", precision);
   const int bk = precision == OIBL_BF16 ? 64 : 32;
@@ -1500,6 +1602,10 @@ static int conv3x3_impl(const void* in, int N, int H, int W, int cin, const void
     p.out_rows = (long)N * H * W;
     p.m_total = p.out_rows;
   }
+  p.ksplit = 0;
+  p.partial = (float*)splitk_ws;
+  if (splitk_ws && g_conv_splitk)
+    p.ksplit = conv_splitk_factor(p.m_total, cout, 9 * (cin / bk));
   if (precision == OIBL_BF16X3) return launch_conv<bf16x3_t>(p, pool, st);
   return precision == OIBL_BF16 ? launch_conv<bf16_t>(p, pool, st) : launch_conv<float>(p, pool, st);
 }
@@ -1544,6 +1650,11 @@ int oibl_debug_set_conv_ablate(int mode) {
 
 int oibl_debug_set_ring_ablate(int mode) {
   g_ring_ablate = mode;
+  return OIBL_OK;
+}
+
+int oibl_debug_set_conv_splitk(int on) {
+  g_conv_splitk = on ? 1 : 0;
   return OIBL_OK;
 }
 
@@ -1698,12 +1809,28 @@ static void vgg_buffer_elems(int N, int H, int W, size_t* a, size_t* b) {
   *b = eb;
 }
 
+// scratch for the split-K partials of the layers whose tiling leaves the chip idle (small batches)
+static size_t vgg_splitk_bytes(int N, int H, int W, int precision) {
+  size_t mx = 0;
+  int h = H, w = W;
+  for (int l = 1; l < OIBL_VGG16_NUM_CONV; ++l) {
+    const long m_total = kVgg[l].pool ? (long)N * (h / 2) * (w / 2) * 4 : (long)N * h * w;
+    const size_t b = conv_splitk_bytes(m_total, kVgg[l].cin, kVgg[l].cout, precision);
+    mx = b > mx ? b : mx;
+    if (kVgg[l].pool) {
+      h /= 2;
+      w /= 2;
+    }
+  }
+  return mx;
+}
+
 size_t oibl_vgg16_workspace_bytes(int N, int H, int W, int precision) {
   if (N <= 0 || H < 16 || W < 16) return 0;
   size_t ea, eb;
   vgg_buffer_elems(N, H, W, &ea, &eb);
   const size_t es = oibl_elem_size(precision);
-  return align_up(ea * es, 256) + align_up(eb * es, 256);
+  return align_up(ea * es, 256) + align_up(eb * es, 256) + vgg_splitk_bytes(N, H, W, precision);
 }
 
 int oibl_vgg16_conv5_forward(const float* x_nchw, int N, int H, int W,
@@ -1734,6 +1861,7 @@ static int vgg_forward_impl(const void* x, int u8, const float* mean3, const flo
   const size_t es = oibl_elem_size(precision);
   char* bufA = (char*)ws;
   char* bufB = bufA + align_up(ea * es, 256);
+  char* splitk = vgg_splitk_bytes(N, H, W, precision) ? bufB + align_up(eb * es, 256) : nullptr;
   hipStream_t st = (hipStream_t)stream;
 
   int rc;
@@ -1774,7 +1902,7 @@ static int vgg_forward_impl(const void* x, int u8, const float* mean3, const flo
     // bf16x3: the last layer hands the head a plain fp32 map
     rc = conv3x3_impl(cur, N, h, w, kVgg[l].cin, packed_w_host[l], bias_host[l], kVgg[l].cout,
                       kVgg[l].relu, kVgg[l].pool, precision, dst, st,
-                      l == OIBL_VGG16_NUM_CONV - 1);
+                      l == OIBL_VGG16_NUM_CONV - 1, splitk);
     if (rc) return rc;
     if (kVgg[l].pool) {
       h /= 2;

@@ -168,6 +168,12 @@ def set_conv_korder(mode: int) -> None:
     _lib.load().oibl_debug_set_conv_korder(int(mode))
 
 
+def set_conv_splitk(on: bool) -> None:
+    """Test hook: allow / forbid split-K for the backbone layers whose tiling leaves the chip idle
+    (small batches: conv4 / conv5 of a single image)."""
+    _lib.load().oibl_debug_set_conv_splitk(1 if on else 0)
+
+
 def set_conv_c64(on) -> None:
     """Test hook: resident-weights kernel for Cin = 64 layers (bf16): False/0 = never, True/1 = auto
     (Cout = 64 only; wider layers go to the ring kernel), 2 = every Cin = 64 layer."""

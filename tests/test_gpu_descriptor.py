@@ -169,3 +169,27 @@ def test_uint8_input_equals_normalised_input(dev, N, H, W, precision):
     want = model(x.to(dev))
     got = model(u8.to(dev))
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-6), ("bf16x3", 2e-5), ("bf16", 6e-3)])
+@pytest.mark.parametrize("N,H,W", [(1, 480, 640), (2, 240, 320), (1, 70, 90)])
+def test_split_k_small_batches(model, dev, precision, tol, N, H, W):
+    """Layers whose tiling leaves the chip idle (conv4 / conv5 of a single image: 40-152 tiles) run
+    split-K: partial sums in fp32, fixed-order reduction with bias / ReLU / pool.  Same convolution,
+    other summation order: equal to rounding with the one-pass route, and (fp32 / bf16x3) within 1e-4
+    of the oracle."""
+    x = synth.images(N, H, W, seed=H + N)
+    model.set_precision(precision)
+    try:
+        ops.set_conv_splitk(False)
+        a = model(x.to(dev)).cpu()
+        ops.set_conv_splitk(True)
+        b = model(x.to(dev)).cpu()
+    finally:
+        ops.set_conv_splitk(True)
+        model.set_precision("fp32")
+    assert_rel_l2(f"split-K on vs off {precision} {N}x{H}x{W}", b, a, tol)
+    if precision != "bf16" and H <= 240:
+        with torch.no_grad():
+            want = od.embednetpca(x, synth.embednetpca_state(0))
+        assert_rel_l2(f"split-K vs oracle {precision}", b, want, TOL_FP32)
