@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 R=$(pwd); TAG=${1:-pmc_bench}
 OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 3 --warmup 1 --eager --skip-cpu-baseline --queries 8192 --gallery 81920"
+CMD="python $R/bench.py --steps 3 --warmup 1 --eager --skip-cpu-baseline --skip-api --queries 8192 --gallery 81920"
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
            "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do

@@ -50,6 +50,10 @@ if [ -z "$QUICK" ]; then
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_match -o bench -- python $R/bench.py --steps 2 --warmup 1 --skip-cpu-baseline --skip-api > $OUT/prof_match.log 2>&1
 fi
 cd $R
+if [ -z "$QUICK" ]; then
+  # MFMA-busy / clock / L2 hit / LDS bank conflicts per kernel, both modes + matching (eager launches)
+  bash tests/run_gpu_pmc_bench.sh ${TAG}/pmc > $OUT/pmc.log 2>&1
+fi
 # keep the merged output small: drop per-dispatch traces larger than 8 MiB
 find $OUT -type f -size +8M -print -delete
 find $OUT -type f | wc -l
