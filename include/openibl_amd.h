@@ -161,7 +161,13 @@ int oibl_vgg16_stem_bf16(const float* x_nchw, int N, int H, int W, const float* 
 /* Whole backbone: x [N][3][H][W] fp32 -> feat [N][P][512] T, P = (H/16)*(W/16) (floor at
  * every pool).  packed_w_host / bias_host are HOST arrays of 13 DEVICE pointers: entry 0
  * is the plain [64][3][3][3] fp32 conv1_1 weight, entries 1..12 are packed by
- * oibl_pack_conv3x3_weights; bias entries are [Cout] fp32. */
+ * oibl_pack_conv3x3_weights; bias entries are [Cout] fp32.
+ * OIBL_BF16X3: activations between the layers are (hi, lo) split elements, but `feat` is written as
+ * plain fp32 (the head consumes it with OIBL_F32).
+ * The workspace holds the two ping-pong activation buffers and, for small batches, the fp32
+ * partial tiles of the layers that run split-K (a layer whose 128-row tiling gives <= 192 tiles is
+ * contracted by 2-8 workgroups per tile and reduced in a fixed order: deterministic, equal to
+ * rounding with the one-pass kernels). */
 size_t oibl_vgg16_workspace_bytes(int N, int H, int W, int precision);
 int oibl_vgg16_conv5_forward(const float* x_nchw, int N, int H, int W,
                              const void* const* packed_w_host,
