@@ -158,6 +158,16 @@ int oibl_vgg16_stem_bf16(const float* x_nchw, int N, int H, int W, const float* 
                          const float* b1, const void* packed_w2, const float* b2, void* out,
                          void* stream);
 
+/* The same fusion in OIBL_BF16X3: out [N][H/2][W/2][64] as (hi, lo) split elements; packed_w2 from
+ * oibl_pack_conv3x3_weights(..., OIBL_BF16X3).  A workgroup serves half of conv1_2's output channels
+ * and consumes a tile in two passes over halves of its input channels, so that the split weights
+ * (72 KiB) and two 42.5 KiB halo buffers fit LDS.  Bit-identical to oibl_conv1_1_nchw followed by
+ * oibl_conv3x3_nhwc(relu=1, pool=1) in OIBL_BF16X3 up to the summation order of conv1_2
+ * (channel chunk outer, tap inner); used automatically by oibl_vgg16_conv5_forward. */
+int oibl_vgg16_stem_x3(const float* x_nchw, int N, int H, int W, const float* w1_oihw,
+                       const float* b1, const void* packed_w2, const float* b2, void* out,
+                       void* stream);
+
 /* Whole backbone: x [N][3][H][W] fp32 -> feat [N][P][512] T, P = (H/16)*(W/16) (floor at
  * every pool).  packed_w_host / bias_host are HOST arrays of 13 DEVICE pointers: entry 0
  * is the plain [64][3][3][3] fp32 conv1_1 weight, entries 1..12 are packed by

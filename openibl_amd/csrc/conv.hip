@@ -1461,6 +1461,370 @@ static int launch_vgg_stem(const void* x, int N, int H, int W, const float* mean
   return OIBL_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// VGG stem, fused, bf16x3: conv1_1 + ReLU + conv1_2 + ReLU + 2x2 max-pool in ONE launch.
+//   x [N][3][H][W] fp32  ->  out [N][H/2][W/2][64] bf16x3 ((hi, lo) groups)
+// Unfused, conv1_1 writes 2.5 GB of split activations per 32 images (0.86 ms, write-bound) and
+// conv1_2 — Cout = 64: no ring tile shape — runs on the generic core at 45 % of the matrix pipe
+// (2.5 ms): 22 % of the bf16x3 step for 13 % of its FLOPs.  The bf16 stem's plan (72 KiB of
+// conv1_2 weights + two 42.5 KiB halo buffers of all 64 channels) does not survive 4-byte
+// elements; this kernel keeps its producer / consumer structure and splits the work so that it does:
+//   * a workgroup serves HALF of conv1_2's output channels (blockIdx.y = 0 / 1; both halves run
+//     at the same time on different CUs and gather the same input window through L2): 9 taps x 2
+//     channel halves x 32 cout x 128 B = 72 KiB of split weights stay resident in LDS;
+//   * a tile is consumed in two PASSES, one per half of conv1_2's input channels: a halo buffer holds
+//     340 pixels x [32 hi | 32 lo] of ONE 32-channel half (42.5 KiB, exactly the bf16 stem's buffer)
+//     and the two buffers alternate between the passes.  Producers (waves 4-7) run conv1_1 for the
+//     32 channels of the next pass (K = 27 padded to 32: lo.hi + hi.lo + hi.hi, 6 MFMAs per 32 halo
+//     pixels), ReLU, split, and write the halo image the consumers read; the gathered input window
+//     and its (hi, lo) fragments are kept in registers for both passes of a tile.  Consumers (waves
+//     0-3) accumulate both passes in registers (9 taps x 12 MFMAs per pass), then pool and store.
+// Only 4 waves read LDS for the main contraction (the generic kernel has 16 competing for it).
+// Numerics: operation for operation those of conv1_1_mfma_kernel<X3> followed by the generic
+// bf16x3 convolution in K order (channel chunk, tap) — bit-identical to that pair (tested).
+// LDS: 72 KiB + 2 x 42.5 KiB = 157 KiB.
+// ---------------------------------------------------------------------------------------------
+constexpr int S3_W_BYTES = 2 * 9 * 32 * 128;
+constexpr int S3_LDS_BYTES = S3_W_BYTES + 2 * ST_HALO_BYTES;
+
+__global__ __launch_bounds__(512) void vgg_stem_x3_kernel(StemParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const wl = smem;                 // [pass h][tap][32 cout][32 hi | 32 lo of input channels 32h..]
+  char* const hb = smem + S3_W_BYTES;    // halo buffer h: channels 32h..32h+31 of the current tile
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int first = blockIdx.x, stride = gridDim.x;
+  const int co0 = blockIdx.y * 32;       // this workgroup's conv1_2 output channels
+  int niter = 0;
+  if (first < p.ntiles) niter = (p.ntiles - first + stride - 1) / stride;
+  const int nstages = 2 * niter;
+  const int Ho = p.H >> 1, Wo = p.W >> 1;
+
+  if (wave >= 4) {
+    // ================================ producers ================================================
+    const int pw = wave - 4;
+    const __amdgpu_buffer_rsrc_t rs_x =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    // conv1_1 weights (A operand), split: w?[h][s] element e <-> channel 32 h + l31, k = 16 s + 8 half + e
+    bf16x8_t wh[2][2], wlo[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = 16 * s + 8 * half + e;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float v = k < 27 ? p.w1[(32 * h + l31) * 27 + k] : 0.f;
+          uint16_t hi, lo;
+          x3_split(v, hi, lo);
+          wh[h][s][e] = (short)hi;
+          wlo[h][s][e] = (short)lo;
+        }
+      }
+    float bb[2][16];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bb[h][r] = p.b1[32 * h + acc_row(r, lane)];
+    const int plane = p.H * p.W;
+
+    // tile-independent lane geometry (as in vgg_stem_kernel)
+    int g_row[3], g_swz[3], g_hy[3], g_hx[3], g_rel[3];
+#pragma unroll
+    for (int bi = 0; bi < 3; ++bi) {
+      const int r = 32 * (pw + 4 * bi) + l31;
+      const int rc = r < ST_HALO_PX ? r : ST_HALO_PX - 1;
+      g_row[bi] = r;
+      g_hy[bi] = rc / C64_HW;
+      g_hx[bi] = rc - g_hy[bi] * C64_HW;
+      g_swz[bi] = c64_swz(g_hy[bi], g_hx[bi]);
+      g_rel[bi] = g_hy[bi] * p.W + g_hx[bi];
+      asm volatile("" : "+v"(g_rel[bi]));
+    }
+    int g_dk[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      int k = 16 * (j >> 3) + 8 * half + (j & 7);
+      if (k >= 27) k -= 8;
+      const int c = k / 9, t = k - 9 * c;
+      g_dk[j] = c * plane + (t / 3 - 1) * p.W + (t % 3 - 1);
+      asm volatile("" : "+v"(g_dk[j]));
+    }
+    auto tap_of = [&](int j) __attribute__((always_inline)) {  // border tiles only
+      const int kA = 16 * (j >> 3) + (j & 7), kB = kA + 8 >= 27 ? kA : kA + 8;
+      return half ? kB % 9 : kA % 9;
+    };
+    auto decode = [&](int tile, int& n, int& ty, int& tx) __attribute__((always_inline)) {
+      const unsigned r2 = (unsigned)tile / (unsigned)p.tiles_x;
+      tx = tile - (int)r2 * p.tiles_x;
+      n = (int)(r2 / (unsigned)p.tiles_y);
+      ty = (int)r2 - n * p.tiles_y;
+    };
+    auto is_interior = [&](int ty, int tx) __attribute__((always_inline)) {
+      return ty >= 1 && ty * 8 + 10 <= p.H && tx >= 1 && tx * 32 + 34 <= p.W;
+    };
+    float xv[3][16];
+    auto issue_loads = [&](int tile) __attribute__((always_inline)) {
+      int n, ty, tx;
+      decode(tile, n, ty, tx);
+      const int y0 = ty * 8 - 1, x0 = tx * 32 - 1;
+      const int origin = ((n * 3) * p.H + y0) * p.W + x0;
+      if (is_interior(ty, tx)) {
+#pragma unroll
+        for (int bi = 0; bi < 3; ++bi) {
+          if (pw + 4 * bi >= ST_BLOCKS) continue;  // wave-uniform
+          const int base = origin + g_rel[bi];
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            xv[bi][j] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (base + g_dk[j]) * 4, 0, 0));
+        }
+      } else {
+#pragma unroll
+        for (int bi = 0; bi < 3; ++bi) {
+          if (pw + 4 * bi >= ST_BLOCKS) continue;
+          const int y = y0 + g_hy[bi], x = x0 + g_hx[bi];
+          unsigned mk = 0;
+          if (y >= 0 && y < p.H && x >= 0 && x < p.W) {
+            const bool ya = y > 0, yc = y + 1 < p.H, xa = x > 0, xc = x + 1 < p.W;
+            mk = (ya && xa ? 1u : 0u) | (ya ? 2u : 0u) | (ya && xc ? 4u : 0u) | (xa ? 8u : 0u) | 16u |
+                 (xc ? 32u : 0u) | (yc && xa ? 64u : 0u) | (yc ? 128u : 0u) | (yc && xc ? 256u : 0u);
+          }
+          const int base = origin + g_rel[bi];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const bool ok = (mk >> tap_of(j)) & 1u;
+            const unsigned off = ok ? (unsigned)(base + g_dk[j]) * 4u : ST_OOB;
+            xv[bi][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)off, 0, 0));
+          }
+        }
+      }
+    };
+    // the gathered window as (hi, lo) B fragments, kept for both passes of the tile
+    bf16x8_t xh[3][2], xl[3][2];
+    auto convert = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int bi = 0; bi < 3; ++bi) {
+        if (pw + 4 * bi >= ST_BLOCKS) continue;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            uint16_t hi, lo;
+            x3_split(xv[bi][8 * s + e], hi, lo);
+            xh[bi][s][e] = (short)hi;
+            xl[bi][s][e] = (short)lo;
+          }
+      }
+    };
+    // conv1_1 of channel half h on the converted window, bias + ReLU + split, halo tile -> LDS
+    auto produce = [&](int tile, int h, char* buf) __attribute__((always_inline)) {
+      int n, ty, tx;
+      decode(tile, n, ty, tx);
+      const int y0 = ty * 8 - 1, x0 = tx * 32 - 1;
+      const bool interior = is_interior(ty, tx);
+#pragma unroll
+      for (int bi = 0; bi < 3; ++bi) {
+        if (pw + 4 * bi >= ST_BLOCKS) continue;  // wave-uniform
+        f32x16_t acc;
+        __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = h ? bb[1][r] : bb[0][r];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {   // the order of conv1_1_mfma_kernel<X3>
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h ? wlo[1][s] : wlo[0][s], xh[bi][s], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h ? wh[1][s] : wh[0][s], xl[bi][s], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h ? wh[1][s] : wh[0][s], xh[bi][s], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        // D[row = channel][col = pixel]: registers 4g..4g+3 = channels 8 g + 4 half + 0..3 of the
+        // lane's pixel -> hi: 8 bytes of 16-B slot g, lo: of slot 4 + g (both swizzled), + 8 half.
+        const int y = y0 + g_hy[bi], x = x0 + g_hx[bi];
+        const bool pix_ok = interior || (y >= 0 && y < p.H && x >= 0 && x < p.W);
+        if (g_row[bi] < ST_HALO_PX) {
+          char* row = buf + g_row[bi] * 128 + 8 * half;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            uint2 hi, lo;
+            ring_split4(fmaxf(acc[4 * g], 0.f), fmaxf(acc[4 * g + 1], 0.f), fmaxf(acc[4 * g + 2], 0.f),
+                        fmaxf(acc[4 * g + 3], 0.f), hi, lo);
+            if (!pix_ok) {   // outside the image: conv1_2's zero padding, not a conv1_1 output
+              hi = make_uint2(0u, 0u);
+              lo = make_uint2(0u, 0u);
+            }
+            *reinterpret_cast<uint2*>(row + ((g ^ g_swz[bi]) << 4)) = hi;
+            *reinterpret_cast<uint2*>(row + (((4 + g) ^ g_swz[bi]) << 4)) = lo;
+          }
+        }
+      }
+    };
+
+    // stage s = (tile s >> 1, channel half s & 1) goes to halo buffer s & 1; the producers run one
+    // stage ahead of the consumers, the gathers one tile ahead of that
+    if (niter > 0) {
+      issue_loads(first);
+      convert();
+      if (niter > 1) issue_loads(first + stride);
+      produce(first, 0, hb);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int s = 0; s < nstages; ++s) {
+      const int nx = s + 1;
+      if (nx < nstages) {
+        const int it = nx >> 1;
+        if ((nx & 1) == 0) {   // a new tile: its window has arrived
+          convert();
+          if (it + 1 < niter) issue_loads(first + (it + 1) * stride);
+        }
+        produce(first + it * stride, nx & 1, hb + (nx & 1) * ST_HALO_BYTES);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    return;
+  }
+
+  // ================================== consumers ================================================
+  {
+    const int piece = ((lane & 7) ^ (4 * (wave & 1) + (lane >> 4))) * 16;
+#pragma unroll
+    for (int j = 0; j < 18; ++j) {
+      const int q = j * 4 + wave;
+      const int r = q * 8 + (lane >> 3);          // LDS row: (h * 9 + tap) * 32 + c
+      const int h = r / 288, rem = r - 288 * h;
+      const int tap = rem >> 5, c = rem & 31;
+      glds16(p.w2 + ((long)(tap * 64 + co0 + c) * 256 + h * 128) + piece, wl + q * 1024);
+    }
+  }
+  int lhy[2], lhx[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    lhy[i] = 2 * wave + ((l31 >> 1) & 1);
+    lhx[i] = 16 * i + 2 * (l31 >> 2) + (l31 & 1);
+  }
+  int w_off[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) w_off[kk] = l31 * 128 + (((2 * kk + half) ^ ((l31 >> 1) & 7)) << 4);
+  const float bval = p.b2[co0 + l31];
+
+  // the pooled outputs of tile i are held back (hi | lo << 16 per pixel) and stored one pixel at a
+  // time between the matrix steps of tile i+1
+  uint32_t pend[8];
+  uint32_t pmask = 0;
+  char* pbase = p.out;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) pend[e] = 0;
+  auto store_px = [&](int e) __attribute__((always_inline)) {
+    if ((pmask >> e) & 1) {
+      uint16_t* o = reinterpret_cast<uint16_t*>(pbase + (8 * (e >> 2) + 2 * (e & 3)) * 256);
+      o[0] = (uint16_t)pend[e];
+      o[32] = (uint16_t)(pend[e] >> 16);
+    }
+  };
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  f32x16_t acc[2];
+  for (int s = 0; s < nstages; ++s) {
+    const int h = s & 1;
+    const int tile = first + (s >> 1) * stride;
+    const char* const cur = hb + h * ST_HALO_BYTES;
+    const char* const wbase = wl + h * (9 * 32 * 128);
+    if (h == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = bval;
+    }
+    // 18 steps (tap, 16-wide half pr of the K-tile), fragment reads one step ahead
+    bf16x8_t fah[2][2], fal[2][2], fbh[2], fbl[2];
+    auto load_step = [&](int sidx, bf16x8_t (&ah)[2], bf16x8_t (&al)[2], bf16x8_t& bh, bf16x8_t& bl)
+        __attribute__((always_inline)) {
+      const int tap = sidx >> 1, pr = sidx & 1;
+      const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int hy = lhy[i] + ky, hx = lhx[i] + kx;
+        const char* px = cur + (hy * C64_HW + hx) * 128;
+        const int sw = c64_swz(hy, hx);
+        ah[i] = *reinterpret_cast<const bf16x8_t*>(px + (((2 * pr + half) ^ sw) << 4));
+        al[i] = *reinterpret_cast<const bf16x8_t*>(px + (((2 * (pr + 2) + half) ^ sw) << 4));
+      }
+      bh = *reinterpret_cast<const bf16x8_t*>(wbase + tap * 4096 + w_off[pr]);
+      bl = *reinterpret_cast<const bf16x8_t*>(wbase + tap * 4096 + w_off[pr + 2]);
+    };
+    load_step(0, fah[0], fal[0], fbh[0], fbl[0]);
+#pragma unroll
+    for (int sidx = 0; sidx < 18; ++sidx) {
+      const int b = sidx & 1;
+      if (sidx + 1 < 18) load_step(sidx + 1, fah[b ^ 1], fal[b ^ 1], fbh[b ^ 1], fbl[b ^ 1]);
+      __builtin_amdgcn_sched_barrier(0);  // keep the next step's reads AHEAD of this step's MFMAs
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[b][i], fbh[b], acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[b][i], fbl[b], acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[b][i], fbh[b], acc[i], 0, 0, 0);
+      if (h == 0 && (sidx & 1) == 1 && (sidx >> 1) < 8) store_px(sidx >> 1);
+    }
+    // every fragment read of `cur` has been consumed by the MFMAs above: hand the buffer back
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (h == 1) {
+      const unsigned r2 = (unsigned)tile / (unsigned)p.tiles_x;
+      const int tx = tile - (int)r2 * p.tiles_x;
+      const int n = (int)(r2 / (unsigned)p.tiles_y), ty = (int)r2 - n * p.tiles_y;
+      const int oy = ty * 4 + wave;
+      // (a pending store of the previous tile that found no slot — none: all 8 went out in pass 0)
+      pbase = p.out + (((long)n * Ho + oy) * Wo + tx * 16 + half) * 256 + blockIdx.y * 128 + l31 * 2;
+      pmask = 0;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int ox = tx * 16 + 8 * i + 2 * g + half;
+          pmask |= (oy < Ho && ox < Wo) ? (1u << (4 * i + g)) : 0u;
+          const float v = fmaxf(fmaxf(fmaxf(acc[i][4 * g], acc[i][4 * g + 1]),
+                                      fmaxf(acc[i][4 * g + 2], acc[i][4 * g + 3])), 0.f);
+          uint16_t hi, lo;
+          x3_split(v, hi, lo);
+          pend[4 * i + g] = (uint32_t)hi | ((uint32_t)lo << 16);
+        }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) store_px(e);
+}
+
+static int launch_vgg_stem_x3(const float* x, int N, int H, int W, const float* w1, const float* b1,
+                              const void* packed_w2, const float* b2, void* out, hipStream_t st) {
+  StemParams p = {};
+  p.x = x;
+  p.w1 = w1;
+  p.b1 = b1;
+  p.w2 = (const char*)packed_w2;
+  p.b2 = b2;
+  p.out = (char*)out;
+  p.x_bytes = (unsigned)((size_t)N * 3 * H * W * 4);
+  p.N = N;
+  p.H = H;
+  p.W = W;
+  p.tiles_x = (W + 31) / 32;
+  p.tiles_y = (H + 7) / 8;
+  const long nt = (long)N * p.tiles_x * p.tiles_y;
+  OIBL_REQUIRE(nt < 0x7fffffffL, "vgg stem: too many tiles");
+  p.ntiles = (int)nt;
+  p.prof = nullptr;
+  int gx = 128;  // two workgroups (output-channel halves) per tile range: one persistent workgroup per CU
+  if (gx > p.ntiles) gx = p.ntiles;
+  auto kern = vgg_stem_x3_kernel;
+  OIBL_SET_MAX_LDS(kern, S3_LDS_BYTES);
+  hipLaunchKernelGGL(kern, dim3(gx, 2), dim3(512), S3_LDS_BYTES, st, p);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
+
 // uint8 NHWC -> normalised fp32 NCHW with the loader's arithmetic ((u / 255 - mean) / std, fp32,
 // correctly rounded divisions): the route of the uint8 entry point whenever the fused stem is not
 // used (fp32 precision, test hooks)
@@ -1636,6 +2000,16 @@ int oibl_vgg16_stem_bf16(const float* x_nchw, int N, int H, int W, const float* 
                "vgg16_stem: packed weights / output must be 16-byte aligned");
   return launch_vgg_stem<false>(x_nchw, N, H, W, nullptr, nullptr, w1_oihw, b1, packed_w2, b2, out,
                                 (hipStream_t)stream);
+}
+
+int oibl_vgg16_stem_x3(const float* x_nchw, int N, int H, int W, const float* w1_oihw, const float* b1,
+                       const void* packed_w2, const float* b2, void* out, void* stream) {
+  OIBL_REQUIRE(x_nchw && w1_oihw && b1 && packed_w2 && b2 && out, "vgg16_stem_x3: null pointer");
+  OIBL_REQUIRE(N > 0 && H >= 2 && W >= 2, "vgg16_stem_x3: bad shape N=%d H=%d W=%d", N, H, W);
+  OIBL_REQUIRE(stem_eligible(N, H, W), "vgg16_stem_x3: input of %d x 3 x %d x %d exceeds 3.5 GB", N, H, W);
+  OIBL_REQUIRE((uintptr_t)packed_w2 % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)x_nchw % 4 == 0,
+               "vgg16_stem_x3: packed weights / output must be 16-byte aligned");
+  return launch_vgg_stem_x3(x_nchw, N, H, W, w1_oihw, b1, packed_w2, b2, out, (hipStream_t)stream);
 }
 
 int oibl_debug_set_conv_c64(int on) {  // 0 = off, 1 = auto, 2 = every Cin = 64 layer
@@ -1879,7 +2253,19 @@ static int vgg_forward_impl(const void* x, int u8, const float* mean3, const flo
     OIBL_LAUNCH_CHECK();
     x_f32 = stage;
   }
-  if (fused) {
+  const bool fused3 = precision == OIBL_BF16X3 && g_stem_fused && stem_eligible(N, H, W) && !g_regstage &&
+                      !g_conv_ablate && g_conv_tile == 0;
+  if (fused3) {
+    // bf16x3: conv1_1 + conv1_2 + pool in one launch (the uint8 entry has normalised into x_f32)
+    if (ev_igemm_begin) OIBL_HIP_CHECK(hipEventRecord((hipEvent_t)ev_igemm_begin, st));
+    rc = launch_vgg_stem_x3(x_f32, N, H, W, (const float*)packed_w_host[0], bias_host[0], packed_w_host[1],
+                            bias_host[1], bufB, st);
+    if (rc) return rc;
+    h /= 2;
+    w /= 2;
+    cur = bufB;
+    l0 = 2;
+  } else if (fused) {
     // conv1_1 + conv1_2 + pool in one launch (the matrix-core span then starts with it)
     if (ev_igemm_begin) OIBL_HIP_CHECK(hipEventRecord((hipEvent_t)ev_igemm_begin, st));
     rc = u8 ? launch_vgg_stem<true>(x, N, H, W, mean3, std3, (const float*)packed_w_host[0],

@@ -75,6 +75,9 @@ def main():
         for name, ms, fl in rows:
             print(f"  tile={a.tile} {name:34s} {ms:9.3f} ms  {fl / ms / 1e9:9.1f} TFLOP/s")
         return
+    if p == "bf16x3":
+        t, _ = timed(lambda: ops.vgg16_stem_x3(x, packed[0], biases[0], packed[1], biases[1]), a.iters)
+        rows.append(("stem fused (conv1_1+conv01)", t, rows[0][2] + rows[1][2]))
     if p == "bf16":
         t, _ = timed(lambda: ops.vgg16_stem(x, packed[0], biases[0], packed[1], biases[1]), a.iters)
         rows.append(("stem fused (conv1_1+conv01)", t, rows[0][2] + rows[1][2]))

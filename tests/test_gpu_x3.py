@@ -253,3 +253,45 @@ def test_sqdist_topk_x3_fused_equals_matrix(dev):
     agree = (i.cpu().numpy() == want).mean()
     print(f"top-10 agreement with the fp32 oracle ranking: {agree:.6f}")
     assert agree > 0.999
+
+
+@pytest.mark.parametrize("N,H,W", [(1, 8, 32), (2, 16, 64), (1, 21, 45), (3, 30, 70), (1, 2, 2),
+                                   (2, 9, 33), (1, 64, 96), (5, 40, 136)])
+def test_vgg_stem_x3_fused(dev, N, H, W):
+    """bf16x3: conv1_1 + conv1_2 + pool in one launch (two channel-half passes per tile, half of the
+    output channels per workgroup): bit-identical to the two unfused launches with conv1_2 in the K
+    order (channel chunk, tap), and within the layer tolerance of the fp64 host convolutions."""
+    x, w1, b1 = _case(N, H, W, 3, 64, seed=5 * H + W)
+    x = x * 60.0
+    _, w2, b2 = _case(1, 4, 4, 64, 64, seed=H + 9 * W)
+    wp2 = ops.pack_conv3x3(w2.to(dev), "bf16x3")
+    y = ops.vgg16_stem_x3(x.to(dev), w1.to(dev), b1.to(dev), wp2, b2.to(dev))
+    assert tuple(y.shape) == (N, H // 2, W // 2, 64) and y.dtype == torch.int32
+    a1 = ops.conv1_1_nchw(x.to(dev), w1.to(dev), b1.to(dev), "bf16x3")
+    ops.set_conv_korder(1)
+    try:
+        ref = ops.conv3x3_nhwc(a1, wp2, b2.to(dev), True, True, "bf16x3")
+    finally:
+        ops.set_conv_korder(0)
+    assert torch.equal(y, ref)
+    h1 = F.relu(F.conv2d(x.double(), w1.double(), b1.double(), padding=1))
+    want = F.max_pool2d(F.relu(F.conv2d(h1, w2.double(), b2.double(), padding=1)), 2, 2)
+    if want.numel():
+        assert_rel_l2("fused bf16x3 stem vs host", _x3_out(y), want, 3e-5)
+
+
+def test_vgg16_backbone_x3_stem_toggle(dev, state_dict):
+    """The backbone entry with and without the fused bf16x3 stem: the same feature map up to the
+    summation order of conv1_2."""
+    x = synth.images(2, 64, 96, seed=4).to(dev)
+    ws = [state_dict[f"base_model.base.{i}.weight"].to(dev) for i in synth.CONV_IDX]
+    bs = [state_dict[f"base_model.base.{i}.bias"].to(dev) for i in synth.CONV_IDX]
+    packed = [ws[0]] + [ops.pack_conv3x3(w, "bf16x3") for w in ws[1:]]
+    a = ops.vgg16_conv5(x, packed, bs, "bf16x3")
+    ops.set_stem_fused(False)
+    try:
+        b = ops.vgg16_conv5(x, packed, bs, "bf16x3")
+    finally:
+        ops.set_stem_fused(True)
+    assert a.dtype == torch.float32
+    assert_rel_l2("backbone bf16x3, fused vs unfused stem", a.cpu(), b.cpu(), 1e-5)
