@@ -1046,6 +1046,7 @@ constexpr int ST_LDS_BYTES_U8 = ST_LDS_BYTES + 1552;
 constexpr int ST_BLOCKS = (ST_HALO_PX + 31) / 32;    // 11 blocks of 32 halo pixels
 constexpr unsigned ST_OOB = 0xF0000000u;
 static int g_stem_fused = 1;
+static int g_stem3_prio = 2;  // test hook: producer issue priority of the bf16x3 stem (0..3)
 
 struct StemParams {
   const void* x;     // U8 = false: [N][3][H][W] fp32 (normalised); U8 = true: [N][H][W][3] uint8
@@ -1059,6 +1060,7 @@ struct StemParams {
   int N, H, W;
   int tiles_x, tiles_y, ntiles;
   unsigned long long* prof;  // optional (test hook): shader-clock totals of block 0, waves 0 and 4
+  int prod_prio;             // bf16x3 stem: issue priority of the producer role outside its MFMAs
 };
 
 // U8 = true: the input is the loader's raw uint8 NHWC image; ToTensor + Normalize
@@ -1484,8 +1486,15 @@ static int launch_vgg_stem(const void* x, int N, int H, int W, const float* mean
 // bf16x3 convolution in K order (channel chunk, tap) — bit-identical to that pair (tested).
 // LDS: 72 KiB + 2 x 42.5 KiB = 157 KiB.
 // ---------------------------------------------------------------------------------------------
+// two fp32 values -> the dword of their hi parts and the dword of their lo parts (packed bf16 pairs)
+__device__ static inline void x3_split_pair(float v0, float v1, uint32_t& hi, uint32_t& lo) {
+  hi = pack_bf16x2(v0, v1);
+  lo = pack_bf16x2(v0 - __builtin_bit_cast(float, hi << 16), v1 - __builtin_bit_cast(float, hi & 0xffff0000u));
+}
+
 constexpr int S3_W_BYTES = 2 * 9 * 32 * 128;
-constexpr int S3_LDS_BYTES = S3_W_BYTES + 2 * ST_HALO_BYTES;
+constexpr int S3_BIAS_OFF = S3_W_BYTES + 2 * ST_HALO_BYTES;   // conv1_1 bias: 64 floats
+constexpr int S3_LDS_BYTES = S3_BIAS_OFF + 256;
 
 __global__ __launch_bounds__(512) void vgg_stem_x3_kernel(StemParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1500,9 +1509,18 @@ __global__ __launch_bounds__(512) void vgg_stem_x3_kernel(StemParams p) {
   if (first < p.ntiles) niter = (p.ntiles - first + stride - 1) / stride;
   const int nstages = 2 * niter;
   const int Ho = p.H >> 1, Wo = p.W >> 1;
+  // conv1_1's bias lives in LDS (the producers have no registers to spare for 2 x 16 values per lane)
+  if (threadIdx.x < 64) reinterpret_cast<float*>(smem + S3_BIAS_OFF)[threadIdx.x] = p.b1[threadIdx.x];
+  __syncthreads();
 
   if (wave >= 4) {
     // ================================ producers ================================================
+    // The producers are the longer role here (VALU-heavy: two splits per value, and every VALU slot
+    // competes with the consumer wave's MFMA stream on the same SIMD): they run at a raised issue
+    // priority throughout, not only around their MFMAs as in the bf16 stem (2.69 -> 2.28 ms).
+    if (p.prod_prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p.prod_prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p.prod_prio == 3) __builtin_amdgcn_s_setprio(3);
     const int pw = wave - 4;
     const __amdgpu_buffer_rsrc_t rs_x =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
@@ -1522,35 +1540,40 @@ __global__ __launch_bounds__(512) void vgg_stem_x3_kernel(StemParams p) {
           wlo[h][s][e] = (short)lo;
         }
       }
-    float bb[2][16];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) bb[h][r] = p.b1[32 * h + acc_row(r, lane)];
+    // accumulator rows of this lane: channels 8 j + 4 half + 0..3 (j = 0..3) of the pass's 32
+    const float* const bias_l = reinterpret_cast<const float*>(smem + S3_BIAS_OFF) + 4 * half;
     const int plane = p.H * p.W;
 
     // tile-independent lane geometry (as in vgg_stem_kernel)
-    int g_row[3], g_swz[3], g_hy[3], g_hx[3], g_rel[3];
+    // halo pixel of this lane in block bi: r = 32 (pw + 4 bi) + l31 (clamped to the last pixel for the
+    // 12 surplus lanes of block 10), (hy, hx) = (r / 34, r % 34); kept per block: the swizzle of its
+    // LDS row and its element offset from the tile's halo origin (the rest is recomputed where needed)
+    auto row_of = [&](int bi) __attribute__((always_inline)) { return 32 * (pw + 4 * bi) + l31; };
+    auto hyx_of = [&](int bi, int& hy, int& hx) __attribute__((always_inline)) {
+      const int r = row_of(bi), rc = r < ST_HALO_PX ? r : ST_HALO_PX - 1;
+      hy = rc / C64_HW;
+      hx = rc - hy * C64_HW;
+    };
+    int g_swz[3], g_rel[3];
 #pragma unroll
     for (int bi = 0; bi < 3; ++bi) {
-      const int r = 32 * (pw + 4 * bi) + l31;
-      const int rc = r < ST_HALO_PX ? r : ST_HALO_PX - 1;
-      g_row[bi] = r;
-      g_hy[bi] = rc / C64_HW;
-      g_hx[bi] = rc - g_hy[bi] * C64_HW;
-      g_swz[bi] = c64_swz(g_hy[bi], g_hx[bi]);
-      g_rel[bi] = g_hy[bi] * p.W + g_hx[bi];
+      int hy, hx;
+      hyx_of(bi, hy, hx);
+      g_swz[bi] = c64_swz(hy, hx);
+      g_rel[bi] = hy * p.W + hx;
       asm volatile("" : "+v"(g_rel[bi]));
     }
-    int g_dk[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      int k = 16 * (j >> 3) + 8 * half + (j & 7);
-      if (k >= 27) k -= 8;
-      const int c = k / 9, t = k - 9 * c;
-      g_dk[j] = c * plane + (t / 3 - 1) * p.W + (t % 3 - 1);
-      asm volatile("" : "+v"(g_dk[j]));
-    }
+    // element offset of input element k(j) from the pixel, j = 8 s + e, k = 16 s + 8 half + e (slots
+    // with k >= 27 carry zero weights and re-read a valid tap): wave-uniform per lane half, so the two
+    // candidates stay in scalar registers and a lane selects (no 16 VGPRs per lane)
+    auto dk_of = [&](int j) __attribute__((always_inline)) {
+      const int kA = 16 * (j >> 3) + (j & 7), kB = kA + 8 >= 27 ? kA : kA + 8;
+      const int oA = (kA / 9) * plane + ((kA % 9) / 3 - 1) * p.W + ((kA % 9) % 3 - 1);
+      const int oB = (kB / 9) * plane + ((kB % 9) / 3 - 1) * p.W + ((kB % 9) % 3 - 1);
+      int hsel = half;
+      asm volatile("" : "+v"(hsel));   // not loop-invariant for the compiler: no 16 hoisted VGPRs
+      return hsel ? oB : oA;
+    };
     auto tap_of = [&](int j) __attribute__((always_inline)) {  // border tiles only
       const int kA = 16 * (j >> 3) + (j & 7), kB = kA + 8 >= 27 ? kA : kA + 8;
       return half ? kB % 9 : kA % 9;
@@ -1578,13 +1601,15 @@ __global__ __launch_bounds__(512) void vgg_stem_x3_kernel(StemParams p) {
 #pragma unroll
           for (int j = 0; j < 16; ++j)
             xv[bi][j] = __builtin_bit_cast(
-                float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (base + g_dk[j]) * 4, 0, 0));
+                float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (base + dk_of(j)) * 4, 0, 0));
         }
       } else {
 #pragma unroll
         for (int bi = 0; bi < 3; ++bi) {
           if (pw + 4 * bi >= ST_BLOCKS) continue;
-          const int y = y0 + g_hy[bi], x = x0 + g_hx[bi];
+          int hy, hx;
+          hyx_of(bi, hy, hx);
+          const int y = y0 + hy, x = x0 + hx;
           unsigned mk = 0;
           if (y >= 0 && y < p.H && x >= 0 && x < p.W) {
             const bool ya = y > 0, yc = y + 1 < p.H, xa = x > 0, xc = x + 1 < p.W;
@@ -1595,7 +1620,7 @@ __global__ __launch_bounds__(512) void vgg_stem_x3_kernel(StemParams p) {
 #pragma unroll
           for (int j = 0; j < 16; ++j) {
             const bool ok = (mk >> tap_of(j)) & 1u;
-            const unsigned off = ok ? (unsigned)(base + g_dk[j]) * 4u : ST_OOB;
+            const unsigned off = ok ? (unsigned)(base + dk_of(j)) * 4u : ST_OOB;
             xv[bi][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)off, 0, 0));
           }
         }
@@ -1604,22 +1629,28 @@ __global__ __launch_bounds__(512) void vgg_stem_x3_kernel(StemParams p) {
     // the gathered window as (hi, lo) B fragments, kept for both passes of the tile
     bf16x8_t xh[3][2], xl[3][2];
     auto convert = [&]() __attribute__((always_inline)) {
+      typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 #pragma unroll
       for (int bi = 0; bi < 3; ++bi) {
         if (pw + 4 * bi >= ST_BLOCKS) continue;
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 2; ++s) {
+          u32x4_t hi4, lo4;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            uint16_t hi, lo;
-            x3_split(xv[bi][8 * s + e], hi, lo);
-            xh[bi][s][e] = (short)hi;
-            xl[bi][s][e] = (short)lo;
+          for (int e2 = 0; e2 < 4; ++e2) {
+            uint32_t hi, lo;
+            x3_split_pair(xv[bi][8 * s + 2 * e2], xv[bi][8 * s + 2 * e2 + 1], hi, lo);
+            hi4[e2] = hi;
+            lo4[e2] = lo;
           }
+          xh[bi][s] = __builtin_bit_cast(bf16x8_t, hi4);
+          xl[bi][s] = __builtin_bit_cast(bf16x8_t, lo4);
+        }
       }
     };
     // conv1_1 of channel half h on the converted window, bias + ReLU + split, halo tile -> LDS
-    auto produce = [&](int tile, int h, char* buf) __attribute__((always_inline)) {
+    auto produce = [&](int tile, auto h_c, char* buf) __attribute__((always_inline)) {
+      constexpr int h = decltype(h_c)::value;
       int n, ty, tx;
       decode(tile, n, ty, tx);
       const int y0 = ty * 8 - 1, x0 = tx * 32 - 1;
@@ -1628,22 +1659,35 @@ __global__ __launch_bounds__(512) void vgg_stem_x3_kernel(StemParams p) {
       for (int bi = 0; bi < 3; ++bi) {
         if (pw + 4 * bi >= ST_BLOCKS) continue;  // wave-uniform
         f32x16_t acc;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 b = *reinterpret_cast<const float4*>(bias_l + 32 * h + 8 * j);
+          acc[4 * j] = b.x;
+          acc[4 * j + 1] = b.y;
+          acc[4 * j + 2] = b.z;
+          acc[4 * j + 3] = b.w;
+        }
         __builtin_amdgcn_s_setprio(3);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = h ? bb[1][r] : bb[0][r];
-#pragma unroll
         for (int s = 0; s < 2; ++s) {   // the order of conv1_1_mfma_kernel<X3>
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h ? wlo[1][s] : wlo[0][s], xh[bi][s], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h ? wh[1][s] : wh[0][s], xl[bi][s], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h ? wh[1][s] : wh[0][s], xh[bi][s], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[h][s], xh[bi][s], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[h][s], xl[bi][s], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[h][s], xh[bi][s], acc, 0, 0, 0);
         }
-        __builtin_amdgcn_s_setprio(0);
+        if (p.prod_prio == 0) __builtin_amdgcn_s_setprio(0);
+        else if (p.prod_prio == 1) __builtin_amdgcn_s_setprio(1);
+        else if (p.prod_prio == 2) __builtin_amdgcn_s_setprio(2);
         // D[row = channel][col = pixel]: registers 4g..4g+3 = channels 8 g + 4 half + 0..3 of the
         // lane's pixel -> hi: 8 bytes of 16-B slot g, lo: of slot 4 + g (both swizzled), + 8 half.
-        const int y = y0 + g_hy[bi], x = x0 + g_hx[bi];
-        const bool pix_ok = interior || (y >= 0 && y < p.H && x >= 0 && x < p.W);
-        if (g_row[bi] < ST_HALO_PX) {
-          char* row = buf + g_row[bi] * 128 + 8 * half;
+        bool pix_ok = true;
+        if (!interior) {   // border tiles only: is this halo pixel inside the image?
+          int hy, hx;
+          hyx_of(bi, hy, hx);
+          const int y = y0 + hy, x = x0 + hx;
+          pix_ok = y >= 0 && y < p.H && x >= 0 && x < p.W;
+        }
+        if (row_of(bi) < ST_HALO_PX) {
+          char* row = buf + row_of(bi) * 128 + 8 * half;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             uint2 hi, lo;
@@ -1662,26 +1706,47 @@ __global__ __launch_bounds__(512) void vgg_stem_x3_kernel(StemParams p) {
 
     // stage s = (tile s >> 1, channel half s & 1) goes to halo buffer s & 1; the producers run one
     // stage ahead of the consumers, the gathers one tile ahead of that
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+    const bool prof = p.prof != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && wave == 4;
+    unsigned long long pt[2] = {0, 0};
+    auto hand_over = [&](unsigned long long t0) __attribute__((always_inline)) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const unsigned long long t1 = prof ? __builtin_amdgcn_s_memtime() : 0;
+      __builtin_amdgcn_s_barrier();
+      if (prof) {
+        const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+        pt[0] += t1 - t0;
+        pt[1] += t2 - t1;
+      }
+    };
     if (niter > 0) {
       issue_loads(first);
       convert();
       if (niter > 1) issue_loads(first + stride);
-      produce(first, 0, hb);
+      produce(first, H0{}, hb);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    for (int s = 0; s < nstages; ++s) {
-      const int nx = s + 1;
-      if (nx < nstages) {
-        const int it = nx >> 1;
-        if ((nx & 1) == 0) {   // a new tile: its window has arrived
-          convert();
-          if (it + 1 < niter) issue_loads(first + (it + 1) * stride);
-        }
-        produce(first + it * stride, nx & 1, hb + (nx & 1) * ST_HALO_BYTES);
+    for (int it = 0; it < niter; ++it) {
+      // while the consumers run pass 0 of tile it: its second channel half; then — its fragments
+      // are no longer needed — the window of tile it+1 (it has had a whole tile to arrive) is
+      // converted and the gathers of tile it+2 go out
+      unsigned long long t0 = prof ? __builtin_amdgcn_s_memtime() : 0;
+      produce(first + it * stride, H1{}, hb + ST_HALO_BYTES);
+      if (it + 1 < niter) {
+        convert();
+        if (it + 2 < niter) issue_loads(first + (it + 2) * stride);
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      hand_over(t0);
+      // while they run pass 1: the first channel half of the next tile
+      t0 = prof ? __builtin_amdgcn_s_memtime() : 0;
+      if (it + 1 < niter) produce(first + (it + 1) * stride, H0{}, hb);
+      hand_over(t0);
+    }
+    if (prof && lane == 0) {
+      p.prof[4] = pt[0];
+      p.prof[5] = pt[1];
     }
     return;
   }
@@ -1725,8 +1790,11 @@ __global__ __launch_bounds__(512) void vgg_stem_x3_kernel(StemParams p) {
   };
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  const bool cprof = p.prof != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0;
+  unsigned long long ct[3] = {0, 0, 0};
   f32x16_t acc[2];
   for (int s = 0; s < nstages; ++s) {
+    const unsigned long long c0 = cprof ? __builtin_amdgcn_s_memtime() : 0;
     const int h = s & 1;
     const int tile = first + (s >> 1) * stride;
     const char* const cur = hb + h * ST_HALO_BYTES;
@@ -1770,7 +1838,12 @@ __global__ __launch_bounds__(512) void vgg_stem_x3_kernel(StemParams p) {
     }
     // every fragment read of `cur` has been consumed by the MFMAs above: hand the buffer back
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long c1 = cprof ? __builtin_amdgcn_s_memtime() : 0;
     __builtin_amdgcn_s_barrier();
+    if (cprof) {
+      ct[0] += c1 - c0;
+      ct[1] += __builtin_amdgcn_s_memtime() - c1;
+    }
     if (h == 1) {
       const unsigned r2 = (unsigned)tile / (unsigned)p.tiles_x;
       const int tx = tile - (int)r2 * p.tiles_x;
@@ -1795,6 +1868,11 @@ __global__ __launch_bounds__(512) void vgg_stem_x3_kernel(StemParams p) {
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) store_px(e);
+  if (cprof && lane == 0) {
+    p.prof[0] = ct[0];
+    p.prof[1] = ct[1];
+    p.prof[2] = 0;
+  }
 }
 
 static int launch_vgg_stem_x3(const float* x, int N, int H, int W, const float* w1, const float* b1,
@@ -1815,7 +1893,8 @@ static int launch_vgg_stem_x3(const float* x, int N, int H, int W, const float* 
   const long nt = (long)N * p.tiles_x * p.tiles_y;
   OIBL_REQUIRE(nt < 0x7fffffffL, "vgg stem: too many tiles");
   p.ntiles = (int)nt;
-  p.prof = nullptr;
+  p.prof = g_prof_buf;
+  p.prod_prio = g_stem3_prio;
   int gx = 128;  // two workgroups (output-channel halves) per tile range: one persistent workgroup per CU
   if (gx > p.ntiles) gx = p.ntiles;
   auto kern = vgg_stem_x3_kernel;
@@ -2024,6 +2103,11 @@ int oibl_debug_set_conv_ablate(int mode) {
 
 int oibl_debug_set_ring_ablate(int mode) {
   g_ring_ablate = mode;
+  return OIBL_OK;
+}
+
+int oibl_debug_set_stem3_prio(int prio) {
+  g_stem3_prio = prio < 0 ? 0 : (prio > 3 ? 3 : prio);
   return OIBL_OK;
 }
 

@@ -104,6 +104,7 @@ _HOOKS = {"oibl_debug_set_regstage": (c_int, [c_int]),
           "oibl_debug_set_ring_raster": (c_int, [c_int]),
           "oibl_debug_set_conv_korder": (c_int, [c_int]),
           "oibl_debug_set_conv_splitk": (c_int, [c_int]),
+          "oibl_debug_set_stem3_prio": (c_int, [c_int]),
           "oibl_debug_set_match_group": (c_int, [c_int]),
           "oibl_debug_set_match_splitk": (c_int, [c_int]),
           "oibl_debug_set_prof_buffer": (c_int, [c_void_p])}

@@ -1,0 +1,40 @@
+"""Role breakdown (shader clocks) of the fused bf16x3 stem kernel, block (0, 0) (diagnostic)."""
+import sys
+from pathlib import Path
+import torch
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from openibl_amd import ops, lib
+
+dev = torch.device("cuda", 0)
+L = lib.load()
+buf = torch.zeros(8, dtype=torch.int64, device=dev)
+N, H, W = 32, 480, 640
+x = torch.randn((N, 3, H, W), device=dev) * 50
+w1 = torch.randn((64, 3, 3, 3), device=dev) * 0.2
+b1 = torch.zeros(64, device=dev)
+w2 = ops.pack_conv3x3(torch.randn((64, 64, 3, 3), device=dev) * 0.05, "bf16x3")
+b2 = torch.zeros(64, device=dev)
+for prio in (0, 1, 2, 3):
+    L.oibl_debug_set_stem3_prio(prio)
+    for _ in range(2):
+        ops.vgg16_stem_x3(x, w1, b1, w2, b2)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(5):
+        ops.vgg16_stem_x3(x, w1, b1, w2, b2)
+    e.record()
+    torch.cuda.synchronize()
+    print(f"stem x3 {N}x{H}x{W}, producer priority {prio}: {s.elapsed_time(e) / 5:.3f} ms")
+L.oibl_debug_set_stem3_prio(int(sys.argv[1]) if len(sys.argv) > 1 else 2)
+L.oibl_debug_set_prof_buffer(buf.data_ptr())
+ops.vgg16_stem_x3(x, w1, b1, w2, b2)
+torch.cuda.synchronize()
+L.oibl_debug_set_prof_buffer(None)
+t = buf.cpu().tolist()
+tiles = N * ((H + 7) // 8) * ((W + 31) // 32) / 128
+print(f"{tiles:.0f} tiles per workgroup (two passes each); ticks are s_memtime counts (100 MHz)")
+for n, v in zip(["consumer: mfma loops", "consumer: barrier wait", "-", "-",
+                 "producer: produce", "producer: barrier wait"], t):
+    if n != "-":
+        print(f"   {n:24s} {v / tiles:9.1f} ticks/tile")
