@@ -1046,7 +1046,7 @@ constexpr int ST_LDS_BYTES_U8 = ST_LDS_BYTES + 1552;
 constexpr int ST_BLOCKS = (ST_HALO_PX + 31) / 32;    // 11 blocks of 32 halo pixels
 constexpr unsigned ST_OOB = 0xF0000000u;
 static int g_stem_fused = 1;
-static int g_stem3_prio = 2;  // test hook: producer issue priority of the bf16x3 stem (0..3)
+static int g_stem3_prio = 3;  // producer issue priority of the bf16x3 stem (0..3; test hook — 3 measured best)
 
 struct StemParams {
   const void* x;     // U8 = false: [N][3][H][W] fp32 (normalised); U8 = true: [N][H][W][3] uint8
@@ -1476,9 +1476,10 @@ static int launch_vgg_stem(const void* x, int N, int H, int W, const float* mean
 //     channel halves x 32 cout x 128 B = 72 KiB of split weights stay resident in LDS;
 //   * a tile is consumed in two PASSES, one per half of conv1_2's input channels: a halo buffer holds
 //     340 pixels x [32 hi | 32 lo] of ONE 32-channel half (42.5 KiB, exactly the bf16 stem's buffer)
-//     and the two buffers alternate between the passes.  Producers (waves 4-7) run conv1_1 for the
+//     and the two buffers alternate between the passes.  Producers (waves 4-15) run conv1_1 for the
 //     32 channels of the next pass (K = 27 padded to 32: lo.hi + hi.lo + hi.hi, 6 MFMAs per 32 halo
-//     pixels), ReLU, split, and write the halo image the consumers read; the gathered input window
+//     pixels; twelve waves, one 32-pixel block of the halo each), ReLU, split, and write the halo
+//     image the consumers read; the gathered input window
 //     and its (hi, lo) fragments are kept in registers for both passes of a tile.  Consumers (waves
 //     0-3) accumulate both passes in registers (9 taps x 12 MFMAs per pass), then pool and store.
 // Only 4 waves read LDS for the main contraction (the generic kernel has 16 competing for it).
@@ -1496,7 +1497,7 @@ constexpr int S3_W_BYTES = 2 * 9 * 32 * 128;
 constexpr int S3_BIAS_OFF = S3_W_BYTES + 2 * ST_HALO_BYTES;   // conv1_1 bias: 64 floats
 constexpr int S3_LDS_BYTES = S3_BIAS_OFF + 256;
 
-__global__ __launch_bounds__(512) void vgg_stem_x3_kernel(StemParams p) {
+__global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const wl = smem;                 // [pass h][tap][32 cout][32 hi | 32 lo of input channels 32h..]
   char* const hb = smem + S3_W_BYTES;    // halo buffer h: channels 32h..32h+31 of the current tile
@@ -1514,14 +1515,18 @@ __global__ __launch_bounds__(512) void vgg_stem_x3_kernel(StemParams p) {
   __syncthreads();
 
   if (wave >= 4) {
-    // ================================ producers ================================================
-    // The producers are the longer role here (VALU-heavy: two splits per value, and every VALU slot
-    // competes with the consumer wave's MFMA stream on the same SIMD): they run at a raised issue
-    // priority throughout, not only around their MFMAs as in the bf16 stem (2.69 -> 2.28 ms).
+    // ================================ producers (waves 4-15) ====================================
+    // Twelve producer waves (three per SIMD, one 32-pixel block each) against four consumers: with one
+    // producer wave per SIMD handling three blocks, the VALU-heavy role (two splits per value, ~1400
+    // dependent VALU instructions per tile at ~8 cycles each) was 1.7x the consumers' time; three
+    // waves per SIMD hide each other's instruction latency.  The kernel therefore runs 16 waves per
+    // workgroup at <= 128 VGPRs.  prod_prio (test hook) raises the role's issue priority outside
+    // its MFMAs.
     if (p.prod_prio == 1) __builtin_amdgcn_s_setprio(1);
     else if (p.prod_prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (p.prod_prio == 3) __builtin_amdgcn_s_setprio(3);
-    const int pw = wave - 4;
+    const int pw = wave - 4;   // 0..11: producer wave pw owns block pw of the 11 (wave 15 only keeps step)
+    const bool has_block = pw < ST_BLOCKS;
     const __amdgpu_buffer_rsrc_t rs_x =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.x_bytes, 0x00020000);
     // conv1_1 weights (A operand), split: w?[h][s] element e <-> channel 32 h + l31, k = 16 s + 8 half + e
@@ -1548,15 +1553,15 @@ __global__ __launch_bounds__(512) void vgg_stem_x3_kernel(StemParams p) {
     // halo pixel of this lane in block bi: r = 32 (pw + 4 bi) + l31 (clamped to the last pixel for the
     // 12 surplus lanes of block 10), (hy, hx) = (r / 34, r % 34); kept per block: the swizzle of its
     // LDS row and its element offset from the tile's halo origin (the rest is recomputed where needed)
-    auto row_of = [&](int bi) __attribute__((always_inline)) { return 32 * (pw + 4 * bi) + l31; };
+    auto row_of = [&](int bi) __attribute__((always_inline)) { return 32 * (pw + bi) + l31; };
     auto hyx_of = [&](int bi, int& hy, int& hx) __attribute__((always_inline)) {
       const int r = row_of(bi), rc = r < ST_HALO_PX ? r : ST_HALO_PX - 1;
       hy = rc / C64_HW;
       hx = rc - hy * C64_HW;
     };
-    int g_swz[3], g_rel[3];
+    int g_swz[1], g_rel[1];
 #pragma unroll
-    for (int bi = 0; bi < 3; ++bi) {
+    for (int bi = 0; bi < 1; ++bi) {
       int hy, hx;
       hyx_of(bi, hy, hx);
       g_swz[bi] = c64_swz(hy, hx);
@@ -1587,7 +1592,7 @@ __global__ __launch_bounds__(512) void vgg_stem_x3_kernel(StemParams p) {
     auto is_interior = [&](int ty, int tx) __attribute__((always_inline)) {
       return ty >= 1 && ty * 8 + 10 <= p.H && tx >= 1 && tx * 32 + 34 <= p.W;
     };
-    float xv[3][16];
+    float xv[1][16];
     auto issue_loads = [&](int tile) __attribute__((always_inline)) {
       int n, ty, tx;
       decode(tile, n, ty, tx);
@@ -1595,8 +1600,8 @@ __global__ __launch_bounds__(512) void vgg_stem_x3_kernel(StemParams p) {
       const int origin = ((n * 3) * p.H + y0) * p.W + x0;
       if (is_interior(ty, tx)) {
 #pragma unroll
-        for (int bi = 0; bi < 3; ++bi) {
-          if (pw + 4 * bi >= ST_BLOCKS) continue;  // wave-uniform
+        for (int bi = 0; bi < 1; ++bi) {
+          if (!has_block) continue;  // wave-uniform
           const int base = origin + g_rel[bi];
 #pragma unroll
           for (int j = 0; j < 16; ++j)
@@ -1605,8 +1610,8 @@ __global__ __launch_bounds__(512) void vgg_stem_x3_kernel(StemParams p) {
         }
       } else {
 #pragma unroll
-        for (int bi = 0; bi < 3; ++bi) {
-          if (pw + 4 * bi >= ST_BLOCKS) continue;
+        for (int bi = 0; bi < 1; ++bi) {
+          if (!has_block) continue;
           int hy, hx;
           hyx_of(bi, hy, hx);
           const int y = y0 + hy, x = x0 + hx;
@@ -1627,12 +1632,12 @@ __global__ __launch_bounds__(512) void vgg_stem_x3_kernel(StemParams p) {
       }
     };
     // the gathered window as (hi, lo) B fragments, kept for both passes of the tile
-    bf16x8_t xh[3][2], xl[3][2];
+    bf16x8_t xh[1][2], xl[1][2];
     auto convert = [&]() __attribute__((always_inline)) {
       typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 #pragma unroll
-      for (int bi = 0; bi < 3; ++bi) {
-        if (pw + 4 * bi >= ST_BLOCKS) continue;
+      for (int bi = 0; bi < 1; ++bi) {
+        if (!has_block) continue;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           u32x4_t hi4, lo4;
@@ -1656,8 +1661,8 @@ __global__ __launch_bounds__(512) void vgg_stem_x3_kernel(StemParams p) {
       const int y0 = ty * 8 - 1, x0 = tx * 32 - 1;
       const bool interior = is_interior(ty, tx);
 #pragma unroll
-      for (int bi = 0; bi < 3; ++bi) {
-        if (pw + 4 * bi >= ST_BLOCKS) continue;  // wave-uniform
+      for (int bi = 0; bi < 1; ++bi) {
+        if (!has_block) continue;  // wave-uniform
         f32x16_t acc;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1763,11 +1768,22 @@ __global__ __launch_bounds__(512) void vgg_stem_x3_kernel(StemParams p) {
       glds16(p.w2 + ((long)(tap * 64 + co0 + c) * 256 + h * 128) + piece, wl + q * 1024);
     }
   }
-  int lhy[2], lhx[2];
+  // A-fragment addressing.  Block i's pixel of this lane is (ly, lx) of the 8 x 32 tile; tap (ky, kx)
+  // reads halo pixel (ly + ky, lx + kx): its row is a compile-time distance (ky * 34 + kx) * 128 from
+  // the lane's own, and its 16-B slot (2 pr + half) ^ swz(hy, hx) differs from the tap-(0,0) slot only
+  // by   (lx + kx) >> 1 = (lx >> 1) + {0, lx & 1, 1}[kx]   and the constant bits pr << 1, (ky & 1) << 2.
+  // Three per-lane slot offsets per block (kx = 0, 1, 2) and one v_xad_u32 per read replace ~12 VALU
+  // instructions per read (hoisted, the 18 x 2 x 2 addresses would cost ~70 of this kernel's 128 VGPRs).
+  int e_kx[2][3], pxb[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    lhy[i] = 2 * wave + ((l31 >> 1) & 1);
-    lhx[i] = 16 * i + 2 * (l31 >> 2) + (l31 & 1);
+    const int ly = 2 * wave + ((l31 >> 1) & 1);
+    const int lx = 16 * i + 2 * (l31 >> 2) + (l31 & 1);
+    const int fix = half ^ ((ly & 1) << 2);
+    e_kx[i][0] = (fix ^ ((lx >> 1) & 7)) << 4;
+    e_kx[i][2] = (fix ^ (((lx >> 1) + 1) & 7)) << 4;
+    e_kx[i][1] = (lx & 1) ? e_kx[i][2] : e_kx[i][0];
+    pxb[i] = (ly * C64_HW + lx) * 128;
   }
   int w_off[4];
 #pragma unroll
@@ -1797,7 +1813,9 @@ __global__ __launch_bounds__(512) void vgg_stem_x3_kernel(StemParams p) {
     const unsigned long long c0 = cprof ? __builtin_amdgcn_s_memtime() : 0;
     const int h = s & 1;
     const int tile = first + (s >> 1) * stride;
-    const char* const cur = hb + h * ST_HALO_BYTES;
+    int pc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) pc[i] = pxb[i] + h * ST_HALO_BYTES;
     const char* const wbase = wl + h * (9 * 32 * 128);
     if (h == 0) {
 #pragma unroll
@@ -1813,11 +1831,13 @@ __global__ __launch_bounds__(512) void vgg_stem_x3_kernel(StemParams p) {
       const int ky = tap / 3, kx = tap - 3 * ky;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int hy = lhy[i] + ky, hx = lhx[i] + kx;
-        const char* px = cur + (hy * C64_HW + hx) * 128;
-        const int sw = c64_swz(hy, hx);
-        ah[i] = *reinterpret_cast<const bf16x8_t*>(px + (((2 * pr + half) ^ sw) << 4));
-        al[i] = *reinterpret_cast<const bf16x8_t*>(px + (((2 * (pr + 2) + half) ^ sw) << 4));
+        const int c = (pr << 5) ^ ((ky & 1) << 6);   // hi chunk; the lo chunk sits 4 slots on
+        int a_hi, a_lo;
+        asm("v_xad_u32 %0, %1, %2, %3" : "=v"(a_hi) : "v"(e_kx[i][kx]), "s"(c), "v"(pc[i]));
+        asm("v_xad_u32 %0, %1, %2, %3" : "=v"(a_lo) : "v"(e_kx[i][kx]), "s"(c ^ 64), "v"(pc[i]));
+        const char* px = hb + (ky * C64_HW + kx) * 128;
+        ah[i] = *reinterpret_cast<const bf16x8_t*>(px + a_hi);
+        al[i] = *reinterpret_cast<const bf16x8_t*>(px + a_lo);
       }
       bh = *reinterpret_cast<const bf16x8_t*>(wbase + tap * 4096 + w_off[pr]);
       bl = *reinterpret_cast<const bf16x8_t*>(wbase + tap * 4096 + w_off[pr + 2]);
@@ -1827,7 +1847,8 @@ __global__ __launch_bounds__(512) void vgg_stem_x3_kernel(StemParams p) {
     for (int sidx = 0; sidx < 18; ++sidx) {
       const int b = sidx & 1;
       if (sidx + 1 < 18) load_step(sidx + 1, fah[b ^ 1], fal[b ^ 1], fbh[b ^ 1], fbl[b ^ 1]);
-      __builtin_amdgcn_sched_barrier(0);  // keep the next step's reads AHEAD of this step's MFMAs
+      // (no sched_barrier here: with one the allocator spills 3 KB per lane at this kernel's 128 VGPRs;
+      //  the reads of step sidx+1 are independent of this step's MFMAs and the scheduler hoists them)
 #pragma unroll
       for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[b][i], fbh[b], acc[i], 0, 0, 0);
 #pragma unroll
@@ -1899,7 +1920,7 @@ static int launch_vgg_stem_x3(const float* x, int N, int H, int W, const float* 
   if (gx > p.ntiles) gx = p.ntiles;
   auto kern = vgg_stem_x3_kernel;
   OIBL_SET_MAX_LDS(kern, S3_LDS_BYTES);
-  hipLaunchKernelGGL(kern, dim3(gx, 2), dim3(512), S3_LDS_BYTES, st, p);
+  hipLaunchKernelGGL(kern, dim3(gx, 2), dim3(1024), S3_LDS_BYTES, st, p);
   OIBL_LAUNCH_CHECK();
   return OIBL_OK;
 }

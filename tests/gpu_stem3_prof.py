@@ -26,7 +26,7 @@ for prio in (0, 1, 2, 3):
     e.record()
     torch.cuda.synchronize()
     print(f"stem x3 {N}x{H}x{W}, producer priority {prio}: {s.elapsed_time(e) / 5:.3f} ms")
-L.oibl_debug_set_stem3_prio(int(sys.argv[1]) if len(sys.argv) > 1 else 2)
+L.oibl_debug_set_stem3_prio(int(sys.argv[1]) if len(sys.argv) > 1 else 3)
 L.oibl_debug_set_prof_buffer(buf.data_ptr())
 ops.vgg16_stem_x3(x, w1, b1, w2, b2)
 torch.cuda.synchronize()
