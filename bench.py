@@ -18,9 +18,9 @@ matrix work, descriptors at ~3e-3 — is measured in the same run and reported u
 labelled as what it is.
 
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
-  roofline      the matrix-core convolution kernels (13 launches per step in bf16x3: conv1_1 and the
-                12 implicit-GEMM launches; 12 in bf16 where conv1_1 + conv1_2 + pool are one fused
-                launch): ALGORITHMIC FLOPs of those launches / their measured span, bracketed with
+  roofline      the matrix-core convolution kernels (12 launches per step: the fused stem — conv1_1 +
+                conv1_2 + pool in one launch — and the 11 ring launches conv2_1..conv5_3, in bf16x3
+                and in bf16 alike): ALGORITHMIC FLOPs of those launches / their measured span, bracketed with
                 HIP events recorded on the launching stream, against the dense bf16 MFMA peak
                 (2.5 PFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md).  In bf16x3 the kernels issue
                 three MFMAs per algorithmic product: `issued_frac` = 3 x `frac` is the share of the
@@ -144,20 +144,20 @@ def time_extraction(c, model, x, precision, steps, warmup, eager=False, pipeline
     span_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
     # launches inside the span and their algorithmic FLOPs (2 flop per MAC of the convolution; the
     # hi/lo split of bf16x3 is an implementation detail of the arithmetic, not more algorithm)
-    if precision == "bf16":
+    if precision in ("bf16", "bf16x3"):
+        # conv1_1 + conv1_2 + pool are ONE launch (the fused stem) and the span starts with it
         launches, fl = 12, (igemm_flops_per_image() + conv11_flops_per_image()) * batch
         kernel = ("oibl::vgg_stem_kernel (conv1_1+conv1_2+pool) + oibl::conv3x3_ring_kernel "
+                  "(conv2_1..conv5_3), 12 launches/step" if precision == "bf16" else
+                  "oibl::vgg_stem_x3_kernel (conv1_1+conv1_2+pool) + oibl::conv3x3_ring_kernel<..., X3> "
                   "(conv2_1..conv5_3), 12 launches/step")
     elif fwd is not None:
-        # the replayed backbone graph holds conv1_1 too: 13 launches inside the span
+        # fp32: the replayed backbone graph holds conv1_1 too: 13 launches inside the span
         launches, fl = 13, (igemm_flops_per_image() + conv11_flops_per_image()) * batch
-        kernel = ("oibl::conv1_1_mfma_kernel<X3> + oibl::conv3x3_igemm_kernel<bf16x3> (conv1_2) + "
-                  "oibl::conv3x3_ring_kernel<..., X3> (conv2_1..conv5_3), 13 launches/step"
-                  if precision == "bf16x3" else
-                  "oibl::conv1_1_kernel + oibl::conv3x3_igemm_kernel (conv1_2..conv5_3), 13 launches/step")
+        kernel = "oibl::conv1_1_kernel + oibl::conv3x3_igemm_kernel (conv1_2..conv5_3), 13 launches/step"
     else:
         launches, fl = 12, igemm_flops_per_image() * batch
-        kernel = ("oibl::conv3x3_igemm_kernel / conv3x3_ring_kernel (conv1_2..conv5_3), 12 launches/step; "
+        kernel = ("oibl::conv3x3_igemm_kernel (conv1_2..conv5_3), 12 launches/step; "
                   "conv1_1 runs before the span")
     achieved = fl / (span_ms * 1e-3) / 1e12
     peak = F32_MFMA_PEAK_TFLOPS if precision == "fp32" else BF16_MFMA_PEAK_TFLOPS

@@ -1046,7 +1046,7 @@ constexpr int ST_LDS_BYTES_U8 = ST_LDS_BYTES + 1552;
 constexpr int ST_BLOCKS = (ST_HALO_PX + 31) / 32;    // 11 blocks of 32 halo pixels
 constexpr unsigned ST_OOB = 0xF0000000u;
 static int g_stem_fused = 1;
-static int g_stem3_prio = 3;  // producer issue priority of the bf16x3 stem (0..3; test hook — 3 measured best)
+static int g_stem3_prio = 0;  // bf16x3 stem, test hook: producer issue priority | consumer priority << 2
 
 struct StemParams {
   const void* x;     // U8 = false: [N][3][H][W] fp32 (normalised); U8 = true: [N][H][W][3] uint8
@@ -1520,11 +1520,15 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
     // producer wave per SIMD handling three blocks, the VALU-heavy role (two splits per value, ~1400
     // dependent VALU instructions per tile at ~8 cycles each) was 1.7x the consumers' time; three
     // waves per SIMD hide each other's instruction latency.  The kernel therefore runs 16 waves per
-    // workgroup at <= 128 VGPRs.  prod_prio (test hook) raises the role's issue priority outside
-    // its MFMAs.
-    if (p.prod_prio == 1) __builtin_amdgcn_s_setprio(1);
-    else if (p.prod_prio == 2) __builtin_amdgcn_s_setprio(2);
-    else if (p.prod_prio == 3) __builtin_amdgcn_s_setprio(3);
+    // workgroup at <= 128 VGPRs.  prod_prio (test hook) sets the roles' issue priorities (producers:
+    // outside their MFMAs, which always go out at priority 3).  Measured (tests/gpu_stem3_prof.py):
+    // every setting lands within 5 % — skewed priorities save shader cycles per tile (10.6k vs
+    // 12.9k), the chip answers with a lower clock and the wall time is 2.07-2.19 ms either way; equal
+    // priorities (the default, 0 / 0) are the fastest.
+    const int pprio = p.prod_prio & 3;
+    if (pprio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (pprio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (pprio == 3) __builtin_amdgcn_s_setprio(3);
     const int pw = wave - 4;   // 0..11: producer wave pw owns block pw of the 11 (wave 15 only keeps step)
     const bool has_block = pw < ST_BLOCKS;
     const __amdgpu_buffer_rsrc_t rs_x =
@@ -1679,9 +1683,9 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[h][s], xl[bi][s], acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[h][s], xh[bi][s], acc, 0, 0, 0);
         }
-        if (p.prod_prio == 0) __builtin_amdgcn_s_setprio(0);
-        else if (p.prod_prio == 1) __builtin_amdgcn_s_setprio(1);
-        else if (p.prod_prio == 2) __builtin_amdgcn_s_setprio(2);
+        if (pprio == 0) __builtin_amdgcn_s_setprio(0);
+        else if (pprio == 1) __builtin_amdgcn_s_setprio(1);
+        else if (pprio == 2) __builtin_amdgcn_s_setprio(2);
         // D[row = channel][col = pixel]: registers 4g..4g+3 = channels 8 g + 4 half + 0..3 of the
         // lane's pixel -> hi: 8 bytes of 16-B slot g, lo: of slot 4 + g (both swizzled), + 8 half.
         bool pix_ok = true;
@@ -1758,6 +1762,12 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
 
   // ================================== consumers ================================================
   {
+    const int cprio = (p.prod_prio >> 2) & 3;   // test hook: the consumers' issue priority
+    if (cprio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (cprio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (cprio == 3) __builtin_amdgcn_s_setprio(3);
+  }
+  {
     const int piece = ((lane & 7) ^ (4 * (wave & 1) + (lane >> 4))) * 16;
 #pragma unroll
     for (int j = 0; j < 18; ++j) {
@@ -1772,83 +1782,86 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
   // reads halo pixel (ly + ky, lx + kx): its row is a compile-time distance (ky * 34 + kx) * 128 from
   // the lane's own, and its 16-B slot (2 pr + half) ^ swz(hy, hx) differs from the tap-(0,0) slot only
   // by   (lx + kx) >> 1 = (lx >> 1) + {0, lx & 1, 1}[kx]   and the constant bits pr << 1, (ky & 1) << 2.
-  // Three per-lane slot offsets per block (kx = 0, 1, 2) and one v_xad_u32 per read replace ~12 VALU
-  // instructions per read (hoisted, the 18 x 2 x 2 addresses would cost ~70 of this kernel's 128 VGPRs).
-  int e_kx[2][3], pxb[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  // Block 1's pixel is 16 columns right of block 0's: the same slot ((lx >> 1) & 7 repeats every 16
+  // columns) 2048 bytes on.  So three per-lane slot offsets (kx = 0, 1, 2), one pixel offset and ONE
+  // v_xad_u32 per pair of reads replace ~12 VALU instructions per read (hoisted, the 18 x 2 x 2
+  // addresses would cost ~70 of this kernel's 128 VGPRs).
+  int e_kx[3], pxb;
+  {
     const int ly = 2 * wave + ((l31 >> 1) & 1);
-    const int lx = 16 * i + 2 * (l31 >> 2) + (l31 & 1);
+    const int lx = 2 * (l31 >> 2) + (l31 & 1);
     const int fix = half ^ ((ly & 1) << 2);
-    e_kx[i][0] = (fix ^ ((lx >> 1) & 7)) << 4;
-    e_kx[i][2] = (fix ^ (((lx >> 1) + 1) & 7)) << 4;
-    e_kx[i][1] = (lx & 1) ? e_kx[i][2] : e_kx[i][0];
-    pxb[i] = (ly * C64_HW + lx) * 128;
+    e_kx[0] = (fix ^ ((lx >> 1) & 7)) << 4;
+    e_kx[2] = (fix ^ (((lx >> 1) + 1) & 7)) << 4;
+    e_kx[1] = (lx & 1) ? e_kx[2] : e_kx[0];
+    pxb = (ly * C64_HW + lx) * 128;
   }
   int w_off[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) w_off[kk] = l31 * 128 + (((2 * kk + half) ^ ((l31 >> 1) & 7)) << 4);
   const float bval = p.b2[co0 + l31];
 
-  // the pooled outputs of tile i are held back (hi | lo << 16 per pixel) and stored one pixel at a
-  // time between the matrix steps of tile i+1
+  // The pooled outputs of tile i are held back and stored one pixel at a time between the matrix
+  // steps of tile i+1.  A pending pixel is ONE dword per lane: lanes l31 and l31 ^ 1 exchange halves
+  // (DPP + v_perm), the even lane stores the hi parts of channels (l31, l31 + 1), the odd lane the lo
+  // parts of (l31 - 1, l31) — a half-wave writes the full 128-byte line of its pixel.  The store is a
+  // buffer store into ONE OUTPUT ROW of the map (descriptor rebuilt per tile from scalars, zero
+  // records for a row below the map): a pixel right of the map is out of range and dropped by the
+  // hardware, the pixel's distance is the instruction's immediate — no mask, no compare, no branch,
+  // so a pass stays one basic block and the scheduler can place the fragment reads freely.
   uint32_t pend[8];
-  uint32_t pmask = 0;
-  char* pbase = p.out;
 #pragma unroll
   for (int e = 0; e < 8; ++e) pend[e] = 0;
+  __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0, 0x00020000);  // nothing pending
+  const unsigned lane_off =
+      blockIdx.y * 128 + half * 256 + ((l31 & 1) ? 64 + (l31 - 1) * 2 : l31 * 2);
+  unsigned poff = lane_off;
   auto store_px = [&](int e) __attribute__((always_inline)) {
-    if ((pmask >> e) & 1) {
-      uint16_t* o = reinterpret_cast<uint16_t*>(pbase + (8 * (e >> 2) + 2 * (e & 3)) * 256);
-      o[0] = (uint16_t)pend[e];
-      o[32] = (uint16_t)(pend[e] >> 16);
-    }
+    __builtin_amdgcn_raw_buffer_store_b32(pend[e], rs_o, (int)(poff + 512u * e), 0, 0);
   };
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   const bool cprof = p.prof != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0;
   unsigned long long ct[3] = {0, 0, 0};
   f32x16_t acc[2];
-  for (int s = 0; s < nstages; ++s) {
+  // one pass = 18 steps (tap, 16-wide half pr of the K-tile) over channel half h of the halo
+  auto run_pass = [&](auto h_c) __attribute__((always_inline)) {
+    constexpr int h = decltype(h_c)::value;
     const unsigned long long c0 = cprof ? __builtin_amdgcn_s_memtime() : 0;
-    const int h = s & 1;
-    const int tile = first + (s >> 1) * stride;
-    int pc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) pc[i] = pxb[i] + h * ST_HALO_BYTES;
-    const char* const wbase = wl + h * (9 * 32 * 128);
+    // LDS addresses beyond the 16-bit immediate of a DS instruction live in the base registers:
+    // pc = this lane's pixel in halo buffer h, w_off[] = its weight row in pass h's weight image
+    const int pc = pxb + S3_W_BYTES + h * ST_HALO_BYTES;
     if (h == 0) {
+      float b = bval;
+      asm volatile("" : "+v"(b));   // per pass: a hoisted 16-register splat would be spilled
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = bval;
+        for (int r = 0; r < 16; ++r) acc[i][r] = b;
     }
-    // 18 steps (tap, 16-wide half pr of the K-tile), fragment reads one step ahead
     bf16x8_t fah[2][2], fal[2][2], fbh[2], fbl[2];
     auto load_step = [&](int sidx, bf16x8_t (&ah)[2], bf16x8_t (&al)[2], bf16x8_t& bh, bf16x8_t& bl)
         __attribute__((always_inline)) {
       const int tap = sidx >> 1, pr = sidx & 1;
       const int ky = tap / 3, kx = tap - 3 * ky;
+      const int c = (pr << 5) ^ ((ky & 1) << 6);   // hi chunk; the lo chunk sits 4 slots on
+      int a_hi, a_lo;
+      asm("v_xad_u32 %0, %1, %2, %3" : "=v"(a_hi) : "v"(e_kx[kx]), "s"(c), "v"(pc));
+      asm("v_xad_u32 %0, %1, %2, %3" : "=v"(a_lo) : "v"(e_kx[kx]), "s"(c ^ 64), "v"(pc));
+      const char* px = smem + (ky * C64_HW + kx) * 128;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int c = (pr << 5) ^ ((ky & 1) << 6);   // hi chunk; the lo chunk sits 4 slots on
-        int a_hi, a_lo;
-        asm("v_xad_u32 %0, %1, %2, %3" : "=v"(a_hi) : "v"(e_kx[i][kx]), "s"(c), "v"(pc[i]));
-        asm("v_xad_u32 %0, %1, %2, %3" : "=v"(a_lo) : "v"(e_kx[i][kx]), "s"(c ^ 64), "v"(pc[i]));
-        const char* px = hb + (ky * C64_HW + kx) * 128;
-        ah[i] = *reinterpret_cast<const bf16x8_t*>(px + a_hi);
-        al[i] = *reinterpret_cast<const bf16x8_t*>(px + a_lo);
+        ah[i] = *reinterpret_cast<const bf16x8_t*>(px + i * 2048 + a_hi);
+        al[i] = *reinterpret_cast<const bf16x8_t*>(px + i * 2048 + a_lo);
       }
-      bh = *reinterpret_cast<const bf16x8_t*>(wbase + tap * 4096 + w_off[pr]);
-      bl = *reinterpret_cast<const bf16x8_t*>(wbase + tap * 4096 + w_off[pr + 2]);
+      bh = *reinterpret_cast<const bf16x8_t*>(smem + tap * 4096 + w_off[pr]);
+      bl = *reinterpret_cast<const bf16x8_t*>(smem + tap * 4096 + w_off[pr + 2]);
     };
     load_step(0, fah[0], fal[0], fbh[0], fbl[0]);
 #pragma unroll
     for (int sidx = 0; sidx < 18; ++sidx) {
       const int b = sidx & 1;
       if (sidx + 1 < 18) load_step(sidx + 1, fah[b ^ 1], fal[b ^ 1], fbh[b ^ 1], fbl[b ^ 1]);
-      // (no sched_barrier here: with one the allocator spills 3 KB per lane at this kernel's 128 VGPRs;
-      //  the reads of step sidx+1 are independent of this step's MFMAs and the scheduler hoists them)
 #pragma unroll
       for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[b][i], fbh[b], acc[i], 0, 0, 0);
 #pragma unroll
@@ -1856,8 +1869,20 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[b][i], fbh[b], acc[i], 0, 0, 0);
       if (h == 0 && (sidx & 1) == 1 && (sidx >> 1) < 8) store_px(sidx >> 1);
+      if (sidx + 1 < 18) {
+        // the six fragment reads of step sidx+1 (and their two address instructions) go out one per
+        // MFMA of this step: a full step of latency cover, no read burst in front of the matrix pipe
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (q < 2) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if (q == 3 && h == 0 && (sidx & 1) == 1 && (sidx >> 1) < 8)
+            __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);   // this step's pending-pixel store
+        }
+      }
     }
-    // every fragment read of `cur` has been consumed by the MFMAs above: hand the buffer back
+    // every fragment read of this halo buffer has been consumed by the MFMAs above: hand it back
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const unsigned long long c1 = cprof ? __builtin_amdgcn_s_memtime() : 0;
     __builtin_amdgcn_s_barrier();
@@ -1865,27 +1890,36 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
       ct[0] += c1 - c0;
       ct[1] += __builtin_amdgcn_s_memtime() - c1;
     }
-    if (h == 1) {
-      const unsigned r2 = (unsigned)tile / (unsigned)p.tiles_x;
-      const int tx = tile - (int)r2 * p.tiles_x;
-      const int n = (int)(r2 / (unsigned)p.tiles_y), ty = (int)r2 - n * p.tiles_y;
-      const int oy = ty * 4 + wave;
-      // (a pending store of the previous tile that found no slot — none: all 8 went out in pass 0)
-      pbase = p.out + (((long)n * Ho + oy) * Wo + tx * 16 + half) * 256 + blockIdx.y * 128 + l31 * 2;
-      pmask = 0;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+    for (int kk = 0; kk < 4; ++kk) w_off[kk] += h == 0 ? 9 * 32 * 128 : -(9 * 32 * 128);   // the other pass's image
+  };
+  using C0 = std::integral_constant<int, 0>;
+  using C1 = std::integral_constant<int, 1>;
+  const uint32_t psel = (l31 & 1) ? 0x03020706u : 0x05040100u;
+  for (int it = 0; it < niter; ++it) {
+    run_pass(C0{});
+    run_pass(C1{});
+    // pool, split, pair up: the tile's eight pixels of this lane become pending
+    const int tile = first + it * stride;
+    const unsigned r2 = (unsigned)tile / (unsigned)p.tiles_x;
+    const int tx = tile - (int)r2 * p.tiles_x;
+    const int n = (int)(r2 / (unsigned)p.tiles_y), ty = (int)r2 - n * p.tiles_y;
+    const int oy = ty * 4 + wave;
+    rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out + ((long)n * Ho + oy) * Wo * 256, 0,
+                                             oy < Ho ? Wo * 256 : 0, 0x00020000);
+    poff = lane_off + (unsigned)tx * (16 * 256);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int ox = tx * 16 + 8 * i + 2 * g + half;
-          pmask |= (oy < Ho && ox < Wo) ? (1u << (4 * i + g)) : 0u;
-          const float v = fmaxf(fmaxf(fmaxf(acc[i][4 * g], acc[i][4 * g + 1]),
-                                      fmaxf(acc[i][4 * g + 2], acc[i][4 * g + 3])), 0.f);
-          uint16_t hi, lo;
-          x3_split(v, hi, lo);
-          pend[4 * i + g] = (uint32_t)hi | ((uint32_t)lo << 16);
-        }
-    }
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float v = fmaxf(fmaxf(fmaxf(acc[i][4 * g], acc[i][4 * g + 1]),
+                                    fmaxf(acc[i][4 * g + 2], acc[i][4 * g + 3])), 0.f);
+        uint16_t hi, lo;
+        x3_split(v, hi, lo);
+        const uint32_t mine = (uint32_t)hi | ((uint32_t)lo << 16);
+        const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);  // lane ^ 1
+        pend[4 * i + g] = __builtin_amdgcn_perm(other, mine, psel);
+      }
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) store_px(e);
@@ -2128,7 +2162,7 @@ int oibl_debug_set_ring_ablate(int mode) {
 }
 
 int oibl_debug_set_stem3_prio(int prio) {
-  g_stem3_prio = prio < 0 ? 0 : (prio > 3 ? 3 : prio);
+  g_stem3_prio = prio < 0 ? 0 : (prio & 15);
   return OIBL_OK;
 }
 

@@ -1,4 +1,5 @@
-"""Role breakdown (shader clocks) of the fused bf16x3 stem kernel, block (0, 0) (diagnostic)."""
+"""Role breakdown (shader clocks, block (0, 0)) of the fused bf16x3 stem per issue-priority setting.
+argv: hook values = producer priority | consumer priority << 2   (default: a sweep)"""
 import sys
 from pathlib import Path
 import torch
@@ -14,27 +15,26 @@ w1 = torch.randn((64, 3, 3, 3), device=dev) * 0.2
 b1 = torch.zeros(64, device=dev)
 w2 = ops.pack_conv3x3(torch.randn((64, 64, 3, 3), device=dev) * 0.05, "bf16x3")
 b2 = torch.zeros(64, device=dev)
-for prio in (0, 1, 2, 3):
-    L.oibl_debug_set_stem3_prio(prio)
-    for _ in range(2):
+tiles = N * ((H + 7) // 8) * ((W + 31) // 32) / 128
+for _ in range(10):
+    ops.vgg16_stem_x3(x, w1, b1, w2, b2)
+for mode in [int(a) for a in sys.argv[1:]] or [0, 3, 5, 10, 12, 15]:
+    L.oibl_debug_set_stem3_prio(mode)
+    for _ in range(3):
         ops.vgg16_stem_x3(x, w1, b1, w2, b2)
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    for _ in range(5):
+    for _ in range(10):
         ops.vgg16_stem_x3(x, w1, b1, w2, b2)
     e.record()
     torch.cuda.synchronize()
-    print(f"stem x3 {N}x{H}x{W}, producer priority {prio}: {s.elapsed_time(e) / 5:.3f} ms")
-L.oibl_debug_set_stem3_prio(int(sys.argv[1]) if len(sys.argv) > 1 else 3)
-L.oibl_debug_set_prof_buffer(buf.data_ptr())
-ops.vgg16_stem_x3(x, w1, b1, w2, b2)
-torch.cuda.synchronize()
-L.oibl_debug_set_prof_buffer(None)
-t = buf.cpu().tolist()
-tiles = N * ((H + 7) // 8) * ((W + 31) // 32) / 128
-print(f"{tiles:.0f} tiles per workgroup (two passes each); ticks are s_memtime counts (100 MHz)")
-for n, v in zip(["consumer: mfma loops", "consumer: barrier wait", "-", "-",
-                 "producer: produce", "producer: barrier wait"], t):
-    if n != "-":
-        print(f"   {n:24s} {v / tiles:9.1f} ticks/tile")
+    L.oibl_debug_set_prof_buffer(buf.data_ptr())
+    ops.vgg16_stem_x3(x, w1, b1, w2, b2)
+    torch.cuda.synchronize()
+    L.oibl_debug_set_prof_buffer(None)
+    t = buf.cpu().tolist()
+    print(f"prod prio {mode & 3} cons prio {(mode >> 2) & 3}: {s.elapsed_time(e) / 10:.3f} ms | "
+          f"consumer loops {t[0] / tiles:8.0f} wait {t[1] / tiles:7.0f} | "
+          f"producer work {t[4] / tiles:8.0f} wait {t[5] / tiles:7.0f} ticks/tile")
+L.oibl_debug_set_stem3_prio(0)

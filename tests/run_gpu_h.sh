@@ -8,4 +8,5 @@ timeout 600 python -m pytest tests/test_gpu_x3.py -m gpu -q --tb=short --timeout
 echo "pytest stem exit $?" | tee -a $OUT/pytest_stem.log
 grep -E "^(FAILED|ERROR)|passed|failed|^E  " $OUT/pytest_stem.log | tail -10
 timeout 300 python tests/gpu_stem3_prof.py 2>&1 | grep -v amdgpu.ids | tee $OUT/stem3_prof.log
-for pr in 0 3; do timeout 300 python tests/gpu_stem3_prof.py $pr 2>&1 | grep -v amdgpu.ids | grep -E "ticks/tile" | sed "s/^/prio=$pr /" | tee -a $OUT/stem3_prof.log; done
+
+timeout 600 python tests/gpu_timing.py --batch 32 --precision bf16x3 2>&1 | grep -v amdgpu.ids | tee $OUT/timing_bf16x3.log

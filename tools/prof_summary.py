@@ -154,7 +154,7 @@ def traffic_table(fp, wp, prof, tag, prec):
         # matrix-core convolution launches, averaged per launch
         tot_b, tot_n = 0.0, 0
         for k, (n, v, t) in fe.items():
-            if not any(tag_ in k for tag_ in ("conv3x3_ring_kernel", "vgg_stem_kernel", "conv3x3_igemm_kernel",
+            if not any(tag_ in k for tag_ in ("conv3x3_ring_kernel", "vgg_stem_kernel", "vgg_stem_x3_kernel", "conv3x3_igemm_kernel",
                                               "conv3x3_c64_kernel")):
                 continue
             w = wr.get(k, [1, 0.0, 1])
