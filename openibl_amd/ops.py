@@ -163,8 +163,9 @@ def set_ring_raster(mode: int) -> None:
 
 
 def set_conv_korder(mode: int) -> None:
-    """Test hook: K order of the implicit-GEMM convolutions, 0 = (tap, channel chunk) [default],
-    1 = (channel chunk, tap): 3-8x fewer fetched bytes, slower (see conv_ring.h)."""
+    """Test hook: K order of the implicit-GEMM convolutions, 0 = (tap, channel chunk), 1 = (channel
+    chunk, tap): 3-8x fewer fetched bytes, slower on all layers but bf16x3 conv2_2; -1 = the per-layer
+    default (order 1 for that layer, 0 elsewhere; see csrc/conv.hip)."""
     _lib.load().oibl_debug_set_conv_korder(int(mode))
 
 

@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--iters", type=int, default=4)
     ap.add_argument("--ablate", default="", help="timing experiment: comma list of ring ablate modes "
                     "(1 = pixel loads, 2 = weight loads, 3 = both served from one line; results wrong)")
-    ap.add_argument("--korder", type=int, default=0, help="K order hook (ops.set_conv_korder)")
+    ap.add_argument("--korder", type=int, default=-1, help="K order hook (ops.set_conv_korder; -1 = per-layer default)")
     a = ap.parse_args()
     ops.set_conv_korder(a.korder)
     modes = [int(m) for m in a.modes.split(",")]

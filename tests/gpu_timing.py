@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--ablate", type=int, default=0)
     ap.add_argument("--c64", type=int, default=1)
     ap.add_argument("--raster", type=int, default=0)
-    ap.add_argument("--korder", type=int, default=0)
+    ap.add_argument("--korder", type=int, default=-1)
     ap.add_argument("--layers", type=int, default=13, help="time conv1_1 and the first LAYERS-1 3x3 layers only")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)

@@ -253,7 +253,7 @@ def test_chunk_major_k_order_hook(dev, precision):
         y1 = ops.conv3x3_nhwc(xd, wp, b.to(dev), True, False, precision)
     finally:
         ops.set_conv_tile(0)
-        ops.set_conv_korder(0)
+        ops.set_conv_korder(-1)
     assert torch.equal(y, y1)
     f = (lambda t: ops.nhwc_to_nchw_f32(ops.x3_join(t) if precision == "bf16x3" else t).cpu())
     want = _host_conv(x, w, b, True, False, "bf16" if precision == "bf16" else "fp32")

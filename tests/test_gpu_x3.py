@@ -272,7 +272,7 @@ def test_vgg_stem_x3_fused(dev, N, H, W):
     try:
         ref = ops.conv3x3_nhwc(a1, wp2, b2.to(dev), True, True, "bf16x3")
     finally:
-        ops.set_conv_korder(0)
+        ops.set_conv_korder(-1)
     assert torch.equal(y, ref)
     h1 = F.relu(F.conv2d(x.double(), w1.double(), b1.double(), padding=1))
     want = F.max_pool2d(F.relu(F.conv2d(h1, w2.double(), b2.double(), padding=1)), 2, 2)
