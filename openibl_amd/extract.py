@@ -1,16 +1,22 @@
-"""The replayed, double-buffered forward behind `ibl.evaluators.extract_features`
+"""The replayed, two-lane forward behind `ibl.evaluators.extract_features`
 (ibl/evaluators.py:36-103) and behind `EmbedNetPCA.graphed()`.
 
 `GraphedForward` captures a forward of a fixed batch shape once into two hipGraphs — backbone (the
 matrix-core launches) and head (everything after the conv5_3 map) — and replays them: a batch costs
 the host two graph launches instead of ~30 kernel launches.  With `pipeline=True` there are two
-slots, each with its own input buffer, feature map and output:
+LANES, each a HIP stream with its own input buffer, activation workspaces, feature map and output;
+batch i runs wholly on lane i % 2:
 
-    copy stream    H2D of batch i+1 into slot (i+1) % 2      (pinned host memory -> no host stall)
-    main stream    backbone graph of batch i    (slot i % 2)
-    side stream    head graph of batch i-1, then the hand-off of its descriptors
+    copy      H2D of batch i+1 into slot (i+1) % 2 as soon as that slot's last backbone has read it
+    lane 0    backbone | head | hand-off of batch 0          backbone | head | hand-off of batch 2 ...
+    lane 1              backbone | head | hand-off of batch 1          backbone | head | ...
 
-so the PCIe copy and the head's latency / HBM-bound kernels hide behind matrix-core work.
+Two hardware queues feed the chip: the head's latency / HBM-bound kernels of one lane hide behind
+the matrix-core work of the other, and so do the partial last rounds of every convolution launch
+(300 tiles on 256 CUs…) — measured +4 % (bf16x3) / +6.6 % (bf16) over one lane
+(`tests/gpu_dual_stream.py`; a third lane adds nothing).  The PCIe copy has its own stream: with
+the copy on the lanes the two lanes fall into step (both copy, then both compute) and the copy is
+no longer hidden (measured: 4275 instead of 5500 images/s from fp32 host batches).
 
 `extract_descriptors` is the loop of `extract_features` over one rank's loader built on it: a batch
 shape is run eagerly the first time it is seen (which also packs weights and sizes workspaces) and
@@ -47,16 +53,19 @@ class GraphedForward:
         fwd = GraphedForward(backbone_fn, head_fn, example, pipeline=True)
         out = fwd(x)              # x: device tensor or (pinned) host tensor of the example's shape
         out = fwd()               # again on the batch resident in the slot
-        fwd.wait()                # the current stream waits for every head launched so far
+        fwd.wait()                # the current stream waits for everything launched so far
 
     backbone_fn(x) -> feature map and head_fn(feat) -> output tensor must only launch work on the
-    current stream and allocate through torch (graph-pool allocations).  The returned tensor is
-    the slot's static output: complete after `wait()` (or a device synchronisation), overwritten
-    by the call `depth` calls later.  `dest=` hands the result off instead: the rows are copied
-    into `dest` on the side stream right behind the head, and the slot is free again without the
-    caller synchronising.
-    `events`: optional (start, stop) torch.cuda.Event pair recorded on the launching stream right
-    around the backbone graph (bench.py's matrix-core span)."""
+    current stream, allocate through torch (graph-pool allocations) and take their scratch from
+    ops.workspace (keyed by stream: every lane captures on its own stream and so owns its scratch).
+    The returned tensor is the slot's static output: complete after `wait()` (or a device
+    synchronisation), overwritten by the call `depth` calls later.  `dest=` hands the result off
+    instead: the rows are copied into `dest` on the lane right behind the head, and the slot is free
+    again without the caller synchronising.  A device tensor `x` must stay unchanged until the lane
+    has copied it (`wait()`); host tensors are read before the call returns unless pinned.
+    `events`: optional (start, stop) torch.cuda.Event pair recorded on the launching lane right
+    around the backbone graph (bench.py's matrix-core span: meaningful with ONE lane — with two the
+    spans of consecutive batches overlap)."""
 
     def __init__(self, backbone_fn: Callable, head_fn: Callable, example: torch.Tensor,
                  pipeline: bool = False):
@@ -68,36 +77,39 @@ class GraphedForward:
         self.pipeline = bool(pipeline)
         self.depth = 2 if self.pipeline else 1
         self.calls = 0
-        self.side = torch.cuda.Stream(device=dev) if self.pipeline else None
+        self.lanes = [torch.cuda.Stream(device=dev) for _ in range(self.depth)] if self.pipeline else [None]
         self.copy = torch.cuda.Stream(device=dev) if self.pipeline else None
-        # never aliases a caller's tensor; every slot starts with the example in place
-        self.static_in = [example.clone(memory_format=torch.contiguous_format) for _ in range(self.depth)]
         self.in_ready = [torch.cuda.Event() for _ in range(self.depth)]
         self.bb_done = [torch.cuda.Event() for _ in range(self.depth)]
-        self.head_done = [torch.cuda.Event() for _ in range(self.depth)]
+        self.last_stream = None               # the stream the last call's input copy ran on
+        # never aliases a caller's tensor; every slot starts with the example in place
+        self.static_in = [example.clone(memory_format=torch.contiguous_format) for _ in range(self.depth)]
+        self.done = [torch.cuda.Event() for _ in range(self.depth)]
         self.g_backbone, self.g_head, self.out = [], [], []
         self._keep = []
         with torch.no_grad():
             head_fn(backbone_fn(self.static_in[0]))   # packs weights, sizes every workspace, warms up
             torch.cuda.synchronize(dev)
             for j in range(self.depth):
-                # Every graph captures into its OWN memory pool: the head of slot 0 runs on the side
-                # stream while the backbone of slot 1 runs on the main stream, so a temporary that
-                # head_fn frees during its capture must never be handed to a later capture (in a
-                # shared pool it would be, and the two slots would alias).
+                # Every graph captures into its OWN memory pool (a temporary that head_fn frees during
+                # its capture must never be handed to another lane's capture), and every lane captures
+                # ON ITS OWN STREAM: ops.workspace keys scratch buffers by stream, so the two lanes —
+                # which run concurrently — record disjoint activation / partial-sum workspaces.
+                kw = {"stream": self.lanes[j]} if self.pipeline else {}
                 gb = torch.cuda.CUDAGraph()
                 # thread_local: a communicator's watchdog thread (RCCL, one process per GPU) may
                 # touch the HIP runtime while this thread captures
-                with torch.cuda.graph(gb, capture_error_mode="thread_local"):
+                with torch.cuda.graph(gb, capture_error_mode="thread_local", **kw):
                     feat = backbone_fn(self.static_in[j])
                 gh = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gh, capture_error_mode="thread_local"):
+                with torch.cuda.graph(gh, capture_error_mode="thread_local", **kw):
                     out = head_fn(feat)
                 self.g_backbone.append(gb)
                 self.g_head.append(gh)
                 self.out.append(out)
                 self._keep += [feat, out]
             self._keep += ops.workspaces_snapshot()   # scratch the graphs recorded pointers into
+            torch.cuda.synchronize(dev)
 
     @property
     def shape(self):
@@ -108,47 +120,56 @@ class GraphedForward:
         j = self.calls % self.depth
         self.calls += 1
         main = torch.cuda.current_stream(self.device)
-        if x is not None:                     # x=None: run again on the batch resident in slot j
-            if x.shape != self.static_in[j].shape or x.dtype != self.static_in[j].dtype:
-                raise ValueError(f"graphed forward was captured for {tuple(self.static_in[j].shape)} "
-                                 f"{self.static_in[j].dtype}")
-            if self.pipeline:
-                # the previous backbone that read this slot's input has finished; whatever produced
-                # x on the caller's stream has, too
-                self.copy.wait_event(self.bb_done[j])
-                if x.is_cuda:
-                    self.copy.wait_stream(main)
-                with torch.cuda.stream(self.copy):
-                    self.static_in[j].copy_(x, non_blocking=True)
-                    self.in_ready[j].record(self.copy)
-                main.wait_event(self.in_ready[j])
-            else:
-                self.static_in[j].copy_(x, non_blocking=True)
-        if self.pipeline:
-            main.wait_event(self.head_done[j])   # slot j's feature map / output are free again
-        if events is not None:
-            events[0].record()
-        self.g_backbone[j].replay()
-        if events is not None:
-            events[1].record()
+        if x is not None and (x.shape != self.static_in[j].shape or x.dtype != self.static_in[j].dtype):
+            raise ValueError(f"graphed forward was captured for {tuple(self.static_in[j].shape)} "
+                             f"{self.static_in[j].dtype}")
         if not self.pipeline:
+            self.last_stream = main
+            if x is not None:                 # x=None: run again on the batch resident in the slot
+                self.static_in[j].copy_(x, non_blocking=True)
+            if events is not None:
+                events[0].record()
+            self.g_backbone[j].replay()
+            if events is not None:
+                events[1].record()
             self.g_head[j].replay()
             if dest is not None:
                 dest.copy_(self.out[j], non_blocking=True)
             return self.out[j]
-        self.bb_done[j].record(main)
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(self.bb_done[j])
+        lane = self.lanes[j]
+        if x is not None:
+            # the slot's last backbone has read its input; whatever produced x on the caller's
+            # stream has finished
+            self.copy.wait_event(self.bb_done[j])
+            if x.is_cuda:
+                self.copy.wait_stream(main)
+            with torch.cuda.stream(self.copy):
+                self.static_in[j].copy_(x, non_blocking=True)
+                self.in_ready[j].record(self.copy)
+            lane.wait_event(self.in_ready[j])
+            self.last_stream = self.copy
+        if dest is not None:
+            lane.wait_stream(main)           # dest was allocated / last written on the caller's stream
+        # the slot's previous batch (feature map, output, hand-off) is behind us on the same lane
+        with torch.cuda.stream(lane):
+            if events is not None:
+                events[0].record(lane)
+            self.g_backbone[j].replay()
+            self.bb_done[j].record(lane)
+            if events is not None:
+                events[1].record(lane)
             self.g_head[j].replay()
             if dest is not None:
                 dest.copy_(self.out[j], non_blocking=True)
-            self.head_done[j].record(self.side)
+            self.done[j].record(lane)
         return self.out[j]
 
     def wait(self) -> None:
-        """Make the current stream wait for every head (and hand-off copy) launched so far."""
+        """Make the current stream wait for every batch (and hand-off copy) launched so far."""
         if self.pipeline:
-            torch.cuda.current_stream(self.device).wait_stream(self.side)
+            main = torch.cuda.current_stream(self.device)
+            for ev in self.done:
+                main.wait_event(ev)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -280,7 +301,7 @@ def extract_descriptors(model, data_loader, vlad=True, pca=None, gpu=None, print
                         last_fwd.wait()               # another shape's side stream: keep the order simple
                     out = fwd(imgs, dest=dst)
                     if slot is not None:
-                        stage.mark(slot, fwd.copy)
+                        stage.mark(slot, fwd.last_stream)
                     last_fwd = fwd
                     if dst is None:
                         fwd.wait()

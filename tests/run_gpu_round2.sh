@@ -22,6 +22,11 @@ timeout 900 python bench.py 2> $OUT/bench_err.log | tee $OUT/bench.json | cut -c
 # the launch line the driver uses for N > 1, with one rank: RCCL init / barrier / all-reduce path
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 \
   bench.py --gpus 1 --steps 10 --warmup 3 --skip-cpu-baseline --skip-api 2> $OUT/bench_torchrun_err.log | tee $OUT/bench_torchrun.json | cut -c1-300
+# flow check of the N = 2 launch line on this one-GPU box: two ranks share the GPU over gloo (the
+# numbers mean nothing; what is checked is that the line comes out: barrier / max-reduce / sharded
+# matching with two real ranks)
+OIBL_BENCH_SHARED_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29543 \
+  bench.py --gpus 2 --steps 5 --warmup 2 --skip-cpu-baseline --skip-api 2> $OUT/bench_2ranks_shared_err.log | tee $OUT/bench_2ranks_shared.json | cut -c1-300
 for p in bf16x3 bf16; do
   timeout 600 python tests/gpu_timing.py --batch 32 --precision $p 2>&1 | grep -v amdgpu.ids | tee $OUT/timing_$p.log
 done
@@ -37,7 +42,9 @@ if [ -z "$QUICK" ]; then
   timeout 300 python bench.py --sustain 12 --precision bf16 2>> $OUT/bench_err.log > $OUT/sustain_bf16.json
 fi
 cd /tmp && export TMPDIR=/tmp
-SKIP="--skip-matching --skip-cpu-baseline --skip-api --skip-fast-mode"
+# --no-pipeline: one lane, so that the per-kernel durations are those of the roofline's span leg
+# (with two lanes in flight the launches of consecutive steps overlap and every duration stretches)
+SKIP="--no-pipeline --skip-matching --skip-cpu-baseline --skip-api --skip-fast-mode"
 for p in bf16x3 bf16; do
   # kernel stats over a run long enough that steady-state launches dominate the averages
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_$p -o bench -- python $R/bench.py --precision $p --steps 40 --warmup 5 $SKIP > $OUT/prof_stats_$p.log 2>&1

@@ -149,6 +149,29 @@ def test_graphed_forward_equals_eager(dev):
     assert torch.equal(a, want1) and torch.equal(b, want2)
 
 
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_two_lanes_in_flight_do_not_share_scratch(dev, precision):
+    """The two lanes of the pipelined replay run concurrently on two streams: activation buffers and
+    split-K partial sums (small batches run the deep layers split-K) must be per lane.  Alternate two
+    different batches for many rounds without waiting in between, hand-off into a result matrix."""
+    import hubconf
+    model = hubconf.vgg16_netvlad(pretrained=False)
+    model.load_state_dict(synth.embednetpca_state(0))
+    model = model.to(dev).eval().set_precision(precision)
+    xs = [synth.images(2, 128, 160, seed=31 + i).to(dev) for i in range(2)]
+    wants = [model(x).clone() for x in xs]
+    assert not torch.equal(wants[0], wants[1])
+    pf = model.graphed(xs[0], pipeline=True)
+    rounds = 24
+    res = torch.zeros((rounds * 2, wants[0].shape[1]), device=dev)
+    for r in range(rounds):
+        pf(xs[r % 2], dest=res[2 * r:2 * r + 2])
+    pf.wait()
+    torch.cuda.synchronize()
+    for r in range(rounds):
+        assert torch.equal(res[2 * r:2 * r + 2], wants[r % 2]), r
+
+
 @pytest.mark.parametrize("precision", ["bf16", "fp32"])
 @pytest.mark.parametrize("N,H,W", [(2, 64, 96), (1, 70, 90), (1, 480, 640)])
 def test_uint8_input_equals_normalised_input(dev, N, H, W, precision):

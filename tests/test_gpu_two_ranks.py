@@ -1,0 +1,116 @@
+"""N > 1 path with the REAL kernels: two ranks share the one GPU of the test box over a gloo group
+(RCCL refuses two ranks on one device; `gpurun` exposes one GPU), so that everything between the
+collectives — the HIP local top-k with global indices, prepared-query exchange, packed gather,
+k-way merge, the Evaluator's sliced extraction — runs as it does on a multi-GPU node, and only the
+transport differs.  tests/test_sharded_gloo.py covers the same logic on CPU with the oracle injected."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+class _Records(torch.utils.data.Dataset):
+    def __init__(self, images, records):
+        self.images, self.records = images, records
+
+    def __len__(self):
+        return len(self.records)
+
+    def __getitem__(self, i):
+        f, pid, x, y = self.records[i]
+        return self.images[i], f, pid, x, y
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import hubconf
+        from ibl.evaluators import Evaluator
+        from ibl.utils.data.sampler import DistributedSliceSampler
+        from openibl_amd import ops, sharded, synth
+        from oracle import descriptor as od
+        from oracle import matching as om
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        out = {}
+
+        # ---- gallery-sharded matching: each rank owns a contiguous slice of the gallery ----------
+        Q, G, d, k = 37, 1003, 256, 10
+        q, g, gt, pids = synth.retrieval_problem(Q, G, dim=d, seed=11, hard_fraction=0.5)
+        dm = om.pairwise_distance(q, g).numpy()
+        wv, wi = om.topk(dm, k)
+        start, per, n_valid = sharded.slice_bounds(G, rank, world)
+        g_loc = g[start:start + n_valid].to(dev)
+        v, i = sharded.sharded_topk(q.to(dev), g_loc, k, start, precision="fp32")
+        out["topk_fp32"] = bool(np.array_equal(i.cpu().numpy(), wi)
+                                and np.allclose(v.cpu().numpy(), wv, rtol=1e-5, atol=1e-5))
+        v3, i3 = sharded.sharded_topk(q.to(dev), g_loc, k, start, precision="bf16x3")
+        # bf16x3 may order near-ties (|difference| ~ 1e-5) differently from fp64: compare by value
+        got = np.take_along_axis(dm, i3.cpu().numpy().astype(np.int64), 1)
+        out["topk_bf16x3"] = bool(np.allclose(got, wv, rtol=0, atol=5e-5)
+                                  and np.allclose(v3.cpu().numpy(), wv, rtol=0, atol=5e-5))
+        # resident shard (prepared once) + queries prepared by the rank that "extracted" them and
+        # exchanged in prepared form: the same lists, bit for bit
+        shard = ops.PreparedRows(g_loc, "bf16x3")
+        qs, qper, _ = sharded.slice_bounds(Q, rank, world)
+        q_loc = torch.stack([q[(qs + j) % Q] for j in range(qper)]).to(dev)
+        qp = sharded.gather_prepared_queries(q_loc, Q, "bf16x3")
+        vp, ip = sharded.sharded_topk(qp, shard, k, start, precision="bf16x3")
+        out["topk_prepared"] = bool(torch.equal(ip, i3) and torch.equal(vp, v3))
+        # every rank holds the same merged lists
+        both = [torch.empty_like(i3) for _ in range(world)]
+        dist.all_gather(both, i3)
+        out["replicated"] = bool(torch.equal(both[0], both[1]))
+
+        # ---- Evaluator.evaluate: sliced extraction on both ranks, device-resident matching --------
+        state = synth.embednetpca_state(0)
+        model = hubconf.vgg16_netvlad()
+        model.load_state_dict(state)
+        model = model.to(dev).eval()
+        nq, ng = 5, 13
+        imgs = synth.images(nq + ng, 64, 96, seed=41)
+        for j in range(nq):
+            imgs[j] = imgs[nq + 2 * j] + 2.0 * torch.randn(imgs[j].shape, generator=torch.Generator().manual_seed(j))
+        query = [(f"q{j}.png", 1000 + j, 0.0, 0.0) for j in range(nq)]
+        gallery = [(f"g{j}.png", j // 2, 0.0, 0.0) for j in range(ng)]
+        gts = [[2 * j] for j in range(nq)]
+        qset, gset = _Records(imgs[:nq], query), _Records(imgs[nq:], gallery)
+
+        def loader(ds):
+            return torch.utils.data.DataLoader(ds, batch_size=4, num_workers=0, shuffle=False,
+                                               sampler=DistributedSliceSampler(ds))
+
+        ev = Evaluator(model)
+        r_dev = ev.evaluate(loader(qset), query + gallery, query, gallery, gts, gallery_loader=loader(gset))
+        r_host = ev.evaluate(loader(qset), query + gallery, query, gallery, gts,
+                             gallery_loader=loader(gset), device_resident=False)
+        with torch.no_grad():
+            desc = od.extract_cnn_feature(imgs, state)
+        want = om.evaluate_all(om.pairwise_distance(desc[:nq], desc[nq:]).numpy(), gts, [x[1] for x in gallery])
+        out["recalls"] = bool(np.array_equal(r_dev, want) and np.array_equal(r_host, want) and want[0] == 1.0)
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_sharded_matching_and_evaluator():
+    world = 2
+    port = 29900 + os.getpid() % 90
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=420)
+            assert p.exitcode == 0
+        for r in range(world):
+            assert ret[r] and all(ret[r].values()), (r, dict(ret[r]))

@@ -77,7 +77,7 @@ def main():
             f"# {tag}: single-image latency (tests/gpu_latency.py; medians / minima over 40 device-synchronised calls)\n\n"
             + (d / "latency.md").read_text())
     sustain_md(d, prof, tag)
-    skip = "--skip-matching --skip-cpu-baseline --skip-api --skip-fast-mode"
+    skip = "--no-pipeline --skip-matching --skip-cpu-baseline --skip-api --skip-fast-mode"
     for sub, name, title in (
             ("prof_stats", f"{tag}_kernel_stats.md", "python bench.py --steps 40 --warmup 5 --skip-matching --skip-cpu-baseline"),
             ("prof_stats_bf16x3", f"{tag}_kernel_stats_bf16x3.md", f"python bench.py --precision bf16x3 --steps 40 --warmup 5 {skip}"),
