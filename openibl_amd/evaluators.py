@@ -80,9 +80,10 @@ def _extract_local(model, data_loader, vlad, pca, gpu, print_freq, rank, scales=
     """Run the loader of this rank; returns the [n_local][d] descriptor matrix ON DEVICE, in
     `store_dtype` (None = float32; float16 / bfloat16 = 16-bit descriptor storage).
 
-    Embed* models take the replayed route of openibl_amd.extract (hipGraph per batch shape, copy /
-    backbone / head on three streams, descriptors written straight into a pre-sized matrix); other
-    modules and multi-scale extraction run batch by batch.  Same kernels, same bits."""
+    Embed* models take the replayed route of openibl_amd.extract (hipGraph per batch shape, batches
+    alternating between two lanes, H2D on a copy stream, descriptors written straight into a
+    pre-sized matrix); other modules and multi-scale extraction run batch by batch.  Same kernels,
+    same bits."""
     model.eval()
     if pca is not None:
         pca.load(gpu=gpu)

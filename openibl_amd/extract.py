@@ -298,7 +298,7 @@ def extract_descriptors(model, data_loader, vlad=True, pca=None, gpu=None, print
                     dst = final[row:row + n]
                 if fwd is not None:
                     if last_fwd is not None and last_fwd is not fwd:
-                        last_fwd.wait()               # another shape's side stream: keep the order simple
+                        last_fwd.wait()               # another shape's lanes: keep the order simple
                     out = fwd(imgs, dest=dst)
                     if slot is not None:
                         stage.mark(slot, fwd.last_stream)

@@ -63,6 +63,12 @@ def main():
                     "--steps 10 --warmup 2 (RCCL group with one rank)\n"
                     + "\n".join(l for l in (d / "bench_torchrun.json").read_text().splitlines()
                                 if l.startswith("{")) + "\n\n")
+        if (d / "bench_2ranks_shared.json").exists():
+            f.write("==== OIBL_BENCH_SHARED_GPU=1 python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2 "
+                    "--steps 5 --warmup 2: FLOW CHECK of the N = 2 launch line, two ranks time-sharing the one GPU "
+                    "over gloo (not a performance number)\n"
+                    + "\n".join(l[:600] for l in (d / "bench_2ranks_shared.json").read_text().splitlines()
+                                if l.startswith("{")) + "\n\n")
         for n in ("gpu.txt", "timing_bf16x3.log", "timing_bf16.log", "timing_bf16x3_raster1.log",
                   "timing_bf16_raster1.log", "timing_fp32.log", "pcie.log", "convbench.log", "shardbench.log"):
             if (d / n).exists():
