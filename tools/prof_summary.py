@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Condense one tests/run_gpu_round.sh output directory (gpurun_out/<tag>/) into the tracked
+"""Condense one tests/run_gpu_round2.sh (round 1: run_gpu_round.sh) output directory (gpurun_out/<tag>/) into the tracked
 summaries under profiles/:  <tag>_bench.json, <tag>_kernel_stats.md, <tag>_hbm_traffic.md,
 <tag>_timing.txt.
 
