@@ -275,7 +275,7 @@ def test_configs1_batch32_480x640_against_oracle(dev, state_dict, precision, tol
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x3"])
 def test_replayed_extraction_equals_batch_by_batch(group, state_dict, dev, precision):
-    """extract_features through the replayed three-stream route == the eager batch-by-batch route,
+    """extract_features through the replayed two-lane route == the eager batch-by-batch route,
     bit for bit: mixed batch shapes (graph per repeated shape, eager for singletons), a ragged last
     batch, pinned and pageable batches, raw uint8 batches, external PCA, 16-bit storage."""
     import hubconf

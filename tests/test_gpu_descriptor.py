@@ -133,7 +133,7 @@ def test_graphed_forward_equals_eager(dev):
     assert torch.equal(fwd(x1), want1)
     with pytest.raises(ValueError):
         fwd(synth.images(1, 64, 96, seed=1).to(dev))
-    # pipelined: head of call i on a second stream, overlapped with the backbone of call i+1
+    # pipelined: two lanes (call i on lane i % 2), each with its own buffers
     pf = model.graphed(x1, pipeline=True)
     outs = []
     for x, want in ((x1, want1), (x2, want2), (x1, want1), (x2, want2), (x2, want2)):
