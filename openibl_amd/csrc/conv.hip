@@ -1338,18 +1338,22 @@ __global__ __launch_bounds__(512) void vgg_stem_kernel(StemParams p) {
   const bool cprof = p.prof != nullptr && blockIdx.x == 0 && wave == 0;
   unsigned long long ct[3] = {0, 0, 0};
   // The pooled outputs of tile i are held back (8 packed registers) and stored one pixel at a time
-  // between the matrix steps of tile i+1, so the store issue hides in the MFMA shadow.
+  // between the matrix steps of tile i+1, so the store issue hides in the MFMA shadow.  A pending
+  // pixel is ONE dword per lane: lanes l31 and l31 ^ 1 exchange halves (DPP + v_perm), the even lane
+  // stores channels (l31, l31 + 1), the odd lane channels (32 + l31 - 1, 32 + l31) — a half-wave
+  // writes the full 128-byte line of its pixel — through a buffer descriptor of ONE OUTPUT ROW
+  // (rebuilt per tile from scalars; zero records for a row below the map): a pixel right of the map
+  // is out of range and dropped by the hardware, its distance is the instruction's immediate.  No
+  // mask, no compare, no branch in the matrix loop (as in vgg_stem_x3_kernel).
   uint32_t pend[8];
-  uint32_t pmask = 0;  // bit e: pixel e = 4 i + g of the held tile is inside the image (per lane)
-  char* pbase = p.out;
 #pragma unroll
   for (int e = 0; e < 8; ++e) pend[e] = 0;
+  __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0, 0x00020000);  // nothing pending
+  const unsigned lane_off = half * 128 + ((l31 & 1) ? 64 + (l31 - 1) * 2 : l31 * 2);
+  const uint32_t psel = (l31 & 1) ? 0x03020706u : 0x05040100u;
+  unsigned poff = lane_off;
   auto store_px = [&](int e) __attribute__((always_inline)) {
-    if ((pmask >> e) & 1) {
-      uint16_t* o = reinterpret_cast<uint16_t*>(pbase + (8 * (e >> 2) + 2 * (e & 3)) * 128);
-      o[0] = (uint16_t)pend[e];
-      o[32] = (uint16_t)(pend[e] >> 16);
-    }
+    __builtin_amdgcn_raw_buffer_store_b32(pend[e], rs_o, (int)(poff + 256u * e), 0, 0);
   };
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -1402,22 +1406,23 @@ __global__ __launch_bounds__(512) void vgg_stem_kernel(StemParams p) {
     const int tx = tile - (int)r2 * p.tiles_x;
     const int n = (int)(r2 / (unsigned)p.tiles_y), ty = (int)r2 - n * p.tiles_y;
     const int oy = ty * 4 + wave;
-    // lane's first pooled pixel (i = g = 0) of this wave's pooled row; pixel (i, g) is 8 i + 2 g
-    // pixels = (8 i + 2 g) * 128 bytes further: immediate offsets on one base address
-    pbase = p.out + ((((long)n * Ho + oy) * Wo + tx * 16 + half) * 64 + l31) * 2;
-    pmask = 0;
+    // lane's first pooled pixel (i = g = 0) of this wave's pooled row; pixel e = 4 i + g is 2 e
+    // pixels = 256 e bytes further: immediate offsets on one base offset into the row's descriptor
+    rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out + ((long)n * Ho + oy) * Wo * 128, 0,
+                                             oy < Ho ? Wo * 128 : 0, 0x00020000);
+    poff = lane_off + (unsigned)tx * (16 * 128);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int ox = tx * 16 + 8 * i + 2 * g + half;
-        pmask |= (oy < Ho && ox < Wo) ? (1u << (4 * i + g)) : 0u;
         float v[2];
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
           v[tn] = fmaxf(fmaxf(fmaxf(acc[i][tn][4 * g], acc[i][tn][4 * g + 1]),
                               fmaxf(acc[i][tn][4 * g + 2], acc[i][tn][4 * g + 3])), 0.f);
-        pend[4 * i + g] = pack_bf16x2(v[0], v[1]);
+        const uint32_t mine = pack_bf16x2(v[0], v[1]);
+        const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);  // lane ^ 1
+        pend[4 * i + g] = __builtin_amdgcn_perm(other, mine, psel);
       }
     if (cprof) {
       const unsigned long long c3 = __builtin_amdgcn_s_memtime();
