@@ -47,6 +47,22 @@ def unwrap_model(model):
     return model
 
 
+_LANE_POOL = {}
+
+
+def _lane_streams(dev: torch.device):
+    """The two lane streams and the copy stream of a device, created ONCE per process.  HIP maps
+    streams onto a few hardware queues; two streams created at different times can land on the same
+    queue, and lanes that share a queue run one after the other — the back-fill is gone without any
+    error (measured: a second pair of fresh streams fell back to the one-lane rate, a pool created
+    once held the two-lane rate in every run, tests/gpu_dual_stream.py).  All GraphedForward objects
+    of a device therefore share one pair of lanes (they are replayed one at a time anyway)."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _LANE_POOL:
+        _LANE_POOL[key] = ([torch.cuda.Stream(device=dev) for _ in range(2)], torch.cuda.Stream(device=dev))
+    return _LANE_POOL[key]
+
+
 class GraphedForward:
     """Two-graph replay of `head_fn(backbone_fn(x))` for one input shape.
 
@@ -77,8 +93,7 @@ class GraphedForward:
         self.pipeline = bool(pipeline)
         self.depth = 2 if self.pipeline else 1
         self.calls = 0
-        self.lanes = [torch.cuda.Stream(device=dev) for _ in range(self.depth)] if self.pipeline else [None]
-        self.copy = torch.cuda.Stream(device=dev) if self.pipeline else None
+        self.lanes, self.copy = _lane_streams(dev) if self.pipeline else ([None], None)
         self.in_ready = [torch.cuda.Event() for _ in range(self.depth)]
         self.bb_done = [torch.cuda.Event() for _ in range(self.depth)]
         self.last_stream = None               # the stream the last call's input copy ran on
@@ -89,7 +104,7 @@ class GraphedForward:
         self._keep = []
         with torch.no_grad():
             head_fn(backbone_fn(self.static_in[0]))   # packs weights, sizes every workspace, warms up
-            torch.cuda.synchronize(dev)
+            torch.cuda.synchronize(dev)               # (also: the shared lanes are idle before a capture)
             for j in range(self.depth):
                 # Every graph captures into its OWN memory pool (a temporary that head_fn frees during
                 # its capture must never be handed to another lane's capture), and every lane captures

@@ -1,6 +1,7 @@
 """Experiment: two independent replay pipelines (own streams, own workspaces) in ONE process against
 one pipelined replay — does a second HW queue back-fill the partial rounds of the first?
-    python tests/gpu_dual_stream.py [precision] [lanes]"""
+    python tests/gpu_dual_stream.py [precision] [lanes ...]      (env OIBL_KORDER / OIBL_RASTER: hooks)"""
+import os
 import sys
 import time
 from pathlib import Path
@@ -17,12 +18,27 @@ model = hubconf.vgg16_netvlad(pretrained=False)
 model.load_state_dict(synth.embednetpca_state(0))
 model = model.to(dev).eval()
 model.set_precision(prec)
+from openibl_amd import ops  # noqa: E402
+if "OIBL_KORDER" in os.environ:
+    ops.set_conv_korder(int(os.environ["OIBL_KORDER"]))
+if "OIBL_RASTER" in os.environ:
+    ops.set_ring_raster(int(os.environ["OIBL_RASTER"]))
 x = synth.images(32, 480, 640, seed=100).contiguous().to(dev)
 bb, head = model.base_model.features_nhwc, model.head_from_features
 
 
 def run(lanes, steps=40, warm=6):
-    streams = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
+    if os.environ.get("OIBL_PRIO") == "1":      # lane i at priority -(i % 2): distinct queue pools
+        streams = [torch.cuda.Stream(device=dev, priority=-(i % 2)) for i in range(lanes)]
+    elif os.environ.get("OIBL_PRIO") == "reuse":
+        global _POOL
+        try:
+            _POOL
+        except NameError:
+            _POOL = [torch.cuda.Stream(device=dev) for _ in range(4)]
+        streams = _POOL[:lanes]
+    else:
+        streams = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
     graphs, outs, keep = [], [], []
     with torch.no_grad():
         head(bb(x))
