@@ -10,13 +10,13 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from openibl_amd import ops, lib as _lib  # noqa: E402
 
 dev = torch.device("cuda", 0)
-Q, G, d, k = 8192, 81920, 4096, 10
+Q, G, d, k = 8192, int(sys.argv[1]) if len(sys.argv) > 1 else 81920, 4096, 10
 g = torch.nn.functional.normalize(torch.randn(G, d, device=dev), dim=1)
 q = torch.nn.functional.normalize(torch.randn(Q, d, device=dev), dim=1)
 lib = _lib.load()
 
 
-def run(prec, lanes, reps=6):
+def run(prec, lanes, reps=20):
     gp, qp = ops.PreparedRows(g, prec), ops.PreparedRows(q, prec)
     p = qp.precision
     per = qp.shape[1] * (2 if prec == "bf16" else 4)
