@@ -201,6 +201,19 @@ def time_extraction(c, model, x, precision, steps, warmup, eager=False, pipeline
         "end_to_end_tflops": round(total_flops_per_image() * value / 1e12, 2),
         "end_to_end_frac": round(total_flops_per_image() * value / 1e12 / (peak * c.world), 4),
     }
+    pj = ROOT / "profiles" / "mfma_peak_latest.json"
+    if pj.exists():
+        # what the matrix pipe sustains on this kind of chip with NOTHING else to do (random register
+        # operands, tests/gpu_mfma_peak.py): the power cap, not the 2.5 PFLOP/s of the data sheet, is
+        # the ceiling a long MFMA-bound kernel can reach
+        try:
+            ceil_tf = float(json.loads(pj.read_text())["tflops"])
+            issued = achieved * (3 if precision == "bf16x3" else 1)
+            roof["power_capped_mfma_tflops"] = ceil_tf
+            roof["issued_frac_of_power_capped"] = round(issued / ceil_tf, 4)
+            roof["power_capped_source"] = "profiles/mfma_peak_latest.json (tests/gpu_mfma_peak.py, measured)"
+        except Exception:
+            pass
     if one_lane is not None:
         roof["measured_with"] = ("one lane: a second timed region of the same K steps on one stream, so that "
                                  "launch durations do not overlap (this rank: %.1f images/s)" % one_lane)

@@ -188,11 +188,58 @@ static int launch_gemm_nt(const void* A, int M, const void* B, int N, int K, flo
   return OIBL_OK;
 }
 
+// Diagnostic: the matrix pipe with nothing else to do.  Every wave keeps four independent
+// v_mfma_f32_32x32x16_bf16 chains going on register operands (no LDS, no memory in the loop): what
+// the chip sustains here, at the clock its power management settles on, is the ceiling every
+// MFMA-bound kernel of this library is measured against in DESIGN.md §6 (tests/gpu_mfma_peak.py).
+__global__ __launch_bounds__(512) void mfma_peak_kernel(long iters, float* out) {
+  // four operand pairs of pseudo-random bf16 values in (-2, 2) per lane, rotated MFMA by MFMA:
+  // constant operands would toggle nothing in the multipliers and flatter the power figure
+  bf16x8_t a[4], b[4];
+  unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+#pragma unroll
+  for (int v = 0; v < 4; ++v)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      h = h * 1664525u + 1013904223u;
+      a[v][e] = (short)(((h >> 16) & 0x807f) | (0x3f00 + ((h >> 8) & 0x0080)));   // sign, 7 mantissa bits, exponent 126 / 127
+      h = h * 1664525u + 1013904223u;
+      b[v][e] = (short)(((h >> 16) & 0x807f) | (0x3f00 + ((h >> 8) & 0x0080)));
+    }
+  f32x16_t acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+  for (long i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(u + c) & 3], b[(u + 2 * c + 1) & 3], acc[c], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[c][r];
+  if (s == 12345.678f) out[0] = s;   // keeps the chains alive
+}
+
 }  // namespace oibl
 
 using namespace oibl;
 
 extern "C" {
+
+// diagnostic (not in the public header): `blocks` workgroups x 8 waves x `iters` x 16 MFMAs of
+// 32x32x16 bf16 (32768 flop each) on register operands
+int oibl_debug_mfma_peak(long iters, int blocks, void* scratch, void* stream) {
+  OIBL_REQUIRE(iters > 0 && blocks > 0 && scratch, "mfma_peak: bad arguments");
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, iters, (float*)scratch);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
 
 // test hook (not in the public header): 1 = register-staged main loop, 0 = global_load_lds
 int oibl_debug_set_regstage(int on) {

@@ -99,6 +99,7 @@ _HOOKS = {"oibl_debug_set_regstage": (c_int, [c_int]),
           "oibl_debug_set_conv_c64": (c_int, [c_int]),
           "oibl_debug_set_stem_fused": (c_int, [c_int]),
           "oibl_debug_event_elapsed_ms": (c_int, [c_void_p, c_void_p, c_void_p]),
+          "oibl_debug_mfma_peak": (c_int, [C.c_long, c_int, c_void_p, c_void_p]),
           "oibl_debug_set_match_ring": (c_int, [c_int]),
           "oibl_debug_set_ring_ablate": (c_int, [c_int]),
           "oibl_debug_set_ring_raster": (c_int, [c_int]),

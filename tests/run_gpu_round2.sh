@@ -38,6 +38,8 @@ if [ -z "$QUICK" ]; then
   timeout 300 python tests/gpu_pcie_rate.py 2>&1 | grep -v amdgpu.ids | tee $OUT/pcie.log
   timeout 300 python tests/gpu_shardbench.py 1,2,4,8 bf16 2>&1 | grep -v amdgpu.ids | tee $OUT/shardbench.log
   timeout 300 python tests/gpu_shardbench.py 1,2,4,8 bf16x3 2>&1 | grep -v amdgpu.ids | tee -a $OUT/shardbench.log
+  # the matrix pipe with nothing else to do (random register operands): the power-capped ceiling
+  timeout 200 python tests/gpu_mfma_peak.py 6 $OUT/mfma_peak.md 2>&1 | grep -v amdgpu.ids | tee $OUT/mfma_peak.log
   timeout 300 python bench.py --sustain 12 --precision bf16x3 2>> $OUT/bench_err.log > $OUT/sustain_bf16x3.json
   timeout 300 python bench.py --sustain 12 --precision bf16 2>> $OUT/bench_err.log > $OUT/sustain_bf16.json
 fi

@@ -82,6 +82,10 @@ def main():
         (prof / f"{tag}_latency.md").write_text(
             f"# {tag}: single-image latency (tests/gpu_latency.py; medians / minima over 40 device-synchronised calls)\n\n"
             + (d / "latency.md").read_text())
+    if (d / "mfma_peak.md").exists():
+        shutil.copy(d / "mfma_peak.md", prof / f"{tag}_mfma_peak.md")
+        if (d / "mfma_peak.json").exists():
+            shutil.copy(d / "mfma_peak.json", prof / "mfma_peak_latest.json")
     sustain_md(d, prof, tag)
     skip = "--no-pipeline --skip-matching --skip-cpu-baseline --skip-api --skip-fast-mode"
     for sub, name, title in (
