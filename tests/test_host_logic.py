@@ -267,3 +267,19 @@ def test_tuple_sampler_yields_the_reference_tuples():
         smp.sort_idx = torch.from_numpy(om.ranking(d.numpy()))
         smp._set_subset(sub)
     _run_tuple_sampler(rank_rows)
+
+
+def test_bench_flop_accounting_matches_baseline_md():
+    """bench.py's algorithmic FLOP model of one 480x640 image is BASELINE.md §2 / SURVEY §8d's:
+    backbone 187.918 GFLOP (conv1_1 1.062), NetVLAD 0.157, PCA 0.268 -> 188.344 GFLOP; importing
+    bench.py needs no GPU."""
+    import importlib.util
+    import pathlib
+    spec = importlib.util.spec_from_file_location("bench_mod", pathlib.Path(__file__).resolve().parent.parent / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert abs(bench.conv11_flops_per_image() / 1e9 - 1.062) < 1e-3
+    assert abs((bench.igemm_flops_per_image() + bench.conv11_flops_per_image()) / 1e9 - 187.918) < 1e-3
+    assert abs(bench.total_flops_per_image() / 1e9 - 188.344) < 2e-3
+    # odd sizes: every pool floors
+    assert bench.igemm_flops_per_image(479, 637) < bench.igemm_flops_per_image(480, 640)
