@@ -323,6 +323,17 @@ int oibl_first_hit_rank(const int32_t* topk_idx, int m, int k, const int32_t* gt
                         const int32_t* gt_values, const int32_t* gallery_pids, int nms_window,
                         int32_t* out_rank, void* stream);
 
+/* ---- k-means centroid initialisation (f4) -------------------------------------------- *
+ * examples/cluster.py:110-115 runs scikit-learn's KMeans(num_clusters, max_iter = 100,
+ * random_state = seed) on 50 000 L2-normalised conv5 descriptors.  The assignment step of a Lloyd
+ * iteration is oibl_sqdist_topk(k = 1) against the centres; this is the update step:
+ *   centers[c] <- mean of the rows x[i] with labels[i] == c   (fp64 accumulation in point order,
+ *                 correctly rounded fp32 result), untouched when no row carries the label;
+ *   counts[c]  <- number of such rows (the caller relocates empty clusters as scikit-learn does).
+ *   x [n][d] fp32, labels [n] int32 in [0, num_clusters), centers [num_clusters][d] fp32.          */
+int oibl_cluster_means(const float* x, const int32_t* labels, int n, int d, int num_clusters,
+                       float* centers, int32_t* counts, void* stream);
+
 /* ---- diagnostics ------------------------------------------------------------------ */
 
 /* Plain C = A . B^T on the shared MFMA GEMM core (used by tests to validate the core and

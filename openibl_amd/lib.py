@@ -86,6 +86,7 @@ SIGNATURES = {
     "oibl_row_argsort_workspace_bytes": (c_size_t, [c_int, c_int]),
     "oibl_row_argsort": (c_int, [c_void_p, c_int, c_int, c_size_t, c_void_p, c_void_p, c_void_p, c_size_t,
                                  c_void_p]),
+    "oibl_cluster_means": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "oibl_first_hit_rank": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                     c_void_p, c_void_p]),
     "oibl_gemm_nt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t,

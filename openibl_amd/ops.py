@@ -670,6 +670,24 @@ def sqdist_topk(x: torch.Tensor, y: torch.Tensor, k: int, index_base: int = 0, p
     return ov, oi
 
 
+def cluster_means(x: torch.Tensor, labels: torch.Tensor, centers: torch.Tensor) -> torch.Tensor:
+    """Lloyd update step (oibl_cluster_means): centers[c] <- mean of the rows x[i] with labels[i] == c,
+    in place (fp64 accumulation in point order, correctly rounded); a centre without points keeps its
+    value.  Returns the int32 member counts [num_clusters]."""
+    dev = _need_cuda(x, labels, centers)
+    if x.dtype != torch.float32 or centers.dtype != torch.float32 or x.dim() != 2 or centers.dim() != 2 \
+            or x.shape[1] != centers.shape[1] or not x.is_contiguous() or not centers.is_contiguous():
+        raise ValueError("cluster_means expects contiguous float32 x [n][d] and centers [K][d]")
+    lab = labels.reshape(-1).to(torch.int32).contiguous()
+    if lab.numel() != x.shape[0]:
+        raise ValueError("cluster_means: one label per row")
+    counts = torch.zeros((centers.shape[0],), dtype=torch.int32, device=dev)
+    _lib.check(_lib.load().oibl_cluster_means(_ptr(x), _ptr(lab), int(x.shape[0]), int(x.shape[1]),
+                                              int(centers.shape[0]), _ptr(centers), _ptr(counts), _stream(dev)),
+               "cluster_means")
+    return counts
+
+
 class PreparedRows:
     """A descriptor matrix ready for matching in one precision: the rows the contraction reads and
     their fp32 squared norms (oibl_match_prepare).  Build it once for a matrix that is matched many

@@ -178,3 +178,15 @@ def tuple_lists(num_query: int, num_gallery: int, seed: int = 41):
         pos.append(sorted(int(v) for v in rng.choice(np.arange(c - 3, c + 4), size=3, replace=False)))
         neg.append(list(range(c - 25, c + 26)))
     return pos, neg
+
+
+def kmeans_points(n: int, d: int, blobs: int, seed: int = 43, spread: float = 0.35) -> np.ndarray:
+    """float32 [n][d] unit-norm points around `blobs` random directions (the shape of the data
+    examples/cluster.py clusters: L2-normalised local descriptors), seeded."""
+    rng = np.random.default_rng([seed, 12])
+    dirs = rng.standard_normal((blobs, d))
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    which = rng.integers(0, blobs, size=n)
+    x = dirs[which] + spread * rng.standard_normal((n, d)) / np.sqrt(d) * np.sqrt(d) * 0.1
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return np.ascontiguousarray(x.astype(np.float32))

@@ -11,6 +11,7 @@ What is exercised, all through the reference's own code objects:
   ibl.pca.PCA.load / PCA.infer                                       (pca.py:86-123)
   ibl.evaluators.pairwise_distance / evaluate_all / spatial_nms      (evaluators.py:105-167)
   ibl.utils.data.sampler.DistributedRandomTupleSampler.sort_gallery  (sampler.py:46-54)
+  sklearn.cluster.KMeans(...).fit as examples/cluster.py calls it    (cluster.py:110-115)
 Two things have to be faked for the reference to run on a CPU-only box without h5py: `Tensor.cuda`
 is patched to the identity, and `h5py.File` is served from an in-memory dict.
 """
@@ -210,6 +211,23 @@ def main():
         np.savez_compressed(OUT / "tuple_sampler.npz", Q=Q, G=G, seed=seed, **tuples)
         print("tuple_sampler", {k: v.shape for k, v in tuples.items()})
 
+    def run_kmeans(name, cases, seed=43):
+        """The centroid initialisation of examples/cluster.py:110-115 — the reference's own call,
+        `KMeans(n_clusters=K, max_iter=niter, random_state=args.seed).fit(X)` with niter = 100 and the
+        script's default seed 43 — on seeded unit-norm points (scikit-learn is the reference's
+        dependency for this step; its version is not pinned by the reference, this is the image's)."""
+        import sklearn
+        from sklearn.cluster import KMeans
+        out = {"sklearn_version": sklearn.__version__, "seed": seed}
+        for i, (n, d, K, blobs) in enumerate(cases):
+            X = synth.kmeans_points(n, d, blobs, seed=seed + i)
+            km = KMeans(n_clusters=K, max_iter=100, random_state=seed).fit(X.copy())
+            out[f"case{i}"] = np.asarray([n, d, K, blobs, seed + i, km.n_iter_])
+            out[f"centers{i}"] = km.cluster_centers_.astype(np.float32)
+            print(name, i, (n, d, K, blobs), "n_iter", km.n_iter_)
+        np.savez_compressed(OUT / f"{name}.npz", **out)
+
+    run_kmeans("kmeans", [(3000, 64, 16, 16), (2000, 32, 24, 10), (6000, 128, 64, 40)])
     run_sort_gallery("sort_gallery", 10, 2500, seed=41)
     run_rerank("rerank_small", 24, 90, seed=31)
     run_matching("match_small", 48, 300, seed=21, views_per_place=1)
