@@ -1,7 +1,11 @@
 from __future__ import absolute_import
 
 import torch.distributed as dist
-from torch.utils.data.sampler import Sampler
+# examples/cluster.py imports SubsetRandomSampler from this module (the reference's sampler.py:9-11
+# pulls torch's samplers into its namespace)
+from torch.utils.data import BatchSampler  # noqa: F401
+from torch.utils.data.sampler import (  # noqa: F401
+    RandomSampler, Sampler, SequentialSampler, SubsetRandomSampler, WeightedRandomSampler)
 
 from openibl_amd.sharded import slice_bounds
 

@@ -197,6 +197,24 @@ def test_reference_test_py_get_data_runs_against_this_package(tmp_path):
     assert r.returncode == 0 and "REFERENCE_GET_DATA_OK" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.skipif(not __import__("os").path.isfile("/root/reference/examples/cluster.py"),
+                    reason="the reference tree is only present in the build container")
+def test_reference_cluster_py_runs_against_this_package(tmp_path):
+    """The reference's own examples/cluster.py, unmodified: its imports resolve to THIS repo's `ibl`
+    (SubsetRandomSampler from ibl.utils.data.sampler included), get_data() builds its loader and the
+    model factory takes its get_model() arguments (cluster.py:27-47)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    from helpers import synthetic_pitts
+    repo = Path(__file__).resolve().parent.parent
+    synthetic_pitts.make(str(tmp_path / "pitts"))
+    r = subprocess.run([sys.executable, str(repo / "tests" / "helpers" / "ref_clusterpy_probe.py"),
+                        str(tmp_path), "/root/reference/examples/cluster.py", str(repo)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "REFERENCE_CLUSTER_OK" in r.stdout, r.stdout + r.stderr
+
+
 def test_logger_tees_and_leaves_stdout_open(tmp_path, capsys):
     import sys
     from ibl.utils.logging import Logger
