@@ -40,3 +40,46 @@ class Dataset(object):
     def images_dir(self):
         import os.path as osp
         return osp.join(self.root, 'raw')
+
+    def load(self, verbose, scale=None):
+        """Fill the record lists from the json files the reference's dataset parsers write under
+        `root` (meta[_scale].json: identities + utm; splits[_scale].json: place ids per split) —
+        the loader the reference's Pittsburgh / Tokyo classes call from their constructors
+        (ibl/utils/data/dataset.py:57-115).  Queries without a positive within 25 m are dropped from
+        val / test, training queries without a positive within `intra_thres`."""
+        import os.path as osp
+        from ..serialization import read_json
+        suffix = '' if scale is None else '_' + str(scale)
+        meta_f = osp.join(self.root, 'meta' + suffix + '.json')
+        splits_f = osp.join(self.root, 'splits' + suffix + '.json')
+        if not (osp.isfile(meta_f) and osp.isfile(splits_f)):
+            raise RuntimeError("Dataset not found.")
+        meta, splits = read_json(meta_f), read_json(splits_f)
+        ident, utm = meta['identities'], meta['utm']
+
+        def pluck(pids):
+            return sorted((fname, pid, utm[pid][0], utm[pid][1]) for pid in pids for fname in ident[pid])
+
+        # examples/test.py:37-38 reads q_train / db_train (the PCA training set); train = q_train +
+        # db_train BEFORE the queries without positives are dropped
+        self.q_train = pluck(sorted(splits.get('q_train', [])))
+        self.db_train = pluck(sorted(splits.get('db_train', [])))
+        self.train = self.q_train + self.db_train
+        if self.q_train and self.db_train:
+            self.train_pos, self.train_neg, sel = get_groundtruth(
+                self.q_train, self.db_train, self.intra_thres, self.inter_thres)
+            self.train_neg = [self.train_neg[i] for i in sel]
+            self.q_train = [self.q_train[i] for i in sel]
+        self.q_val = pluck(sorted(splits.get('q_val', [])))
+        self.db_val = pluck(sorted(splits.get('db_val', [])))
+        self.q_test = pluck(sorted(splits.get('q_test', [])))
+        self.db_test = pluck(sorted(splits.get('db_test', [])))
+        if self.q_val and self.db_val:
+            self.val_pos, sel = get_groundtruth(self.q_val, self.db_val, self.inter_thres)
+            self.q_val = [self.q_val[i] for i in sel]
+        if self.q_test and self.db_test:
+            self.test_pos, sel = get_groundtruth(self.q_test, self.db_test, self.inter_thres)
+            self.q_test = [self.q_test[i] for i in sel]
+        if verbose:
+            print(self.__class__.__name__, "dataset loaded: {} test queries, {} test gallery".format(
+                len(self.q_test), len(self.db_test)))

@@ -111,3 +111,50 @@ class DistributedRandomTupleSampler(Sampler):
             assert len(picked) == self.neg_num
             self.neg_cache[anchor] = picked
             yield [anchor, positive + offset] + [g + offset for g in picked]
+
+
+class DistributedRandomDiffTupleSampler(DistributedRandomTupleSampler):
+    """The SFRS mining sampler (ibl/utils/data/sampler.py:92-190 of the reference;
+    examples/netvlad_img_sfrs.py): tuples `[anchor, easiest positive, neg_num hardest negatives,
+    up to pos_num "difficult" positives]`.  As above, what runs on the GPU is the full-row ranking of
+    `sort_gallery` (sampler.py:130: `torch.argsort(distmat, dim=1)`); the k-reciprocal matrix
+    `distmat_jac` is only indexed.
+
+    Difficult positives (sampler.py:158-178): of the anchor's best-ranked `pos_pool` positives, those
+    that the Jaccard distance ranks HIGHER than the descriptor distance does, largest promotion first,
+    then the ones both rankings agree on.  The two small sorts are `torch.argsort` calls on the same
+    values as in the reference (its tie behaviour on equal promotions is torch's, so torch is asked);
+    a seeded run yields the same tuples (tests/golden/diff_tuple_sampler.npz)."""
+
+    def __init__(self, query_source, gallery_source, pos_list, neg_list, pos_num=10, pos_pool=20,
+                 neg_num=10, neg_pool=1000, sub_length=None, num_replicas=None, rank=None):
+        super().__init__(query_source, gallery_source, pos_list, neg_list, neg_num=neg_num, neg_pool=neg_pool,
+                         sub_length=sub_length, num_replicas=num_replicas, rank=rank)
+        self.pos_num, self.pos_pool = pos_num, pos_pool
+        self.distmat_jac = None
+
+    def sort_gallery(self, distmat, distmat_jac, sub_set):
+        super().sort_gallery(distmat, sub_set)
+        self.distmat_jac = distmat_jac
+
+    def _difficult_positives(self, anchor, ranked_pos):
+        import torch
+        pool = torch.as_tensor(ranked_pos[: self.pos_pool], dtype=torch.long)
+        jac = torch.as_tensor(self.distmat_jac[anchor])[pool]
+        by_jac = torch.argsort(jac, dim=0)                  # by_jac[i]: descriptor rank of the i-th by Jaccard
+        gap = torch.arange(by_jac.size(0)) - by_jac         # < 0: promoted by the Jaccard distance
+        slots = torch.arange(by_jac.size(0))
+        promoted = slots[gap < 0][torch.argsort(gap[gap < 0], dim=0)]
+        chosen = torch.cat((promoted, slots[gap == 0]), dim=0)[: self.pos_num]
+        return pool[by_jac[chosen]].tolist()
+
+    def __iter__(self):
+        import numpy as np
+        offset = len(self.query_source)
+        base = super().__iter__()
+        for slot in self._my_slots():
+            anchor = self.sub_set[slot]
+            ranked = np.asarray(self.sort_idx[anchor])
+            ranked_pos = ranked[np.isin(ranked, self.pos_list[anchor])].tolist()
+            extra = self._difficult_positives(anchor, ranked_pos)   # (no RNG: before or after `base` alike)
+            yield next(base) + [p + offset for p in extra]

@@ -62,3 +62,25 @@ def synchronize():
     """Barrier across all processes (no-op without a multi-process group)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+def simple_group_split(world_size, rank, num_groups):
+    """Process groups of world_size / num_groups consecutive ranks each; returns the one `rank` belongs
+    to (ibl/utils/dist_utils.py:44-52: the SyncBN groups of the training scripts — VGG16 itself has
+    no normalisation layers, the evaluation path never calls this)."""
+    size = world_size // num_groups
+    members = [list(range(g * size, (g + 1) * size)) for g in range(num_groups)]
+    groups = [dist.new_group(m) for m in members]          # every rank creates every group, in order
+    mine = rank // size
+    print("Rank no.{} start sync BN on the process group of {}".format(rank, members[mine]))
+    return groups[mine]
+
+
+def convert_sync_bn(model, process_group=None, gpu=None):
+    """Replace the batch-norm layers below `model` by SyncBatchNorm, in place (dist_utils.py:54-62)."""
+    for name, child in list(model.named_children()):
+        converted = torch.nn.SyncBatchNorm.convert_sync_batchnorm(child, process_group)
+        if converted is not child:
+            setattr(model, name, converted if gpu is None else converted.cuda(gpu))
+        elif gpu is not None and any(isinstance(m, torch.nn.SyncBatchNorm) for m in child.modules()):
+            child.cuda(gpu)

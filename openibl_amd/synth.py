@@ -168,14 +168,16 @@ def tie_free_matrix(rows: int, cols: int, seed: int = 41, scale: float = 4.0) ->
     return torch.from_numpy(m)
 
 
-def tuple_lists(num_query: int, num_gallery: int, seed: int = 41):
+def tuple_lists(num_query: int, num_gallery: int, seed: int = 41, positives: int = 3):
     """Positive / exclusion lists for the mining-sampler tests: per query a few "positives" and a
-    larger "non-negative" zone around them (gallery positions), seeded."""
-    rng = np.random.default_rng([seed, 10])
+    larger "non-negative" zone around them (gallery positions), seeded.  `positives` > 3 draws them
+    from a wider window (the SFRS sampler ranks a pool of positives)."""
+    rng = np.random.default_rng([seed, 10] if positives == 3 else [seed, 10, positives])
+    half = 3 if positives == 3 else positives
     pos, neg = [], []
     for _ in range(num_query):
         c = int(rng.integers(30, num_gallery - 30))
-        pos.append(sorted(int(v) for v in rng.choice(np.arange(c - 3, c + 4), size=3, replace=False)))
+        pos.append(sorted(int(v) for v in rng.choice(np.arange(c - half, c + half + 1), size=positives, replace=False)))
         neg.append(list(range(c - 25, c + 26)))
     return pos, neg
 

@@ -215,7 +215,10 @@ def main():
         """The centroid initialisation of examples/cluster.py:110-115 — the reference's own call,
         `KMeans(n_clusters=K, max_iter=niter, random_state=args.seed).fit(X)` with niter = 100 and the
         script's default seed 43 — on seeded unit-norm points (scikit-learn is the reference's
-        dependency for this step; its version is not pinned by the reference, this is the image's)."""
+        dependency for this step; its version is not pinned by the reference, this is the image's).
+        scikit-learn sums in float32 in thread-dependent chunks: two runs of this very call differ in
+        the last bit of some centre coordinates (seen: 6e-8), so unlike every other fixture this one
+        regenerates to one ulp, not bit for bit — the committed file is one such run."""
         import sklearn
         from sklearn.cluster import KMeans
         out = {"sklearn_version": sklearn.__version__, "seed": seed}
@@ -227,6 +230,29 @@ def main():
             print(name, i, (n, d, K, blobs), "n_iter", km.n_iter_)
         np.savez_compressed(OUT / f"{name}.npz", **out)
 
+    def run_diff_tuple_sampler(name, Q, G, seed):
+        """DistributedRandomDiffTupleSampler (ibl/utils/data/sampler.py:92-190; the SFRS mining
+        sampler): sort_gallery + two epochs of tuples on two replicas, seeded `random`, tie-free
+        descriptor and Jaccard matrices, 8 positives per query of which pos_pool = 6 are ranked."""
+        import random
+        from ibl.utils.data.sampler import DistributedRandomDiffTupleSampler
+        distmat = synth.tie_free_matrix(Q, G, seed)
+        jac = synth.tie_free_matrix(Q, G, seed + 1, scale=1.0)
+        pos, neg = synth.tuple_lists(Q, G, seed, positives=8)
+        tuples = {}
+        for r in range(2):
+            smp = DistributedRandomDiffTupleSampler(list(range(Q)), list(range(G)), pos, neg, pos_num=4, pos_pool=6,
+                                                    neg_num=5, neg_pool=40, num_replicas=2, rank=r)
+            random.seed(2000 + r)
+            for ep in range(2):
+                smp.sort_gallery(distmat, jac, list(range(1, Q)))
+                rows = list(iter(smp))
+                width = max(len(t) for t in rows)
+                tuples[f"r{r}_e{ep}"] = np.asarray([t + [-1] * (width - len(t)) for t in rows], dtype=np.int32)
+        np.savez_compressed(OUT / f"{name}.npz", Q=Q, G=G, seed=seed, **tuples)
+        print(name, {k: v.shape for k, v in tuples.items()})
+
+    run_diff_tuple_sampler("diff_tuple_sampler", 10, 2500, seed=51)
     run_kmeans("kmeans", [(3000, 64, 16, 16), (2000, 32, 24, 10), (6000, 128, 64, 40)])
     run_sort_gallery("sort_gallery", 10, 2500, seed=41)
     run_rerank("rerank_small", 24, 90, seed=31)

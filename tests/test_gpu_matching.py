@@ -340,3 +340,11 @@ def test_tuple_sampler_on_the_device_ranking(dev):
     from test_host_logic import _run_tuple_sampler
     torch.cuda.set_device(dev)
     _run_tuple_sampler(lambda smp, d, sub: smp.sort_gallery(d, sub))
+
+
+def test_diff_tuple_sampler_on_the_device_ranking(dev):
+    """DistributedRandomDiffTupleSampler.sort_gallery (the SFRS sampler, sampler.py:126-135) ranks on
+    the GPU; the tuples equal the ones the reference's sampler yields."""
+    from test_host_logic import _run_diff_tuple_sampler
+    torch.cuda.set_device(dev)
+    _run_diff_tuple_sampler(lambda smp, d, jac, sub: smp.sort_gallery(d, jac, sub))

@@ -287,6 +287,37 @@ def test_tuple_sampler_yields_the_reference_tuples():
     _run_tuple_sampler(rank_rows)
 
 
+def _run_diff_tuple_sampler(rank_rows):
+    import random
+    from ibl.utils.data.sampler import DistributedRandomDiffTupleSampler
+    g = load_golden("diff_tuple_sampler")
+    Q, G, seed = int(g["Q"]), int(g["G"]), int(g["seed"])
+    pos, neg = synth.tuple_lists(Q, G, seed, positives=8)
+    d = synth.tie_free_matrix(Q, G, seed)
+    jac = synth.tie_free_matrix(Q, G, seed + 1, scale=1.0)
+    for r in range(2):
+        smp = DistributedRandomDiffTupleSampler(list(range(Q)), list(range(G)), pos, neg, pos_num=4, pos_pool=6,
+                                                neg_num=5, neg_pool=40, num_replicas=2, rank=r)
+        random.seed(2000 + r)
+        for ep in range(2):
+            rank_rows(smp, d, jac, list(range(1, Q)))
+            assert len(smp) == 5
+            want = g[f"r{r}_e{ep}"]
+            got = [t + [-1] * (want.shape[1] - len(t)) for t in iter(smp)]
+            np.testing.assert_array_equal(np.asarray(got, dtype=np.int32), want)
+
+
+def test_diff_tuple_sampler_yields_the_reference_tuples():
+    """The SFRS mining sampler (difficult positives by Jaccard promotion on top of the tuple sampler's
+    bookkeeping) against the tuples the reference's own DistributedRandomDiffTupleSampler yielded
+    (tests/golden/diff_tuple_sampler.npz); ranking from the oracle here, from the device in the GPU test."""
+    def rank_rows(smp, d, jac, sub):
+        smp.sort_idx = torch.from_numpy(om.ranking(d.numpy()))
+        smp.distmat_jac = jac
+        smp._set_subset(sub)
+    _run_diff_tuple_sampler(rank_rows)
+
+
 def test_bench_flop_accounting_matches_baseline_md():
     """bench.py's algorithmic FLOP model of one 480x640 image is BASELINE.md §2 / SURVEY §8d's:
     backbone 187.918 GFLOP (conv1_1 1.062), NetVLAD 0.157, PCA 0.268 -> 188.344 GFLOP; importing
@@ -377,3 +408,53 @@ def test_kmeans_empty_cluster_relocation_matches_sklearn():
     c, it = cluster.kmeans_centroids(x, 12, 100, 43, assign_fn=_np_assign, update_fn=_np_update, return_n_iter=True)
     assert it == km.n_iter_
     assert np.abs(c - km.cluster_centers_).max() <= 1e-6
+
+
+_SURFACE = {"ibl.evaluators": "ibl/evaluators.py", "ibl.pca": "ibl/pca.py", "ibl.models": "ibl/models/__init__.py",
+            "ibl.models.vgg": "ibl/models/vgg.py", "ibl.models.netvlad": "ibl/models/netvlad.py",
+            "ibl.utils": "ibl/utils/__init__.py", "ibl.utils.data": "ibl/utils/data/__init__.py",
+            "ibl.utils.data.sampler": "ibl/utils/data/sampler.py",
+            "ibl.utils.data.preprocessor": "ibl/utils/data/preprocessor.py",
+            "ibl.utils.data.dataset": "ibl/utils/data/dataset.py",
+            "ibl.utils.serialization": "ibl/utils/serialization.py", "ibl.utils.dist_utils": "ibl/utils/dist_utils.py",
+            "ibl.utils.meters": "ibl/utils/meters.py", "ibl.utils.osutils": "ibl/utils/osutils.py",
+            "ibl.utils.logging": "ibl/utils/logging.py", "ibl.utils.rerank": "ibl/utils/rerank.py",
+            "ibl.datasets": "ibl/datasets/__init__.py", "hubconf": "hubconf.py"}
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/ibl"),
+                    reason="the reference tree is only present in the build container")
+def test_public_surface_of_the_reference_is_present():
+    """Every public function / class (and public method, and parameter name) the reference defines in
+    the modules of its inference-side package — everything but `ibl.trainers` — exists here under the
+    same name: read from the reference's sources with `ast` (nothing of it is imported or executed)."""
+    import ast
+    import importlib
+    import inspect
+    import os
+    problems = []
+    for mod, rel in _SURFACE.items():
+        tree = ast.parse(open(os.path.join("/root/reference", rel)).read())
+        ours = importlib.import_module(mod)
+        for node in tree.body:
+            if not isinstance(node, (ast.FunctionDef, ast.ClassDef)) or node.name.startswith("_"):
+                continue
+            if not hasattr(ours, node.name):
+                problems.append(f"{mod}.{node.name} missing")
+                continue
+            obj = getattr(ours, node.name)
+            items = [(node.name, node, obj)] if isinstance(node, ast.FunctionDef) else \
+                [(f"{node.name}.{m.name}", m, getattr(obj, m.name, None)) for m in node.body
+                 if isinstance(m, ast.FunctionDef) and (not m.name.startswith("_") or m.name == "__init__")]
+            for label, fn, target in items:
+                if target is None:
+                    problems.append(f"{mod}.{label} missing")
+                    continue
+                try:
+                    have = set(inspect.signature(target).parameters)
+                except (TypeError, ValueError):
+                    continue
+                lacking = {a.arg for a in fn.args.args} - have - {"self"}
+                if lacking and "kwargs" not in have:
+                    problems.append(f"{mod}.{label} lacks parameters {sorted(lacking)}")
+    assert not problems, "\n".join(problems)
