@@ -135,3 +135,15 @@ def test_oracle_is_not_imported_by_the_product():
                     bad.append(str(f))
     hub = ast.parse((ROOT / "hubconf.py").read_text())
     assert not bad, bad
+
+
+def test_every_entry_point_is_documented_for_binders():
+    """INTEGRATION.md names every function include/openibl_amd.h declares."""
+    import re
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    header = re.sub(r"/\*.*?\*/", "", (root / "include" / "openibl_amd.h").read_text(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(oibl_[a-z0-9_]+)\s*\(", header)))
+    doc = (root / "INTEGRATION.md").read_text()
+    assert len(names) >= 49
+    assert not [n for n in names if n not in doc]
