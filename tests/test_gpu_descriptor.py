@@ -216,3 +216,29 @@ def test_split_k_small_batches(model, dev, precision, tol, N, H, W):
         with torch.no_grad():
             want = od.embednetpca(x, synth.embednetpca_state(0))
         assert_rel_l2(f"split-K vs oracle {precision}", b, want, TOL_FP32)
+
+
+def test_embedregionnet_eval_branch_is_the_embednet_forward(dev, state_dict):
+    """EmbedRegionNet.forward in eval mode (ibl/models/netvlad.py:196-205) returns (pool_x, normalised
+    VLAD) exactly like EmbedNet.forward — against the reference's vectors and bit for bit against
+    EmbedNet here; its SFRS training branch is out of scope and says so."""
+    from ibl import models
+    g = load_golden("desc_small")
+    base = models.create("vgg16", pretrained=False)
+    pool = models.create("netvlad", dim=base.feature_dim)
+    region = models.create("embedregionnet", base, pool, tuple_size=1)
+    plain = models.create("embednet", base, pool)
+    sd = {k: v for k, v in state_dict.items() if not k.startswith("pca_layer")}
+    region.load_state_dict(sd)
+    region = region.to(dev).eval().set_precision("fp32")
+    plain = plain.to(dev).eval().set_precision("fp32")
+    n, _, h, w = [int(v) for v in g["shape"]]
+    x = synth.images(n, h, w, seed=int(g["image_seed"])).to(dev)
+    pool_x, vlad = region(x)
+    p2, v2 = plain(x)
+    assert torch.equal(pool_x, p2) and torch.equal(vlad, v2)
+    assert_rel_l2("EmbedRegionNet eval vlad", vlad.cpu(), g["vlad_norm"], 1e-4)
+    assert_rel_l2("EmbedRegionNet eval pool_x", pool_x.cpu(), g["pool_x"], 1e-4)
+    region.train()
+    with pytest.raises(NotImplementedError):
+        region(x)
