@@ -8,6 +8,7 @@ but travels to the GPU box with the repo snapshot.
 from __future__ import annotations
 
 import hashlib
+import json
 import os
 import shutil
 import subprocess
@@ -82,6 +83,32 @@ def build(force: bool = False, verbose: bool = True) -> Path:
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
+def _parse_resource_usage(text: str) -> dict:
+    """{mangled kernel name: {"VGPRs": n, "AGPRs": n, "ScratchSize": bytes per lane, "LDS": bytes,
+    "Occupancy": waves per SIMD, "SGPRs": n}} from hipcc's kernel-resource-usage remarks."""
+    import re
+    out, cur = {}, None
+    for line in text.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+(VGPRs|AGPRs|SGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|"
+                      r"LDS Size \[bytes/block\]): (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).split(" ")[0]] = int(m.group(2))
+    return out
+
+
+def resource_usage() -> dict:
+    """The report of the current build (builds first if the library is stale)."""
+    build(verbose=False)
+    p = BUILD_DIR / "resource_usage.json"
+    if not p.exists():
+        build(force=True, verbose=False)
+    return json.loads(p.read_text())
+
+
 def _build_locked(verbose: bool) -> Path:
     hipcc = _hipcc()
     srcs = sources()
@@ -89,7 +116,9 @@ def _build_locked(verbose: bool) -> Path:
 
     def compile_one(pair):
         src, obj = pair
-        cmd = [hipcc, *CXXFLAGS, "-c", str(src), "-o", str(obj)]
+        # -Rpass-analysis: the compiler's per-kernel register / scratch / LDS report, kept next to the
+        # objects (build/resource_usage.json; tests/test_abi.py holds the hot kernels to their budgets)
+        cmd = [hipcc, *CXXFLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", str(src), "-o", str(obj)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src.name}:\n{r.stdout}\n{r.stderr}")
@@ -98,7 +127,8 @@ def _build_locked(verbose: bool) -> Path:
         return r.stderr
 
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        list(ex.map(compile_one, zip(srcs, objs)))
+        remarks = list(ex.map(compile_one, zip(srcs, objs)))
+    (BUILD_DIR / "resource_usage.json").write_text(json.dumps(_parse_resource_usage("\n".join(remarks)), indent=1))
 
     tmp = LIB_PATH.with_name(LIB_PATH.name + f".tmp{os.getpid()}")
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fno-gpu-rdc",

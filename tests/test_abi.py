@@ -147,3 +147,34 @@ def test_every_entry_point_is_documented_for_binders():
     doc = (root / "INTEGRATION.md").read_text()
     assert len(names) >= 49
     assert not [n for n in names if n not in doc]
+
+
+def test_hot_kernels_stay_inside_their_register_budgets():
+    """The compiler's per-kernel report of the current build (hipcc -Rpass-analysis=kernel-resource-usage,
+    kept by openibl_amd.build): the kernels of the default path do not spill — ring convolutions and
+    distances (2 waves per SIMD: <= 256 VGPRs), the bf16 stems, every LDS-DMA instantiation of the
+    generic core — and the bf16x3 stem fits 16 waves per workgroup (<= 128 VGPRs; the 12 bytes of
+    scratch it has are two values parked across the whole kernel, outside its loops).  The
+    register-staging variants behind the test hook (GLDS = false) index staged registers and do spill;
+    they are not on any default path."""
+    import re
+    from openibl_amd import build
+    usage = build.resource_usage()
+    assert len(usage) > 100
+    seen = set()
+    for name, u in usage.items():
+        scratch, vgprs = u.get("ScratchSize", 0), u.get("VGPRs", 0) + u.get("AGPRs", 0)
+        if "conv3x3_ring_kernel" in name or "pairwise_ring_kernel" in name or "vgg_stem_kernel" in name:
+            assert scratch == 0 and vgprs <= 256, (name, u)
+            seen.add(re.sub(r"I.*", "", name))
+        elif "vgg_stem_x3_kernel" in name:
+            assert u["VGPRs"] <= 128 and u.get("AGPRs", 0) == 0 and scratch <= 16, (name, u)
+            seen.add("x3stem")
+        elif "conv3x3_igemm_kernel" in name:
+            glds = re.search(r"ELb([01])ELb([01])ELb([01])EEE", name).group(2)
+            if glds == "1":
+                assert scratch == 0, (name, u)
+        elif any(k in name for k in ("pairwise_kernel", "gemm_nt_kernel", "netvlad_assign_kernel", "pca_partial_kernel")):
+            if re.search(r"ELb1EEE", name):
+                assert scratch == 0, (name, u)
+    assert len(seen) >= 4
