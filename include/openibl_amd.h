@@ -26,8 +26,17 @@
  *                   (~2^-17 relative per product: fp32-class descriptors at 3x the bf16 MFMA work
  *                   instead of 16x).  Element = 4 bytes; a row of C elements (C % 32 == 0) is stored
  *                   as C/32 groups of [32 x hi | 32 x lo] (128 bytes), see oibl_x3_split_rows.
+ *       OIBL_F16MX : fp16 main term + MX-fp6 cross terms — every operand travels as hi = fp16(v)
+ *                   plus block-scaled e2m3 images of hi and of lo = v - hi (one e8m0 scale per 32
+ *                   elements); a product is hi.hi on v_mfma_f32_32x32x16_f16 plus
+ *                   q6(hi).q6(lo) + q6(lo).q6(hi) on ONE v_mfma_scale_f32_32x32x64_f8f6f4 (the two
+ *                   cross terms concatenated along K), fp32 accumulate: ~2^-15 relative per product —
+ *                   inside north_star's 1e-4 on the descriptor — at HALF the matrix-pipe time of
+ *                   OIBL_BF16X3.  Element = 4 bytes; a row of C elements (C % 32 == 0) is C/32 lines
+ *                   of 128 bytes: [32 x fp16 | q6(hi) 16 B | q6(lo) 16 B | q6(hi) 8 B, scale, pad |
+ *                   q6(lo) 8 B, scale, pad], see oibl_mx_split_rows.
  *     and with it the element type of activation / packed-weight buffers ("T" below:
- *     uint16 bf16 bits, float, or the 4-byte split pair).
+ *     uint16 bf16 bits, float, or the 4-byte split element).
  */
 #ifndef OPENIBL_AMD_H
 #define OPENIBL_AMD_H
@@ -48,6 +57,7 @@ extern "C" {
 #define OIBL_BF16 0
 #define OIBL_F32 1
 #define OIBL_BF16X3 2
+#define OIBL_F16MX 3
 
 /* Storage type of a descriptor matrix handed to the *_st matching entry points. */
 #define OIBL_ST_F32 0
@@ -82,6 +92,11 @@ int oibl_cast_f16_to_f32(const uint16_t* src, float* dst, size_t n, void* stream
  * the activation / operand layout of the OIBL_BF16X3 kernels.  join returns hi + lo (exact). */
 int oibl_x3_split_rows(const float* src, void* dst, size_t rows, int C, void* stream);
 int oibl_x3_join_rows(const void* src, float* dst, size_t rows, int C, void* stream);
+/* fp32 rows [rows][C] <-> OIBL_F16MX rows (C/32 lines of 128 bytes per row; C % 32 == 0).  join
+ * returns what the kernels see of every element: which = 0: hi + q6(lo) (the stored value to ~2^-15
+ * of the line's largest element), 1: hi (fp16, exact), 2: q6(hi), 3: q6(lo). */
+int oibl_mx_split_rows(const float* src, void* dst, size_t rows, int C, void* stream);
+int oibl_mx_join_rows(const void* src, float* dst, size_t rows, int C, int which, void* stream);
 
 /* ---- bilinear resize --------------------------------------------------------------- *
  * x [N][C][H][W] fp32 -> out [N][C][H2][W2] fp32 with the arithmetic of
@@ -174,6 +189,8 @@ int oibl_vgg16_stem_x3(const float* x_nchw, int N, int H, int W, const float* w1
  * oibl_pack_conv3x3_weights; bias entries are [Cout] fp32.
  * OIBL_BF16X3: activations between the layers are (hi, lo) split elements, but `feat` is written as
  * plain fp32 (the head consumes it with OIBL_F32).
+ * OIBL_F16MX: entry 1 (conv1_2) is packed with OIBL_BF16X3 — conv1_1 + conv1_2 + pool run in split
+ * bf16 (K = 27 and Cout = 64 fit no MX tile) — entries 2..12 with OIBL_F16MX; `feat` is plain fp32.
  * The workspace holds the two ping-pong activation buffers and, for small batches, the fp32
  * partial tiles of the layers that run split-K (a layer whose 128-row tiling gives <= 192 tiles is
  * contracted by 2-8 workgroups per tile and reduced in a fixed order: deterministic, equal to

@@ -259,7 +259,8 @@ int oibl_abi_version(void) { return 2; }
 const char* oibl_last_error(void) { return g_err; }
 const char* oibl_target_arch(void) { return "gfx950"; }
 size_t oibl_elem_size(int precision) {
-  return precision == OIBL_BF16 ? 2 : (precision == OIBL_F32 || precision == OIBL_BF16X3) ? 4 : 0;
+  return precision == OIBL_BF16 ? 2
+         : (precision == OIBL_F32 || precision == OIBL_BF16X3 || precision == OIBL_F16MX) ? 4 : 0;
 }
 
 int oibl_cast_f32_to_bf16(const float* src, uint16_t* dst, size_t n, void* stream) {

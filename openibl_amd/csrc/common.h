@@ -136,6 +136,105 @@ __device__ static inline float x3_load(const void* row, size_t c) {
   return bf16_bits_to_f32(p[0]) + bf16_bits_to_f32(p[32]);
 }
 
+// f16mx (OIBL_F16MX): a value v travels as hi = fp16(v) plus MX-fp6 (e2m3, one e8m0 scale per 32
+// elements) images of hi and of lo = v - hi, and a product is evaluated as
+//     a.b ~= hi(a).hi(b)                        2 x v_mfma_f32_32x32x16_f16 per 32 K
+//          + q6(hi(a)).q6(lo(b)) + q6(lo(a)).q6(hi(b))   1 x v_mfma_scale_f32_32x32x64_f8f6f4 (K = 64:
+//                                                the two cross terms concatenated along K)
+// with fp32 accumulation.  The cross terms are 2^-11 of the product and carry 4 significant bits, the
+// dropped lo.lo term is 2^-22: ~2^-15 relative per product (tools/f16mx_numerics.py: 3.9e-5 on the
+// conv5_3 map after 13 layers against fp64; bf16x3 1.5e-5, plain bf16 8e-3).  Half the matrix-pipe
+// time of bf16x3 per product (96 instead of 192 cycles per 32x32x32 block; 1.77x measured under the
+// power cap, profiles/r03_a_mx_probe.txt).
+// Storage: rows of elements in groups of 32 = one 128-byte line = one K-step of the GEMM cores:
+//   bytes   0.. 63  hi[0:32] fp16                       (k-chunks 0, 1: the two f16 MFMAs)
+//   bytes  64.. 79  first 16 bytes of q6(hi)            (slot 4)
+//   bytes  80.. 95  first 16 bytes of q6(lo)            (slot 5)
+//   bytes  96..111  last 8 bytes of q6(hi) | scale byte of q6(hi) | 7 x 0     (slot 6)
+//   bytes 112..127  last 8 bytes of q6(lo) | scale byte of q6(lo) | 7 x 0     (slot 7)
+// q6 = 32 x e2m3 packed 6 bits each (element e at bits 6e..6e+5, the order of
+// v_cvt_scalef32_pk32_fp6_f16), value = code * 2^(scale byte - 127).  A lane of the MX instruction
+// holds one row's 32 K elements of one 32-block (lanes 0-31: block 0, lanes 32-63: block 1): the A
+// side reads slots (4, 6) in its lower half and (5, 7) in its upper half — K = [q6(hi) | q6(lo)] —
+// the B side the other way round — K = [q6(lo) | q6(hi)] — so ONE stored format serves both operands.
+// The struct is only a tag (sizeof = 4 bytes per element).
+struct f16mx_t {
+  uint16_t a, b;
+};
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+
+// scale byte (e8m0) of a block whose largest |hi| is amax: the smallest power of two s with
+// amax / s <= 7.5 (the e2m3 maximum), never below 12 so that the byte of the lo block (11 less:
+// |lo| <= 2^-11 |hi| elementwise) stays a valid exponent
+__host__ __device__ static inline int mx_scale_byte(float amax) {
+  const uint32_t bits = __builtin_bit_cast(uint32_t, amax);
+  const int b = (int)((bits + 0x00100000u) >> 23) - 2;   // + 1 when the mantissa is >= 1.875
+  return b < 12 ? 12 : (b > 254 ? 254 : b);
+}
+
+// 32 fp32 values (one pixel's / row's 32-element group) -> the 128-byte f16mx line
+__device__ static inline void mx_pack_line(const float (&v)[32], uint4 (&out)[8]) {
+#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass only needs the declaration)
+  typedef __attribute__((ext_vector_type(2))) float f2;
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  typedef __attribute__((ext_vector_type(32))) _Float16 h32;
+  typedef __attribute__((ext_vector_type(6))) unsigned u6;
+  h32 h;
+  f32x16_t le, lo;   // remainders of the even / odd elements (the fp32 convert interleaves its inputs)
+  float amax = 0.f;
+#pragma unroll
+  for (int e = 0; e < 32; e += 2) {
+    const float c0 = __builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
+    const float c1 = __builtin_amdgcn_fmed3f(v[e + 1], -65504.f, 65504.f);
+    const h2 p = __builtin_convertvector((f2){c0, c1}, h2);
+    h[e] = p[0];
+    h[e + 1] = p[1];
+    const float h0 = (float)p[0], h1 = (float)p[1];
+    le[e >> 1] = v[e] - h0;
+    lo[e >> 1] = v[e + 1] - h1;
+    amax = fmaxf(amax, fmaxf(__builtin_fabsf(h0), __builtin_fabsf(h1)));
+  }
+  const int bh = mx_scale_byte(amax), bl = bh - 11;
+  const u6 h6 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(h, __builtin_bit_cast(float, (uint32_t)bh << 23));
+  const u6 l6 = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(le, lo, __builtin_bit_cast(float, (uint32_t)bl << 23));
+  typedef __attribute__((ext_vector_type(4))) unsigned u4;
+  typedef __attribute__((ext_vector_type(16))) unsigned u16v;
+  const u16v hw = __builtin_bit_cast(u16v, h);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) out[s] = make_uint4(hw[4 * s], hw[4 * s + 1], hw[4 * s + 2], hw[4 * s + 3]);
+  out[4] = make_uint4(h6[0], h6[1], h6[2], h6[3]);
+  out[5] = make_uint4(l6[0], l6[1], l6[2], l6[3]);
+  out[6] = make_uint4(h6[4], h6[5], (unsigned)bh, 0u);
+  out[7] = make_uint4(l6[4], l6[5], (unsigned)bl, 0u);
+#endif
+}
+
+// value of e2m3 code c (sign, 2 exponent bits, 3 mantissa bits; bias 1)
+__host__ __device__ static inline float mx_e2m3_value(unsigned c) {
+  const int e = (c >> 3) & 3, m = c & 7;
+  const float v = e == 0 ? (float)m * 0.125f : (1.0f + (float)m * 0.125f) * (float)(1 << (e - 1));
+  return (c & 32) ? -v : v;
+}
+// element c (0..31) of a stored line as the kernels see it: hi (exact fp16) and the two fp6 images
+__host__ __device__ static inline void mx_line_decode(const void* line, int c, float& hi, float& hi6, float& lo6) {
+  const unsigned char* b = static_cast<const unsigned char*>(line);
+  hi = f16_bits_to_f32((uint16_t)(b[2 * c] | (b[2 * c + 1] << 8)));
+  const int bit = 6 * c;
+  auto code = [&](int first, int last) {   // the 24 packed bytes are split 16 + 8 over two slots
+    unsigned long long w = 0;
+    const int byte0 = bit >> 3;
+    for (int k = 0; k < 2; ++k) {
+      const int by = byte0 + k;
+      if (by < 24) w |= (unsigned long long)b[by < 16 ? first + by : last + by - 16] << (8 * k);
+    }
+    return (unsigned)(w >> (bit & 7)) & 63u;
+  };
+  const float sh = __builtin_ldexpf(1.0f, (int)b[104] - 127), sl = __builtin_ldexpf(1.0f, (int)b[120] - 127);
+  hi6 = mx_e2m3_value(code(64, 96)) * sh;
+  lo6 = mx_e2m3_value(code(80, 112)) * sl;
+}
+
 template <typename T>
 struct Elem;
 template <>

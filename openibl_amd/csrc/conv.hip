@@ -45,6 +45,80 @@ __global__ void x3_join_rows_kernel(const char* __restrict__ src, float* __restr
   }
 }
 
+// ---- f16mx (common.h) ------------------------------------------------------------------------
+// weights: one thread per (tap, cout, 32-channel group) line of the packed tensor [tap][Cout][Cin]
+__global__ void pack_conv3x3_mx_kernel(const float* __restrict__ w, char* __restrict__ packed, int cout,
+                                       int cin) {
+  const int groups = cin >> 5;
+  const size_t total = (size_t)9 * cout * groups;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i % groups);
+    const size_t t = i / groups;
+    const int co = (int)(t % cout);
+    const int tap = (int)(t / cout);
+    float v[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) v[e] = w[((size_t)co * cin + g * 32 + e) * 9 + tap];
+    uint4 line[8];
+    mx_pack_line(v, line);
+    uint4* dst = reinterpret_cast<uint4*>(packed + i * 128);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dst[k] = line[k];
+  }
+}
+// rows: SRC = 0 fp32 rows [rows][C] -> f16mx lines; SRC = 1 bf16x3 lines -> f16mx lines (may be in
+// place: a thread reads its whole line before it writes it).  One thread per line.
+template <int SRC>
+__global__ void mx_pack_rows_kernel(const char* __restrict__ src, char* __restrict__ dst, size_t lines) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < lines;
+       i += (size_t)gridDim.x * blockDim.x) {
+    float v[32];
+    const uint4* sp = reinterpret_cast<const uint4*>(src + i * 128);
+    if constexpr (SRC == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const uint4 t = sp[k];
+        v[4 * k] = __builtin_bit_cast(float, t.x);
+        v[4 * k + 1] = __builtin_bit_cast(float, t.y);
+        v[4 * k + 2] = __builtin_bit_cast(float, t.z);
+        v[4 * k + 3] = __builtin_bit_cast(float, t.w);
+      }
+    } else {
+      uint4 hi[4], lo[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        hi[k] = sp[k];
+        lo[k] = sp[4 + k];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned h[4] = {hi[k].x, hi[k].y, hi[k].z, hi[k].w}, l[4] = {lo[k].x, lo[k].y, lo[k].z, lo[k].w};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          v[8 * k + 2 * d] = __builtin_bit_cast(float, h[d] << 16) + __builtin_bit_cast(float, l[d] << 16);
+          v[8 * k + 2 * d + 1] = __builtin_bit_cast(float, h[d] & 0xffff0000u) + __builtin_bit_cast(float, l[d] & 0xffff0000u);
+        }
+      }
+    }
+    uint4 line[8];
+    mx_pack_line(v, line);
+    uint4* dp = reinterpret_cast<uint4*>(dst + i * 128);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dp[k] = line[k];
+  }
+}
+// f16mx lines -> fp32 rows as the kernels see the values: WHICH = 0 hi + q6(lo) (the stored value to
+// ~2^-15), 1 hi alone, 2 q6(hi), 3 q6(lo)   (tests)
+__global__ void mx_join_rows_kernel(const char* __restrict__ src, float* __restrict__ dst, size_t n, int which) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    float hi, hi6, lo6;
+    mx_line_decode(src + (i >> 5) * 128, (int)(i & 31), hi, hi6, lo6);
+    dst[i] = which == 0 ? hi + lo6 : which == 1 ? hi : which == 2 ? hi6 : lo6;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // conv1_1: x [N][3][H][W] fp32 -> out [N][H][W][64] T.   Cin = 3 gives K = 27: no MFMA shape fits
 // without an explicit im2col pass, and the layer is 0.56 % of the backbone FLOPs, so it runs on
@@ -601,16 +675,17 @@ static int g_ring_raster = 0;                     // test hook: xcd_tile() mode 
 static int g_conv_korder = -1;
 static int conv_korder_for(int precision, int cin, int cout) {
   if (g_conv_korder >= 0) return g_conv_korder;
-  return precision == OIBL_BF16X3 && cin == 128 && cout == 128 ? 1 : 0;
+  return (precision == OIBL_BF16X3 || precision == OIBL_F16MX) && cin == 128 && cout == 128 ? 1 : 0;
 }
 static unsigned long long* g_prof_buf = nullptr;  // test hook: phase profile of block 0
 static int g_ring_ablate = 0;                     // test hook: see RingParams::ablate
 
 // ring-schedule kernel (conv_ring.h): bf16, Cin % 64 == 0; WM = 2: 256 x 256 tile (Cout % 256 == 0),
 // WM = 4: 512 x 128 tile (Cout % 128 == 0)
-template <int WM, bool POOL, bool ODD, bool X3 = false>
+template <int WM, bool POOL, bool ODD, int P = RING_BF16>
 static int launch_conv_ring_impl(const ConvParams& p, hipStream_t st) {
   using G = RingGeo<WM>;
+  constexpr bool X3 = P != RING_BF16;  // 4-byte elements
   RingParams q;
   q.in = p.in;
   q.w = p.w;
@@ -640,22 +715,22 @@ static int launch_conv_ring_impl(const ConvParams& p, hipStream_t st) {
   q.tiles_m = (int)tiles_m;
   q.raster = g_ring_raster;
   q.korder = p.korder;
-  constexpr int lds = ring_lds_bytes<WM, POOL, X3>();
-  auto kern = conv3x3_ring_kernel<WM, POOL, ODD, X3>;
+  constexpr int lds = ring_lds_bytes<WM, POOL, P>();
+  auto kern = conv3x3_ring_kernel<WM, POOL, ODD, P>;
   OIBL_SET_MAX_LDS(kern, lds);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, q);
   OIBL_LAUNCH_CHECK();
   return OIBL_OK;
 }
 
-template <int WM, bool POOL, bool X3 = false>
+template <int WM, bool POOL, int P = RING_BF16>
 static int launch_conv_ring(const ConvParams& p, hipStream_t st) {
-  // an odd number of K-tiles happens only for Cin = 64 in bf16 (bf16x3 has twice the K-tiles),
-  // which only the 512 x 128 variant serves
-  if constexpr (WM == 4 && !X3) {
+  // an odd number of K-tiles happens only for Cin = 64 in bf16 (the 4-byte element types have twice
+  // the K-tiles), which only the 512 x 128 variant serves
+  if constexpr (WM == 4 && P == RING_BF16) {
     if ((9 * (p.cin / 64)) & 1) return launch_conv_ring_impl<WM, POOL, true>(p, st);
   }
-  return launch_conv_ring_impl<WM, POOL, false, X3>(p, st);
+  return launch_conv_ring_impl<WM, POOL, false, P>(p, st);
 }
 
 // 0 = not eligible, else the wave-row count of the instantiation to use (es = bytes per element)
@@ -703,8 +778,8 @@ static int launch_conv(const ConvParams& p, int pool, hipStream_t st) {
     int mode = g_conv_tile;
     if (rv && (mode == 4 || (mode == 0 && ring_tiles >= g_ring_min_tiles))) {
       if (rv == 2)
-        return pool ? launch_conv_ring<2, true, true>(p, st) : launch_conv_ring<2, false, true>(p, st);
-      return pool ? launch_conv_ring<4, true, true>(p, st) : launch_conv_ring<4, false, true>(p, st);
+        return pool ? launch_conv_ring<2, true, RING_X3>(p, st) : launch_conv_ring<2, false, RING_X3>(p, st);
+      return pool ? launch_conv_ring<4, true, RING_X3>(p, st) : launch_conv_ring<4, false, RING_X3>(p, st);
     }
     if (mode == 4) mode = 0;
     // (the 512 x 64 tile — 64 x 64 per wave — is kept behind the hook: 2.73 ms vs 2.48 ms for the
@@ -744,6 +819,30 @@ static int launch_conv(const ConvParams& p, int pool, hipStream_t st) {
   if (p.cout % 128 == 0) { OIBL_CONV_DISPATCH(C128x128); }
   OIBL_CONV_DISPATCH(C128x64);
 #undef OIBL_CONV_DISPATCH
+}
+
+// f16mx: the ring kernels are the only implementation (Cin % 64 == 0, Cout % 128 == 0 — every layer
+// of the backbone behind the stem)
+static int g_mx_variant = 0;  // test hook: 1 = LDS-DMA issue in the LOAD segment (RING_MX_EARLY)
+static int launch_conv_mx(const ConvParams& p, int pool, hipStream_t st) {
+  const int rv = (pool && p.out_f32) ? 0 : ring_variant(p, 4);
+  if (g_mx_variant == 1) {
+    if (rv == 2) return pool ? launch_conv_ring<2, true, RING_MX_EARLY>(p, st) : launch_conv_ring<2, false, RING_MX_EARLY>(p, st);
+    if (rv == 4) return pool ? launch_conv_ring<4, true, RING_MX_EARLY>(p, st) : launch_conv_ring<4, false, RING_MX_EARLY>(p, st);
+  }
+  if (g_mx_variant >= 4 && g_mx_variant <= 7 && rv == 2 && !pool) {   // timing experiments (wrong results)
+    switch (g_mx_variant) {
+      case 4: return launch_conv_ring<2, false, RING_MX_NOMFMA>(p, st);
+      case 5: return launch_conv_ring<2, false, RING_MX_NODMA>(p, st);
+      case 6: return launch_conv_ring<2, false, RING_MX_NOREAD>(p, st);
+      default: return launch_conv_ring<2, false, RING_MX_NOBAR>(p, st);
+    }
+  }
+  if (rv == 2) return pool ? launch_conv_ring<2, true, RING_MX>(p, st) : launch_conv_ring<2, false, RING_MX>(p, st);
+  if (rv == 4) return pool ? launch_conv_ring<4, true, RING_MX>(p, st) : launch_conv_ring<4, false, RING_MX>(p, st);
+  set_error("conv3x3 (f16mx): unsupported layer cin=%d cout=%d (needs Cin %% 64 == 0, Cout %% 128 == 0)", p.cin,
+            p.cout);
+  return OIBL_E_UNSUPPORTED;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2057,7 +2156,7 @@ static const VggLayer kVgg[OIBL_VGG16_NUM_CONV] = {
     {512, 512, 1, 0}, {512, 512, 1, 0}, {512, 512, 0, 0}};
 
 static bool precision_ok(int precision) {
-  return precision == OIBL_BF16 || precision == OIBL_F32 || precision == OIBL_BF16X3;
+  return precision == OIBL_BF16 || precision == OIBL_F32 || precision == OIBL_BF16X3 || precision == OIBL_F16MX;
 }
 
 // out_f32 (bf16x3 only): write the output as plain fp32 NHWC
@@ -2066,6 +2165,7 @@ static int g_conv_splitk = 1;  // test hook: 0 = never split K
 // splitk_ws (optional): scratch for the split-K partials of layers with too few tiles
 // (conv_splitk_bytes); without it every layer runs one-pass
 static size_t conv_splitk_bytes(long m_total, int cin, int cout, int precision) {
+  if (precision == OIBL_F16MX) return 0;  // one-pass ring kernels only
   const int steps = 9 * (cin / (precision == OIBL_BF16 ? 64 : 32));
   const int s = conv_splitk_factor(m_total, cout, steps);
   return s ? align_up((size_t)s * m_total * cout * sizeof(float), 256) : 0;
@@ -2103,7 +2203,7 @@ static int conv3x3_impl(const void* in, int N, int H, int W, int cin, const void
   p.cout = cout;
   p.relu = relu;
   p.ablate = g_conv_ablate;
-  p.out_f32 = precision == OIBL_BF16X3 ? out_f32 : 0;
+  p.out_f32 = (precision == OIBL_BF16X3 || precision == OIBL_F16MX) ? out_f32 : 0;
   p.korder = conv_korder_for(precision, cin, cout);
   p.tiles_n = 0;
   if (pool) {
@@ -2115,8 +2215,9 @@ static int conv3x3_impl(const void* in, int N, int H, int W, int cin, const void
   }
   p.ksplit = 0;
   p.partial = (float*)splitk_ws;
-  if (splitk_ws && g_conv_splitk)
+  if (splitk_ws && g_conv_splitk && precision != OIBL_F16MX)
     p.ksplit = conv_splitk_factor(p.m_total, cout, 9 * (cin / bk));
+  if (precision == OIBL_F16MX) return launch_conv_mx(p, pool, st);
   if (precision == OIBL_BF16X3) return launch_conv<bf16x3_t>(p, pool, st);
   return precision == OIBL_BF16 ? launch_conv<bf16_t>(p, pool, st) : launch_conv<float>(p, pool, st);
 }
@@ -2184,6 +2285,11 @@ int oibl_debug_set_conv_splitk(int on) {
   return OIBL_OK;
 }
 
+int oibl_debug_set_mx_variant(int v) {
+  g_mx_variant = v;
+  return OIBL_OK;
+}
+
 int oibl_debug_set_conv_korder(int mode) {
   g_conv_korder = mode < 0 ? -1 : (mode ? 1 : 0);
   return OIBL_OK;
@@ -2213,11 +2319,16 @@ int oibl_pack_conv3x3_weights(const float* w_oihw, int cout, int cin, int precis
   OIBL_REQUIRE(w_oihw && packed, "pack_conv3x3_weights: null pointer");
   OIBL_REQUIRE(cout > 0 && cin > 0, "pack_conv3x3_weights: bad shape");
   OIBL_REQUIRE(precision_ok(precision), "pack_conv3x3_weights: bad precision %d", precision);
-  OIBL_REQUIRE(precision != OIBL_BF16X3 || cin % 32 == 0, "pack_conv3x3_weights: bf16x3 needs Cin %% 32 == 0");
+  OIBL_REQUIRE((precision != OIBL_BF16X3 && precision != OIBL_F16MX) || cin % 32 == 0,
+               "pack_conv3x3_weights: bf16x3 / f16mx need Cin %% 32 == 0");
   const size_t total = (size_t)9 * cout * cin;
   unsigned blocks = (unsigned)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
-  if (precision == OIBL_BF16)
+  if (precision == OIBL_F16MX) {
+    unsigned b = (unsigned)((total / 32 + 127) / 128);
+    hipLaunchKernelGGL(pack_conv3x3_mx_kernel, dim3(b > 8192 ? 8192 : b), dim3(128), 0, (hipStream_t)stream, w_oihw,
+                       (char*)packed, cout, cin);
+  } else if (precision == OIBL_BF16)
     hipLaunchKernelGGL(pack_conv3x3_kernel<bf16_t>, dim3(blocks), dim3(256), 0,
                        (hipStream_t)stream, w_oihw, (bf16_t*)packed, cout, cin);
   else if (precision == OIBL_BF16X3)
@@ -2405,7 +2516,8 @@ static int vgg_forward_impl(const void* x, int u8, const float* mean3, const flo
     OIBL_LAUNCH_CHECK();
     x_f32 = stage;
   }
-  const bool fused3 = precision == OIBL_BF16X3 && g_stem_fused && stem_eligible(N, H, W) && !g_regstage &&
+  const bool mx = precision == OIBL_F16MX;
+  const bool fused3 = (precision == OIBL_BF16X3 || mx) && g_stem_fused && stem_eligible(N, H, W) && !g_regstage &&
                       !g_conv_ablate && g_conv_tile == 0;
   if (fused3) {
     // bf16x3: conv1_1 + conv1_2 + pool in one launch (the uint8 entry has normalised into x_f32)
@@ -2430,10 +2542,28 @@ static int vgg_forward_impl(const void* x, int u8, const float* mean3, const flo
     cur = bufB;
     l0 = 2;
   } else {
-    rc = oibl_conv1_1_nchw(x_f32, N, H, W, (const float*)packed_w_host[0], bias_host[0], precision,
-                           bufA, stream);
+    rc = oibl_conv1_1_nchw(x_f32, N, H, W, (const float*)packed_w_host[0], bias_host[0],
+                           mx ? OIBL_BF16X3 : precision, bufA, stream);
     if (rc) return rc;
     if (ev_igemm_begin) OIBL_HIP_CHECK(hipEventRecord((hipEvent_t)ev_igemm_begin, st));
+    if (mx) {  // conv1_2 in bf16x3 as well (Cout = 64: no ring tile), see below
+      rc = conv3x3_impl(bufA, N, h, w, kVgg[1].cin, packed_w_host[1], bias_host[1], kVgg[1].cout, kVgg[1].relu,
+                        kVgg[1].pool, OIBL_BF16X3, bufB, st);
+      if (rc) return rc;
+      h /= 2;
+      w /= 2;
+      cur = bufB;
+      l0 = 2;
+    }
+  }
+  if (mx) {
+    // f16mx: conv1_1 + conv1_2 + pool run in bf16x3 (K = 27 and Cout = 64 fit no MX ring tile; 12.6 % of the
+    // FLOPs); the pooled map [N][H/2][W/2][64] is re-packed from (hi, lo) groups to f16mx lines in place
+    const size_t lines = (size_t)N * h * w * 2;
+    unsigned b = (unsigned)((lines + 255) / 256);
+    hipLaunchKernelGGL(mx_pack_rows_kernel<1>, dim3(b > 16384 ? 16384 : b), dim3(256), 0, st, (const char*)cur,
+                       (char*)cur, lines);
+    OIBL_LAUNCH_CHECK();
   }
   for (int l = l0; l < OIBL_VGG16_NUM_CONV; ++l) {
     void* dst = (l == OIBL_VGG16_NUM_CONV - 1) ? feat : (l % 2 == 0 ? (void*)bufA : (void*)bufB);
@@ -2483,6 +2613,30 @@ int oibl_x3_split_rows(const float* src, void* dst, size_t rows, int C, void* st
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(x3_split_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src,
                      (char*)dst, n, C);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
+
+int oibl_mx_split_rows(const float* src, void* dst, size_t rows, int C, void* stream) {
+  OIBL_REQUIRE(src && dst, "mx_split_rows: null pointer");
+  OIBL_REQUIRE(C > 0 && C % 32 == 0, "mx_split_rows: C %% 32 != 0");
+  if (rows == 0) return OIBL_OK;
+  const size_t lines = rows * (size_t)(C / 32);
+  unsigned b = (unsigned)((lines + 255) / 256);
+  hipLaunchKernelGGL(mx_pack_rows_kernel<0>, dim3(b > 16384 ? 16384 : b), dim3(256), 0, (hipStream_t)stream,
+                     (const char*)src, (char*)dst, lines);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
+
+int oibl_mx_join_rows(const void* src, float* dst, size_t rows, int C, int which, void* stream) {
+  OIBL_REQUIRE(src && dst, "mx_join_rows: null pointer");
+  OIBL_REQUIRE(C > 0 && C % 32 == 0 && which >= 0 && which <= 3, "mx_join_rows: bad arguments");
+  if (rows == 0) return OIBL_OK;
+  const size_t n = rows * (size_t)C;
+  unsigned b = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(mx_join_rows_kernel, dim3(b > 16384 ? 16384 : b), dim3(256), 0, (hipStream_t)stream,
+                     (const char*)src, dst, n, which);
   OIBL_LAUNCH_CHECK();
   return OIBL_OK;
 }

@@ -14,6 +14,10 @@
 // a K-tile is one such 128-byte group (32 real channels), so the loaders only see 4-byte elements;
 // the main loop runs 12 MFMAs per phase and the epilogue splits every output into its (hi, lo) pair
 // again — or, for the layer that feeds the fp32 head, stores plain fp32 (RingParams::out_f32).
+//
+// P = RING_MX: f16mx activations and weights (common.h) — the same 128-byte groups of 32 channels, so
+// the loaders are those of bf16x3; 6 MFMAs per phase; the epilogue stages the tile as fp32 and turns
+// every (pixel, 32-channel group) into its f16mx line (mx_pack_line) before the copy-out.
 #pragma once
 
 #include "ring_core.h"
@@ -57,11 +61,12 @@ __device__ static inline unsigned ring_div_u31(unsigned m, unsigned mul, unsigne
 }
 
 // epilogue staging: the output tile (X3 without pooling: one half of its rows at a time)
-template <int WM, bool POOL, bool X3 = false>
+template <int WM, bool POOL, int P = RING_BF16>
 constexpr int ring_lds_bytes() {
   using G = RingGeo<WM>;
-  constexpr int rows = POOL ? G::BM / 4 : (X3 ? G::BM / 2 : G::BM);
-  constexpr int epi = rows * (G::BN * (X3 ? 4 : 2) + 16);
+  constexpr bool E4 = P != RING_BF16;
+  constexpr int rows = POOL ? G::BM / 4 : (E4 ? G::BM / 2 : G::BM);
+  constexpr int epi = rows * (G::BN * (E4 ? 4 : 2) + (P >= RING_MX ? 0 : 16));
   return epi > G::MAIN_LDS ? epi : G::MAIN_LDS;
 }
 
@@ -221,10 +226,12 @@ __device__ static inline void ring_split4(float a0, float a1, float a2, float a3
   lo.y = __builtin_bit_cast(uint32_t, __builtin_convertvector((f2){r2, r3}, bf2));
 }
 
-template <int WM, bool POOL, bool ODD, bool X3 = false>
+template <int WM, bool POOL, bool ODD, int P = RING_BF16>
 __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
   using G = RingGeo<WM>;
   constexpr int NA = G::NA, NB = G::NB;
+  constexpr bool X3 = P != RING_BF16;   // 4-byte elements, 32 channels per K-tile (bf16x3 and f16mx)
+  constexpr bool MX = P >= RING_MX;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
   ConvRingALoader<NA, POOL, X3> la;
   ConvRingBLoader<NB, X3> lb;
   la.init(p, m0, rows_a, piece);
-  lb.init(p, n0, rows_b, piece);
+  lb.init(p, n0, rows_b, MX ? ring_piece_mxb(wave, lane) : piece);
 
   // The accumulators start at the bias (the fma chain of every output begins with it), laid out
   // like the results: natural layout = one channel per lane and column tile, transposed layout
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
   }
 
   const unsigned long long t_loop = prof ? __builtin_amdgcn_s_memtime() : 0;
-  ring_mainloop<WM, ODD, !POOL, X3>(acc, smem, wave, lane, la, lb, nsteps);
+  ring_mainloop<WM, ODD, !POOL, P>(acc, smem, wave, lane, la, lb, nsteps);
   // (the main loop ends on a workgroup barrier: the staging LDS is free for the epilogue)
   const unsigned long long t_epi = prof ? __builtin_amdgcn_s_memtime() : 0;
 
@@ -296,6 +303,117 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
   //      X3   : an output element is 4 bytes — the (hi, lo) pair at x3_off(channel) / + 64, or the
   //             fp32 value when out_f32 is set; without pooling the tile is staged in two passes of
   //             BM / 2 rows (accumulator row tiles {0, 1}, then {2, 3} of every wave).
+  if constexpr (MX) {
+    // ---- f16mx epilogue.  The tile (without pooling: one half of its rows at a time) is staged as
+    // fp32, rows of BN floats = CPR 16-byte chunks, chunk q of row r at physical chunk q ^ (r % CPR):
+    // the 8 chunks of a (row, 32-channel group) item stay inside one aligned 128-byte block, 16
+    // consecutive rows of one logical chunk fall on 16 distinct bank slots (the accumulator writes
+    // and the item reads walk rows), and a row's chunks read in order are a permutation of the row
+    // (the copy-out walks chunks).  Then one thread per item reads its 32 values, packs the f16mx
+    // line (mx_pack_line) and writes it back in place; the copy-out moves full lines.
+    // out_f32 (the layer feeding the fp32 head): no packing, the fp32 rows go out as they are.
+    constexpr int CPR = G::BN / 4;
+    constexpr int ROWB = G::BN * 4;
+    constexpr int PASSES = POOL ? 1 : 2;
+    constexpr int ROWS = (POOL ? G::BM / 4 : G::BM) / PASSES;
+    constexpr int ITEMS = ROWS * (G::BN / 32);
+    constexpr int ITERS = ROWS * CPR / 512, BATCH = 8;
+    static_assert(ITEMS % 512 == 0 && ITERS % BATCH == 0, "f16mx epilogue shape");
+    const long row0 = POOL ? (m0 >> 2) : m0;
+    char* obase = reinterpret_cast<char*>(p.out) + (long)n0 * 4;
+    const long orow_bytes = (long)p.cout * 4;
+    const float floor_v = p.relu ? 0.f : -INFINITY;
+    unsigned long long t_copy = 0;
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
+      if constexpr (POOL) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int col = wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const float v = fmaxf(fmaxf(fmaxf(acc[i][j][4 * g], acc[i][j][4 * g + 1]),
+                                          fmaxf(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3])), floor_v);
+              const int row = (wm * 4 + i) * 8 + 2 * g + (lane >> 5);
+              *reinterpret_cast<float*>(smem + row * ROWB + (((col >> 2) ^ (row & (CPR - 1))) << 4) + (col & 3) * 4) = v;
+            }
+        }
+      } else {
+        const int half = lane >> 5;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int q = (wn * 64 + j * 32 + 8 * g + 4 * half) >> 2;  // chunk of this quad's 4 channels
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2) {
+              const int i = 2 * pass + i2;
+              const int row = wm * 64 + i2 * 32 + (lane & 31);
+              *reinterpret_cast<float4*>(smem + row * ROWB + ((q ^ (row & (CPR - 1))) << 4)) =
+                  make_float4(fmaxf(acc[i][j][4 * g], floor_v), fmaxf(acc[i][j][4 * g + 1], floor_v),
+                              fmaxf(acc[i][j][4 * g + 2], floor_v), fmaxf(acc[i][j][4 * g + 3], floor_v));
+            }
+          }
+      }
+      __syncthreads();
+      if (pass == 0 && prof) t_copy = __builtin_amdgcn_s_memtime();
+      if (!p.out_f32) {
+#pragma unroll 1
+        for (int it = 0; it < ITEMS / 512; ++it) {
+          const int item = it * 512 + (int)threadIdx.x;
+          const int row = item % ROWS, grp = item / ROWS;
+          char* const rowp = smem + row * ROWB;
+          const int sw = row & (CPR - 1);
+          float v[32];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float4 t = *reinterpret_cast<const float4*>(rowp + (((grp * 8 + k) ^ sw) << 4));
+            v[4 * k] = t.x;
+            v[4 * k + 1] = t.y;
+            v[4 * k + 2] = t.z;
+            v[4 * k + 3] = t.w;
+          }
+          uint4 line[8];
+          mx_pack_line(v, line);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) *reinterpret_cast<uint4*>(rowp + (((grp * 8 + k) ^ sw) << 4)) = line[k];
+        }
+        __syncthreads();
+      }
+#pragma unroll
+      for (int it0 = 0; it0 < ITERS; it0 += BATCH) {
+        uint4 v[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+          const int idx = (it0 + u) * 512 + (int)threadIdx.x;
+          const int lr = idx / CPR, q = idx % CPR;
+          v[u] = *reinterpret_cast<const uint4*>(smem + lr * ROWB + ((q ^ (lr & (CPR - 1))) << 4));
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+          const int idx = (it0 + u) * 512 + (int)threadIdx.x;
+          const int lr = idx / CPR;
+          const long grow = row0 + (PASSES == 1 ? lr : (lr >> 6) * 128 + pass * 64 + (lr & 63));
+          if (grow < p.out_rows)
+            *reinterpret_cast<uint4*>(obase + grow * orow_bytes + (idx % CPR) * 16) = v[u];
+        }
+      }
+      if (pass + 1 < PASSES) __syncthreads();
+    }
+    if (prof) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+      if (lane == 0) {
+        p.prof[0] = t_loop - t_start;
+        p.prof[1] = t_epi - t_loop;
+        p.prof[2] = t_copy - t_epi;
+        p.prof[3] = t_end - t_copy;
+      }
+    }
+    return;
+  }
   constexpr int EB = X3 ? 4 : 2;
   constexpr int PITCH = G::BN * EB + 16;
   constexpr int PASSES = (X3 && !POOL) ? 2 : 1;

@@ -95,6 +95,39 @@ __global__ void row_sqnorm_cast_kernel(const void* __restrict__ x, float* __rest
   if (lane == 0) out[row] = s;
 }
 
+// f16mx operand rows (common.h): one wave per row, a lane packs whole 32-element groups (their 128-byte
+// lines); the norm is that of the widened row, as in the other modes.
+template <int ST>
+__global__ void row_sqnorm_mx_kernel(const void* __restrict__ x, float* __restrict__ out,
+                                     void* __restrict__ xo, int rows, int d) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const size_t es = ST == OIBL_ST_F32 ? 4 : 2;
+  const char* xr = static_cast<const char*>(x) + (size_t)row * d * es;
+  uint4* orow = reinterpret_cast<uint4*>(static_cast<char*>(xo) + (size_t)row * d * 4);
+  float s = 0.f;
+  for (int g = lane; g < (d >> 5); g += 64) {
+    float v[32];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float4 t = load4_widen<ST>(xr, g * 32 + 4 * k);
+      v[4 * k] = t.x;
+      v[4 * k + 1] = t.y;
+      v[4 * k + 2] = t.z;
+      v[4 * k + 3] = t.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 32; ++e) s = fmaf(v[e], v[e], s);
+    uint4 line[8];
+    mx_pack_line(v, line);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) orow[g * 8 + k] = line[k];
+  }
+  s = wave_sum(s);
+  if (lane == 0) out[row] = s;
+}
+
 struct PairParams {
   const void* x;  // [m][d] T
   const void* y;  // [n][d] T
@@ -189,9 +222,10 @@ struct PairRingParams {
   float thr_slack;
 };
 
-template <bool FILTER, bool X3 = false>
+template <bool FILTER, int P = RING_BF16>
 __global__ __launch_bounds__(512) void pairwise_ring_kernel(PairRingParams p) {
   using G = RingGeo<2>;
+  constexpr bool X3 = P != RING_BF16;  // 4-byte operand elements, 32 K per K-tile (bf16x3 and f16mx)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -221,7 +255,8 @@ __global__ __launch_bounds__(512) void pairwise_ring_kernel(PairRingParams p) {
   RingRowLoader<2> la, lb;
   la.init(static_cast<const char*>(p.x) + koff, p.x_bytes - koff, m0, p.m, (long)p.d * (X3 ? 4 : 2), rows_a,
           piece);
-  lb.init(static_cast<const char*>(p.y) + koff, p.y_bytes - koff, n0, p.n, p.y_row_bytes, rows_b, piece);
+  lb.init(static_cast<const char*>(p.y) + koff, p.y_bytes - koff, n0, p.n, p.y_row_bytes, rows_b,
+          P >= RING_MX ? ring_piece_mxb(wave, lane) : piece);
 
   f32x16_t acc[4][2];
 #pragma unroll
@@ -231,7 +266,7 @@ __global__ __launch_bounds__(512) void pairwise_ring_kernel(PairRingParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  ring_mainloop<2, false, false, X3>(acc, smem, wave, lane, la, lb, d_part >> (X3 ? 5 : 6));
+  ring_mainloop<2, false, false, P>(acc, smem, wave, lane, la, lb, d_part >> (X3 ? 5 : 6));
 
   // norms (and thresholds) of the tile's rows / columns -> LDS; out-of-range rows/columns are
   // clamped here and masked at the store
@@ -808,15 +843,21 @@ int oibl_debug_set_match_ring(int mode) {
 static size_t pw_off_yn(int m) { return align_up((size_t)m * sizeof(float), 256); }
 static size_t pw_off_xt(int m, int n) { return pw_off_yn(m) + align_up((size_t)n * sizeof(float), 256); }
 
+// f16mx needs K-tiles of 32 elements in even number >= 4 (d % 64 == 0, d >= 128); the one legal width
+// below that (d = 64) is served in bf16x3 — same element size, more accurate, never on the hot path
+static int eff_precision(int precision, int d) {
+  return precision == OIBL_F16MX && d < 128 ? OIBL_BF16X3 : precision;
+}
 static bool st_ok(int st) { return st == OIBL_ST_F32 || st == OIBL_ST_F16 || st == OIBL_ST_BF16; }
 // bytes of the operand copy the contraction reads instead of the stored rows (0: reads them as is)
 static size_t pw_copy_bytes(int rows, int d, int precision, int st) {
   if (precision == OIBL_BF16) return st == OIBL_ST_BF16 ? 0 : align_up((size_t)rows * d * 2, 256);
-  if (precision == OIBL_BF16X3) return align_up((size_t)rows * d * 4, 256);  // the (hi, lo) rows
+  if (precision == OIBL_BF16X3 || precision == OIBL_F16MX) return align_up((size_t)rows * d * 4, 256);  // split rows
   return st == OIBL_ST_F32 ? 0 : align_up((size_t)rows * d * 4, 256);
 }
 
 size_t oibl_pairwise_st_workspace_bytes(int m, int n, int d, int precision, int x_st, int y_st) {
+  precision = eff_precision(precision, d);
   if (m <= 0 || n <= 0 || d <= 0 || !st_ok(x_st) || !st_ok(y_st)) return 0;
   return pw_off_xt(m, n) + pw_copy_bytes(m, d, precision, x_st) + pw_copy_bytes(n, d, precision, y_st);
 }
@@ -831,7 +872,10 @@ static bool pair_ring_legal(int m, int n, int d, int es = 2) {
   return d % 64 == 0 && ksteps >= 4 && (ksteps & 1) == 0 && (size_t)m * d * es < (size_t)0xE0000000u &&
          (size_t)n * d * es < (size_t)0xE0000000u && n <= (1 << 20) && !g_regstage;
 }
-static bool mfma16(int precision) { return precision == OIBL_BF16 || precision == OIBL_BF16X3; }
+static bool mfma16(int precision) {
+  return precision == OIBL_BF16 || precision == OIBL_BF16X3 || precision == OIBL_F16MX;
+}
+
 static int opnd_es(int precision) { return precision == OIBL_BF16 ? 2 : 4; }
 static bool pair_ring_wanted(int m, int n, int d, int es = 2) {
   if (!g_match_ring || !pair_ring_legal(m, n, d, es)) return false;
@@ -840,7 +884,7 @@ static bool pair_ring_wanted(int m, int n, int d, int es = 2) {
 }
 
 extern "C++" {
-template <bool FILTER, bool X3 = false>
+template <bool FILTER, int P = RING_BF16>
 static int launch_pairwise_ring(PairRingParams& p, hipStream_t st, int ksplit = 1) {
   p.tiles_m = (p.m + 255) / 256;
   p.tiles_n = (p.n + 255) / 256;
@@ -848,7 +892,7 @@ static int launch_pairwise_ring(PairRingParams& p, hipStream_t st, int ksplit = 
   const long grid = (long)p.tiles_m * p.tiles_n;
   OIBL_REQUIRE(grid > 0 && grid <= 0x7fffffffL, "pairwise: grid out of range");
   constexpr int lds = RingGeo<2>::MAIN_LDS;
-  auto kern = pairwise_ring_kernel<FILTER, X3>;
+  auto kern = pairwise_ring_kernel<FILTER, P>;
   OIBL_SET_MAX_LDS(kern, lds);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)ksplit), dim3(512), lds, st, p);
   OIBL_LAUNCH_CHECK();
@@ -867,6 +911,9 @@ static int prepare_rows(const void* x, int rows, int d, int precision, float* no
     *opnd = ST == OIBL_ST_BF16 ? x : copy;
   } else if (precision == OIBL_BF16X3) {
     hipLaunchKernelGGL((row_sqnorm_cast_kernel<ST, 3>), grid, block, 0, st, x, norms, copy, rows, d);
+    *opnd = copy;
+  } else if (precision == OIBL_F16MX) {
+    hipLaunchKernelGGL((row_sqnorm_mx_kernel<ST>), grid, block, 0, st, x, norms, copy, rows, d);
     *opnd = copy;
   } else if (ST == OIBL_ST_F32) {
     hipLaunchKernelGGL(row_sqnorm_kernel, grid, block, 0, st, (const float*)x, norms, rows, d);
@@ -906,6 +953,34 @@ static int pairwise_launch(const void* xo, const void* yo, const float* xn, cons
                            int rows, int m_all, int n, int d, int precision, float* dist, size_t ldd,
                            hipStream_t st) {
   const size_t es = oibl_elem_size(precision);
+  if (precision == OIBL_F16MX) {
+    // the ring kernel is the only f16mx implementation: panels of rows / columns keep every launch inside
+    // the 32-bit buffer offsets of its operand loaders
+    OIBL_REQUIRE(ldd <= ((size_t)1 << 20), "pairwise (f16mx): row stride %zu above 2^20", ldd);
+    long panel = (long)(((size_t)0xE0000000u / ((size_t)d * 4) - 1) / 256 * 256);
+    if (panel > (1 << 20)) panel = 1 << 20;
+    for (long r0 = 0; r0 < rows; r0 += panel)
+      for (long c0 = 0; c0 < n; c0 += panel) {
+        const int pr = (int)(rows - r0 < panel ? rows - r0 : panel), pc = (int)(n - c0 < panel ? n - c0 : panel);
+        PairRingParams q = {};
+        q.x = (const char*)xo + (size_t)(row0 + r0) * d * 4;
+        q.y = (const char*)yo + (size_t)c0 * d * 4;
+        q.xn = xn + row0 + r0;
+        q.yn = yn + c0;
+        q.dist = dist + (size_t)r0 * ldd + c0;
+        q.ldd = ldd;
+        q.x_bytes = (unsigned)((size_t)pr * d * 4);
+        q.y_bytes = (unsigned)((size_t)pc * d * 4);
+        q.y_row_bytes = (long)d * 4;
+        q.yn_stride = 1;
+        q.m = pr;
+        q.n = pc;
+        q.d = d;
+        const int rc = launch_pairwise_ring<false, RING_MX>(q, st);
+        if (rc) return rc;
+      }
+    return OIBL_OK;
+  }
   if (mfma16(precision) && pair_ring_wanted(rows, n, d, (int)es) && ldd <= ((size_t)1 << 20)) {
     PairRingParams q = {};
     q.x = (const char*)xo + (size_t)row0 * d * es;
@@ -921,7 +996,7 @@ static int pairwise_launch(const void* xo, const void* yo, const float* xn, cons
     q.m = rows;
     q.n = n;
     q.d = d;
-    return precision == OIBL_BF16X3 ? launch_pairwise_ring<false, true>(q, st)
+    return precision == OIBL_BF16X3 ? launch_pairwise_ring<false, RING_X3>(q, st)
                                     : launch_pairwise_ring<false>(q, st);
   }
   PairParams p;
@@ -970,6 +1045,7 @@ static int pairwise_launch(const void* xo, const void* yo, const float* xn, cons
 int oibl_pairwise_sqdist_st(const void* x, int x_st, int m, const void* y, int y_st, int n, int d,
                             int precision, float* dist, size_t ldd, void* ws, size_t ws_bytes,
                             void* stream) {
+  precision = eff_precision(precision, d);
   OIBL_REQUIRE(x && y && dist && ws, "pairwise: null pointer");
   OIBL_REQUIRE(mfma16(precision) || precision == OIBL_F32, "pairwise: bad precision %d", precision);
   OIBL_REQUIRE(st_ok(x_st) && st_ok(y_st), "pairwise: bad storage type %d / %d", x_st, y_st);
@@ -1060,6 +1136,7 @@ static TopkPlan topk_plan(int m, int n, int d, int k, int precision, size_t prep
 
 size_t oibl_sqdist_topk_st_workspace_bytes(int m, int n, int d, int k, int precision, int x_st,
                                            int y_st) {
+  precision = eff_precision(precision, d);
   if (m <= 0 || n <= 0 || d <= 0 || k <= 0 || !st_ok(x_st) || !st_ok(y_st)) return 0;
   return topk_plan(m, n, d, k, precision, oibl_pairwise_st_workspace_bytes(m, n, d, precision, x_st, y_st)).total;
 }
@@ -1094,7 +1171,7 @@ static int sqdist_topk_core(const void* xo, const float* xn, int m, const void* 
     q.yn = yn;
     q.dist = sample;
     q.ldd = (size_t)t.S;
-    const bool x3 = precision == OIBL_BF16X3;
+    const bool x3 = precision == OIBL_BF16X3, mx = precision == OIBL_F16MX;
     const size_t es = (size_t)opnd_es(precision);
     q.x_bytes = (unsigned)((size_t)m * d * es);
     q.y_bytes = (unsigned)((size_t)n * d * es);
@@ -1110,7 +1187,9 @@ static int sqdist_topk_core(const void* xo, const float* xn, int m, const void* 
       q.part_stride = half;
       q.yn_max = (unsigned*)(cnt + m);
     }
-    rc = x3 ? launch_pairwise_ring<false, true>(q, st, t.ksplit) : launch_pairwise_ring<false>(q, st, t.ksplit);
+    rc = mx   ? launch_pairwise_ring<false, RING_MX>(q, st, t.ksplit)
+         : x3 ? launch_pairwise_ring<false, RING_X3>(q, st, t.ksplit)
+              : launch_pairwise_ring<false>(q, st, t.ksplit);
     if (rc) return rc;
     launch_row_topk(sample, nullptr, m, t.S, (size_t)t.S, k, 0, sval, sidx, nullptr, nullptr, st,
                     t.ksplit == 2 ? sample + half : nullptr);
@@ -1120,7 +1199,7 @@ static int sqdist_topk_core(const void* xo, const float* xn, int m, const void* 
     q.part_stride = 0;
     // (each of the two orders is within K' 2^-24 |x||y| of the exact dot product, K' = d products —
     //  3 d in bf16x3 — so they differ by at most twice that, and a distance by twice that again)
-    q.thr_slack = t.ksplit == 2 ? 4.0f * (float)d * (x3 ? 3.0f : 1.0f) * 5.9604645e-8f : 0.f;
+    q.thr_slack = t.ksplit == 2 ? 4.0f * (float)d * ((x3 || mx) ? 3.0f : 1.0f) * 5.9604645e-8f : 0.f;
     q.dist = nullptr;
     q.y_row_bytes = (long)d * es;
     q.yn_stride = 1;
@@ -1133,7 +1212,9 @@ static int sqdist_topk_core(const void* xo, const float* xn, int m, const void* 
     q.cap = t.cap;
     q.index_base = index_base;
     q.index_stride = 1;
-    rc = x3 ? launch_pairwise_ring<true, true>(q, st) : launch_pairwise_ring<true>(q, st);
+    rc = mx   ? launch_pairwise_ring<true, RING_MX>(q, st)
+         : x3 ? launch_pairwise_ring<true, RING_X3>(q, st)
+              : launch_pairwise_ring<true>(q, st);
     if (rc) return rc;
     // 3. exact top-k of every candidate list ((value, index) keys: independent of append order)
     launch_row_topk(q.cand_val, q.cand_idx, m, t.cap, (size_t)t.cap, k, 0, out_val, out_idx, cnt,
@@ -1165,6 +1246,7 @@ static int topk_args_ok(int m, int n, int d, int k, int index_base, int precisio
 int oibl_sqdist_topk_st(const void* x, int x_st, int m, const void* y, int y_st, int n, int d, int k,
                         int index_base, int precision, int exact, float* out_val, int32_t* out_idx,
                         int32_t* overflow, void* ws, size_t ws_bytes, void* stream) {
+  precision = eff_precision(precision, d);
   OIBL_REQUIRE(x && y && out_val && out_idx && ws, "sqdist_topk: null pointer");
   OIBL_REQUIRE(st_ok(x_st) && st_ok(y_st), "sqdist_topk: bad storage type %d / %d", x_st, y_st);
   int rc = topk_args_ok(m, n, d, k, index_base, precision);
@@ -1189,12 +1271,14 @@ int oibl_sqdist_topk_st(const void* x, int x_st, int m, const void* y, int y_st,
 
 // ---- prepared operands: a gallery (or query set) that is matched many times ----------------------
 size_t oibl_match_operand_bytes(int rows, int d, int precision, int st) {
+  precision = eff_precision(precision, d);
   if (rows <= 0 || d <= 0 || !st_ok(st)) return 0;
   return pw_copy_bytes(rows, d, precision, st);
 }
 
 int oibl_match_prepare(const void* x, int x_st, int rows, int d, int precision, float* norms,
                        void* operand, void* stream) {
+  precision = eff_precision(precision, d);
   OIBL_REQUIRE(x && norms, "match_prepare: null pointer");
   OIBL_REQUIRE(mfma16(precision) || precision == OIBL_F32, "match_prepare: bad precision %d", precision);
   OIBL_REQUIRE(st_ok(x_st), "match_prepare: bad storage type %d", x_st);
@@ -1207,6 +1291,7 @@ int oibl_match_prepare(const void* x, int x_st, int rows, int d, int precision, 
 }
 
 size_t oibl_sqdist_topk_prepared_workspace_bytes(int m, int n, int d, int k, int precision) {
+  precision = eff_precision(precision, d);
   if (m <= 0 || n <= 0 || d <= 0 || k <= 0) return 0;
   return topk_plan(m, n, d, k, precision, 0).total;
 }
@@ -1215,6 +1300,7 @@ int oibl_sqdist_topk_prepared(const void* xo, const float* xn, int m, const void
                               int n, int d, int k, int index_base, int precision, int exact,
                               float* out_val, int32_t* out_idx, int32_t* overflow, void* ws,
                               size_t ws_bytes, void* stream) {
+  precision = eff_precision(precision, d);
   OIBL_REQUIRE(xo && xn && yo && yn && out_val && out_idx && ws, "sqdist_topk_prepared: null pointer");
   int rc = topk_args_ok(m, n, d, k, index_base, precision);
   if (rc) return rc;

@@ -56,6 +56,16 @@ namespace oibl {
 
 constexpr unsigned RG_OOB = 0xF0000000u;  // voffset that is out of range for every descriptor here
 
+// operand arithmetic of an instantiation (template argument P; false / true of the older bool
+// parameter convert to RING_BF16 / RING_X3)
+constexpr int RING_BF16 = 0;  // bf16 rows, 64 K per 128-byte K-tile, 8 MFMAs per phase
+constexpr int RING_X3 = 1;    // bf16x3 rows ([32 hi | 32 lo]), 32 K per K-tile, 12 MFMAs per phase
+constexpr int RING_MX = 2;    // f16mx rows (common.h), 32 K per K-tile, 4 f16 + 2 MX-fp6 MFMAs per phase;
+                              // the LDS-DMA instructions of a phase are issued inside its COMPUTE segment
+constexpr int RING_MX_EARLY = 3;  // the same with the LDS-DMA issue in the LOAD segment (as bf16 / bf16x3)
+// timing experiments on the RING_MX_EARLY stream (WRONG results): one ingredient of the loop removed
+constexpr int RING_MX_NOMFMA = 4, RING_MX_NODMA = 5, RING_MX_NOREAD = 6, RING_MX_NOBAR = 7;
+
 // Geometry of one instantiation.  WM = wave rows (2 or 4); the 8 waves form a WM x (8 / WM) grid,
 // every wave owns 128 x 64 outputs, so the tile is 256 x 256 (WM = 2) or 512 x 128 (WM = 4).
 // Stagger group of a wave = wave >> 2 (waves w and w + 4 share a SIMD).
@@ -86,6 +96,12 @@ __device__ static inline int ring_b_row(int wave, int lane, int h, int i) {
 // Byte offset of this lane's (swizzled) 16-B piece inside its row's 128-byte K segment.
 __device__ static inline int ring_piece(int wave, int lane) {
   return ((lane & 7) ^ (4 * (wave & 1) + (lane >> 4))) * 16;
+}
+
+// f16mx, B operand: the same LDS position receives the line's slot s ^ 1 for s >= 4 (q6(hi) <-> q6(lo))
+__device__ static inline int ring_piece_mxb(int wave, int lane) {
+  const int s = (lane & 7) ^ (4 * (wave & 1) + (lane >> 4));
+  return (s >= 4 ? s ^ 1 : s) * 16;
 }
 
 __device__ static inline void buf_glds16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff,
@@ -133,11 +149,18 @@ struct RingRowLoader {
 // consecutive columns of one row per register quad — what an epilogue that writes row-major
 // 16-bit outputs wants (8-byte stores instead of 2-byte ones).  Each output element is the same
 // k-ordered fma chain either way: identical bits.
-// X3 = bf16x3 operands (common.h): a K-tile row is [32 hi | 32 lo], so the four fragments of a row
-// are hi[0:16], hi[16:32], lo[0:16], lo[16:32] and a phase multiplies lo.hi + hi.lo + hi.hi per
+// P = RING_X3: bf16x3 operands (common.h): a K-tile row is [32 hi | 32 lo], so the four fragments of a
+// row are hi[0:16], hi[16:32], lo[0:16], lo[16:32] and a phase multiplies lo.hi + hi.lo + hi.hi per
 // 16-wide half: 12 MFMAs per phase instead of 8 on the same LDS traffic.
+// P = RING_MX: f16mx operands (common.h): fragments 0, 1 are hi[0:16], hi[16:32] in fp16, fragments
+// 2, 3 together are one MX operand (6 dwords of e2m3 + the scale byte in dword 6) — q6(hi) in the
+// lower lane half and q6(lo) in the upper one on the A side, the other way round on the B side: the B
+// LOADER stages slots 4..7 of every line pairwise exchanged (ring_piece_mxb: the exchange sits in the
+// per-lane source offset of the LDS-DMA, fixed for the kernel) — so that ONE K = 64 MX instruction adds
+// both cross terms: per 32x32 tile and K-tile 2 f16 MFMAs + 1 MX MFMA, 6 per phase, on the same LDS
+// traffic and with the same fragment addresses for both operands.
 // On return every wave has passed a workgroup barrier: the staging LDS is free.
-template <int WM, bool ODD, bool SWAP, bool X3 = false, typename LA, typename LB>
+template <int WM, bool ODD, bool SWAP, int P = RING_BF16, typename LA, typename LB>
 __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, int wave, int lane,
                                             LA& la, LB& lb, int nsteps) {
   using G = RingGeo<WM>;
@@ -154,14 +177,22 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
   // than a COMPUTE segment.
   constexpr bool SPLIT = NA >= 4 * NB;
   auto stage_a = [&](int buf, int h, int part) __attribute__((always_inline)) {
+    if constexpr (P == RING_MX_NODMA) return;
     char* d = st_base + buf * G::TILE + (h ? OFF_A1 : OFF_A0);
     if constexpr (SPLIT) la.stage(h, d, part * (NA / 2), (part + 1) * (NA / 2));
     else if (part == 0) la.stage(h, d, 0, NA);
   };
   auto stage_b = [&](int buf, int h) __attribute__((always_inline)) {
+    if constexpr (P == RING_MX_NODMA) return;
     lb.stage(h, st_base + buf * G::TILE + (h ? OFF_B1 : OFF_B0));
   };
 
+  constexpr bool X3 = P == RING_X3, MX = P >= RING_MX;
+  // LATE: with 6 MFMAs (192 cycles) per phase the LOAD segment (fragment reads + 2-4 LDS-DMA issues at
+  // 100-185 cycles each next to the reads) is longer than the COMPUTE segment it is paired with, so the
+  // DMA issue moves into COMPUTE, between the MFMAs (~60 cycles each there); every counted wait then
+  // sits BEFORE its phase's issues and allows that many fewer instructions in flight.
+  constexpr bool LATE = P == RING_MX;
   int frag_off[4];
   {
     const int row = lane & 31, half = lane >> 5, swz = (lane >> 1) & 7;
@@ -172,21 +203,38 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
   const char* const rd_b = smem + wn * 4096;  // + buf * TILE + OFF_B{h}
 
   bf16x8_t fa[2][4], fbx[4], fby[4];
+  // One fragment.  MX, fragment 3 (the tail of the MX operand): 8 data bytes + the scale byte are
+  // fetched as ds_read_b64 + ds_read_b32 instead of one ds_read_b128 — the same LDS cycles, and the
+  // 6-register operand of the MX instruction is then the register sequence {b128, b64} of two loads
+  // (coalesced by the allocator); with a b128 tail the operand had to be re-assembled by copies into
+  // fresh registers, ~20 VGPRs the distance kernels do not have.
+  auto read_frag = [&](const char* s, int kk) __attribute__((always_inline)) -> bf16x8_t {
+    if constexpr (MX) {
+      if (kk == 3) {
+        const uint2 d = *reinterpret_cast<const uint2*>(s + frag_off[3]);
+        const unsigned sc = *reinterpret_cast<const unsigned*>(s + frag_off[3] + 8);
+        typedef __attribute__((ext_vector_type(4))) unsigned u4;
+        return __builtin_bit_cast(bf16x8_t, (u4){d.x, d.y, sc, 0u});
+      }
+    }
+    return *reinterpret_cast<const bf16x8_t*>(s + frag_off[kk]);
+  };
   auto read_a = [&](int buf, int h) __attribute__((always_inline)) {
+    if constexpr (P == RING_MX_NOREAD) return;
     const char* s = rd_a + buf * G::TILE + (h ? OFF_A1 : OFF_A0);
 #pragma unroll
     for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
-        fa[i2][kk] = *reinterpret_cast<const bf16x8_t*>(s + i2 * 4096 + frag_off[kk]);
+      for (int kk = 0; kk < 4; ++kk) fa[i2][kk] = read_frag(s + i2 * 4096, kk);
   };
   auto read_b = [&](int buf, int h, bf16x8_t (&f)[4]) __attribute__((always_inline)) {
+    if constexpr (P == RING_MX_NOREAD) return;
     const char* s = rd_b + buf * G::TILE + (h ? OFF_B1 : OFF_B0);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) f[kk] = *reinterpret_cast<const bf16x8_t*>(s + frag_off[kk]);
+    for (int kk = 0; kk < 4; ++kk) f[kk] = read_frag(s, kk);
   };
 
-  auto compute = [&](auto h_c, auto j_c, const bf16x8_t (&fb)[4]) __attribute__((always_inline)) {
+  auto compute = [&](auto h_c, auto j_c, const bf16x8_t (&fb)[4], auto&& issue) __attribute__((always_inline)) {
     constexpr int h = decltype(h_c)::value, j = decltype(j_c)::value;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -196,7 +244,36 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
           SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kb], fa[i2][ka], acc[2 * h + i2][j], 0, 0, 0)
                : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i2][ka], fb[kb], acc[2 * h + i2][j], 0, 0, 0);
     };
-    if constexpr (X3) {
+    if constexpr (P == RING_MX_NOMFMA) {
+      asm volatile("" : "+v"(acc[2 * h][j]), "+v"(acc[2 * h + 1][j]));
+    } else if constexpr (MX) {
+      typedef __attribute__((ext_vector_type(4))) int i4;
+      auto f16 = [&](int i2, int k) __attribute__((always_inline)) {
+        const f16x8_t a = __builtin_bit_cast(f16x8_t, fa[i2][k]), b = __builtin_bit_cast(f16x8_t, fb[k]);
+        acc[2 * h + i2][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, acc[2 * h + i2][j], 0, 0, 0)
+                                  : __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[2 * h + i2][j], 0, 0, 0);
+      };
+      const i32x8_t b8 = __builtin_shufflevector(__builtin_bit_cast(i4, fb[2]), __builtin_bit_cast(i4, fb[3]),
+                                                 0, 1, 2, 3, 4, 5, 6, 7);
+      auto mx = [&](int i2) __attribute__((always_inline)) {
+        const i32x8_t a8 = __builtin_shufflevector(__builtin_bit_cast(i4, fa[i2][2]),
+                                                   __builtin_bit_cast(i4, fa[i2][3]), 0, 1, 2, 3, 4, 5, 6, 7);
+        // e2m3 x e2m3 (cbsz = blgp = 2); scales: byte 0 of dword 6 of either operand
+        acc[2 * h + i2][j] =
+            SWAP ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8, a8, acc[2 * h + i2][j], 2, 2, 0, b8[6], 0, a8[6])
+                 : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[2 * h + i2][j], 2, 2, 0, a8[6], 0, b8[6]);
+      };
+      f16(0, 0);
+      f16(1, 0);
+      issue();
+      f16(0, 1);
+      f16(1, 1);
+      mx(0);
+      mx(1);
+      // (the MX instruction's 6-register operands are assembled by copies, and copy + MFMA were seen
+      //  to be sunk out of the segment, past the barrier, into the next LOAD segment: pin the results)
+      asm volatile("" : "+v"(acc[2 * h][j]), "+v"(acc[2 * h + 1][j]));
+    } else if constexpr (X3) {
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {
 #pragma unroll
@@ -217,7 +294,7 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
   };
   auto bar = [&]() __attribute__((always_inline)) {
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
+    if constexpr (P != RING_MX_NOBAR) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
 
@@ -258,49 +335,68 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
     constexpr int TAIL = decltype(tail_c)::value;
     bf16x8_t(&b0)[4] = PAR ? fby : fbx;  // B0 of this tile
     bf16x8_t(&b1)[4] = PAR ? fbx : fby;  // B1 of this tile; from P3 on: B0 of the next tile
+    // A phase = reads; [early: issues;] counted wait; barrier; COMPUTE [late: issues inside]; barrier.
+    // `cnt` = what the wait allows in flight when it stands AFTER the phase's `n_issue` instructions.
+    auto phase = [&](auto cnt_c, auto n_issue_c, auto h_c, auto j_c, const bf16x8_t (&fb)[4], auto&& issue)
+        __attribute__((always_inline)) {
+      constexpr int CNT = decltype(cnt_c)::value, NI = decltype(n_issue_c)::value;
+      if constexpr (!LATE) {
+        issue();
+        if constexpr (CNT >= 0) wait_vmcnt<CNT>();
+        bar();
+        compute(h_c, j_c, fb, [] {});
+      } else {
+        if constexpr (CNT >= 0) wait_vmcnt<(CNT - NI)>();
+        bar();
+        compute(h_c, j_c, fb, issue);
+      }
+      bar();
+    };
+#define RING_IC(x) std::integral_constant<int, (x)> {}
+    constexpr int HA = SPLIT ? NA / 2 : NA;   // instructions of the A issue in P0 / P2
+    constexpr int HB = SPLIT ? NA / 2 : 0;    // A instructions issued next to the B unit in P1 / P3
     // P0: A0 x B0
     read_a(PAR, 0);
-    if constexpr (TAIL <= 1) {
-      stage_a(PAR ^ 1, 1, 0);  // A1(t+1) (SPLIT: its first half)
-      wait_vmcnt<3 * NA + 2 * NB - (SPLIT ? NA / 2 : 0)>();
-    } else wait_vmcnt<NA>();
-    bar();
-    compute(I0{}, I0{}, b0);
-    bar();
+    if constexpr (TAIL <= 1)
+      phase(RING_IC(3 * NA + 2 * NB - (SPLIT ? NA / 2 : 0)), RING_IC(HA), I0{}, I0{}, b0,
+            [&] { stage_a(PAR ^ 1, 1, 0); });  // A1(t+1) (SPLIT: its first half)
+    else
+      phase(RING_IC(NA), RING_IC(0), I0{}, I0{}, b0, [] {});
     // P1: A0 x B1
     read_b(PAR, 1, b1);
-    if constexpr (TAIL == 0) {
-      stage_a(PAR ^ 1, 1, 1);  // SPLIT: second half of A1(t+1)
-      lb.begin_tile();
-      stage_b(PAR, 0);  // B0(t+2)
-      wait_vmcnt<2 * NA + 3 * NB>();
-    } else if constexpr (TAIL == 1) {
-      stage_a(PAR ^ 1, 1, 1);
-      wait_vmcnt<2 * NA + 2 * NB>();
-    } else wait_vmcnt<0>();
-    bar();
-    compute(I0{}, I1{}, b1);
-    bar();
+    if constexpr (TAIL == 0)
+      phase(RING_IC(2 * NA + 3 * NB), RING_IC(HB + NB), I0{}, I1{}, b1, [&] {
+        stage_a(PAR ^ 1, 1, 1);  // SPLIT: second half of A1(t+1)
+        lb.begin_tile();
+        stage_b(PAR, 0);  // B0(t+2)
+      });
+    else if constexpr (TAIL == 1)
+      phase(RING_IC(2 * NA + 2 * NB), RING_IC(HB), I0{}, I1{}, b1, [&] { stage_a(PAR ^ 1, 1, 1); });
+    else
+      phase(RING_IC(0), RING_IC(0), I0{}, I1{}, b1, [] {});
     // P2: A1 x B1
     read_a(PAR, 1);
-    if constexpr (TAIL == 0) {
-      la.begin_tile();
-      stage_a(PAR, 0, 0);  // A0(t+2) (SPLIT: its first half)
-      wait_vmcnt<3 * NA + 2 * NB - (SPLIT ? NA / 2 : 0)>();
-    } else if constexpr (TAIL == 1) wait_vmcnt<2 * NA + NB>();
-    bar();
-    compute(I1{}, I1{}, b1);
-    bar();
+    if constexpr (TAIL == 0)
+      phase(RING_IC(3 * NA + 2 * NB - (SPLIT ? NA / 2 : 0)), RING_IC(HA), I1{}, I1{}, b1, [&] {
+        la.begin_tile();
+        stage_a(PAR, 0, 0);  // A0(t+2) (SPLIT: its first half)
+      });
+    else if constexpr (TAIL == 1)
+      phase(RING_IC(2 * NA + NB), RING_IC(0), I1{}, I1{}, b1, [] {});
+    else
+      phase(RING_IC(-1), RING_IC(0), I1{}, I1{}, b1, [] {});
     // P3: A1 x B0   (B0 of the next tile goes into the register set B1 just vacated)
     if constexpr (TAIL <= 1) read_b(PAR ^ 1, 0, b1);
-    if constexpr (TAIL == 0) {
-      stage_a(PAR, 0, 1);  // SPLIT: second half of A0(t+2)
-      stage_b(PAR, 1);     // B1(t+2)
-      wait_vmcnt<2 * NA + 3 * NB>();
-    } else if constexpr (TAIL == 1) wait_vmcnt<NA + NB>();
-    bar();
-    compute(I1{}, I0{}, b0);
-    bar();
+    if constexpr (TAIL == 0)
+      phase(RING_IC(2 * NA + 3 * NB), RING_IC(HB + NB), I1{}, I0{}, b0, [&] {
+        stage_a(PAR, 0, 1);  // SPLIT: second half of A0(t+2)
+        stage_b(PAR, 1);     // B1(t+2)
+      });
+    else if constexpr (TAIL == 1)
+      phase(RING_IC(NA + NB), RING_IC(0), I1{}, I0{}, b0, [] {});
+    else
+      phase(RING_IC(-1), RING_IC(0), I1{}, I0{}, b0, [] {});
+#undef RING_IC
   };
   for (int t = 0; t + 3 < nsteps; t += 2) {  // pairs of steady-state tiles
     ktile(I0{}, I0{});

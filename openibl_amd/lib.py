@@ -71,6 +71,8 @@ SIGNATURES = {
                                     c_void_p]),
     "oibl_x3_split_rows": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "oibl_x3_join_rows": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "oibl_mx_split_rows": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "oibl_mx_join_rows": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "oibl_match_operand_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "oibl_match_prepare": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "oibl_sqdist_topk_prepared_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
@@ -105,6 +107,7 @@ _HOOKS = {"oibl_debug_set_regstage": (c_int, [c_int]),
           "oibl_debug_set_ring_ablate": (c_int, [c_int]),
           "oibl_debug_set_ring_raster": (c_int, [c_int]),
           "oibl_debug_set_conv_korder": (c_int, [c_int]),
+          "oibl_debug_set_mx_variant": (c_int, [c_int]),
           "oibl_debug_set_conv_splitk": (c_int, [c_int]),
           "oibl_debug_set_stem3_prio": (c_int, [c_int]),
           "oibl_debug_set_match_group": (c_int, [c_int]),

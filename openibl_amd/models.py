@@ -33,12 +33,13 @@ _CFG_D = (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 51
 
 def default_precision() -> str:
     """'fp32' (exact fp32 MFMA, reference-grade numerics) unless OPENIBL_AMD_PRECISION is set to
-    'bf16x3' (split bf16: fp32-class descriptors at 3x the bf16 matrix work) or 'bf16'."""
+    'f16mx' (fp16 main term + MX-fp6 cross terms: descriptors within 1e-4 at 1.5 matrix instructions
+    per bf16 one), 'bf16x3' (split bf16: fp32-class descriptors at 3x the bf16 matrix work) or 'bf16'."""
     return os.environ.get("OPENIBL_AMD_PRECISION", "fp32").lower()
 
 
 class _PrecisionMixin:
-    """`module.set_precision('bf16' | 'bf16x3' | 'fp32')` switches the arithmetic of the contractions."""
+    """`module.set_precision('bf16' | 'f16mx' | 'bf16x3' | 'fp32')` switches the arithmetic of the contractions."""
 
     def set_precision(self, precision: str):
         ops.precision_code(precision)
@@ -139,8 +140,11 @@ class VGG(_PrecisionMixin, nn.Module):
         hit = self._cache.get("packed")
         if hit is None or hit[0] != key:
             ws = [convs[0].weight.detach().float().contiguous()]
-            ws += [ops.pack_conv3x3(c.weight.detach().float().contiguous(), self.precision)
-                   for c in convs[1:]]
+            # f16mx: conv1_1 + conv1_2 + pool run in split bf16 (K = 27 / Cout = 64 fit no MX tile)
+            prec = [("bf16x3" if (i == 1 and ops.precision_code(self.precision) == ops.F16MX) else self.precision)
+                    for i in range(len(convs))]
+            ws += [ops.pack_conv3x3(c.weight.detach().float().contiguous(), prec[i])
+                   for i, c in enumerate(convs) if i >= 1]
             bs = [c.bias.detach().float().contiguous() for c in convs]
             self._cache["packed"] = (key, ws, bs)
             hit = self._cache["packed"]

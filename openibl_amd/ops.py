@@ -15,11 +15,12 @@ from . import lib as _lib
 BF16 = 0
 F32 = 1
 BF16X3 = 2   # split bf16: (hi, lo) operand pairs, three MFMAs per product, fp32-class results
-# element containers: bf16x3 activations / packed weights are opaque 4-byte elements (rows of
-# [32 hi | 32 lo] groups, see x3_split) carried in int32 tensors of the logical shape
-_DTYPES = {BF16: torch.bfloat16, F32: torch.float32, BF16X3: torch.int32}
+F16MX = 3    # fp16 main term + MX-fp6 cross terms: 1e-4-class results at half the matrix time of bf16x3
+# element containers: bf16x3 / f16mx activations and packed weights are opaque 4-byte elements (128-byte
+# groups of 32 elements, see x3_split / mx_split) carried in int32 tensors of the logical shape
+_DTYPES = {BF16: torch.bfloat16, F32: torch.float32, BF16X3: torch.int32, F16MX: torch.int32}
 _NAMES = {"bf16": BF16, "bfloat16": BF16, "fp32": F32, "f32": F32, "float32": F32,
-          "bf16x3": BF16X3, "x3": BF16X3}
+          "bf16x3": BF16X3, "x3": BF16X3, "f16mx": F16MX, "mx": F16MX}
 
 
 def precision_code(p) -> int:
@@ -27,8 +28,8 @@ def precision_code(p) -> int:
         try:
             return _NAMES[p.lower()]
         except KeyError:
-            raise ValueError(f"unknown precision {p!r} (use 'bf16', 'bf16x3' or 'fp32')")
-    if p in (BF16, F32, BF16X3):
+            raise ValueError(f"unknown precision {p!r} (use 'bf16', 'f16mx', 'bf16x3' or 'fp32')")
+    if p in (BF16, F32, BF16X3, F16MX):
         return int(p)
     raise ValueError(f"unknown precision {p!r}")
 
@@ -38,7 +39,7 @@ def head_precision(p) -> int:
     runs them in exact fp32 — they are HBM / latency bound there (the PCA streams its weight once
     per batch), so splitting the operands would buy nothing."""
     p = precision_code(p)
-    return F32 if p == BF16X3 else p
+    return F32 if p in (BF16X3, F16MX) else p
 
 
 def elem_dtype(p) -> torch.dtype:
@@ -131,6 +132,32 @@ def x3_split(x: torch.Tensor) -> torch.Tensor:
     C_ = int(x.shape[-1])
     _lib.check(_lib.load().oibl_x3_split_rows(_ptr(x), _ptr(out), x.numel() // C_, C_, _stream(dev)),
                "x3_split_rows")
+    return out
+
+
+def mx_split(x: torch.Tensor) -> torch.Tensor:
+    """float32 [..., C] (C % 32 == 0) -> the f16mx operand layout (int32 container, same shape): per 32
+    elements one 128-byte line [32 fp16 | e2m3 images of hi and lo + their scale bytes]."""
+    dev = _need_cuda(x)
+    if x.dtype != torch.float32 or x.shape[-1] % 32 != 0:
+        raise ValueError("mx_split expects a float32 tensor whose last dimension is a multiple of 32")
+    C_ = int(x.shape[-1])
+    out = torch.empty(x.shape, dtype=torch.int32, device=dev)
+    _lib.check(_lib.load().oibl_mx_split_rows(_ptr(x), _ptr(out), x.numel() // C_, C_, _stream(dev)),
+               "mx_split_rows")
+    return out
+
+
+def mx_join(x: torch.Tensor, which: int = 0) -> torch.Tensor:
+    """f16mx tensor (int32 container) -> float32: which = 0 hi + q6(lo) (the stored value to ~2^-15 of
+    the group's largest element), 1 hi (fp16), 2 q6(hi), 3 q6(lo) — what the kernels multiply."""
+    dev = _need_cuda(x)
+    if x.dtype != torch.int32 or x.shape[-1] % 32 != 0:
+        raise ValueError("mx_join expects an int32 f16mx container whose last dimension is a multiple of 32")
+    C_ = int(x.shape[-1])
+    out = torch.empty(x.shape, dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().oibl_mx_join_rows(_ptr(x), _ptr(out), x.numel() // C_, C_, int(which), _stream(dev)),
+               "mx_join_rows")
     return out
 
 
@@ -701,7 +728,6 @@ class PreparedRows:
             raise ValueError("PreparedRows expects [rows][d]")
         x = _pad_dim(x.contiguous())
         st = storage_code(x)
-        rows, d = map(int, x.shape)
         rows, d = map(int, x.shape)
         self.precision, self.shape, self.device = p, (rows, d), dev
         self.norms = torch.empty((rows,), dtype=torch.float32, device=dev)
