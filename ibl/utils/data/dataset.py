@@ -74,12 +74,14 @@ class Dataset(object):
         self.db_val = pluck(sorted(splits.get('db_val', [])))
         self.q_test = pluck(sorted(splits.get('q_test', [])))
         self.db_test = pluck(sorted(splits.get('db_test', [])))
+        # validation / test positives: the 25 m radius is a literal in the reference, independent of
+        # inter_thres, and no query may be left without a positive (ibl/utils/data/dataset.py:89-92)
         if self.q_val and self.db_val:
-            self.val_pos, sel = get_groundtruth(self.q_val, self.db_val, self.inter_thres)
-            self.q_val = [self.q_val[i] for i in sel]
+            self.val_pos, sel = get_groundtruth(self.q_val, self.db_val, 25)
+            assert len(sel) == len(self.q_val), "validation queries without a positive within 25 m"
         if self.q_test and self.db_test:
-            self.test_pos, sel = get_groundtruth(self.q_test, self.db_test, self.inter_thres)
-            self.q_test = [self.q_test[i] for i in sel]
+            self.test_pos, sel = get_groundtruth(self.q_test, self.db_test, 25)
+            assert len(sel) == len(self.q_test), "test queries without a positive within 25 m"
         if verbose:
             print(self.__class__.__name__, "dataset loaded: {} test queries, {} test gallery".format(
                 len(self.q_test), len(self.db_test)))

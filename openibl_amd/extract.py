@@ -161,6 +161,10 @@ class GraphedForward:
             with torch.cuda.stream(self.copy):
                 self.static_in[j].copy_(x, non_blocking=True)
                 self.in_ready[j].record(self.copy)
+            if x.is_cuda:
+                # the caller may drop x right after this call: its block must not be handed out again
+                # (on the caller's stream) before the copy stream has read it
+                x.record_stream(self.copy)
             lane.wait_event(self.in_ready[j])
             self.last_stream = self.copy
         if dest is not None:
@@ -222,7 +226,8 @@ class _PinnedStage:
         self.done = [None, None]
         self.i = 0
 
-    def stage(self, x: torch.Tensor, dev) -> torch.Tensor:
+    def stage(self, x: torch.Tensor, dev):
+        """-> (pinned view holding x, buffer index for mark())"""
         j = self.i
         self.i ^= 1
         if self.done[j] is not None:
@@ -260,7 +265,7 @@ def extract_descriptors(model, data_loader, vlad=True, pca=None, gpu=None, print
     except Exception:
         n_batches = -1
     final, chunks, row = None, [], 0
-    seen, graphs = {}, OrderedDict()
+    seen, graphs, evicted = {}, OrderedDict(), set()
     stage = _PinnedStage()
     main = torch.cuda.current_stream(dev)
     last_fwd = None
@@ -282,7 +287,7 @@ def extract_descriptors(model, data_loader, vlad=True, pca=None, gpu=None, print
             key = (tuple(imgs.shape), imgs.dtype)
             seen[key] = seen.get(key, 0) + 1
             fwd = graphs.get(key)
-            if fwd is None and use_graphs and seen[key] >= 2:
+            if fwd is None and use_graphs and seen[key] >= 2 and key not in evicted:
                 if last_fwd is not None:
                     last_fwd.wait()
                 main.synchronize()            # capture starts from an idle device
@@ -290,7 +295,10 @@ def extract_descriptors(model, data_loader, vlad=True, pca=None, gpu=None, print
                 fwd = GraphedForward(backbone, head, ex, pipeline=True)
                 graphs[key] = fwd
                 while len(graphs) > MAX_CACHED_SHAPES:
-                    graphs.popitem(last=False)
+                    # a loader cycling through more shapes than are kept would re-capture (a device
+                    # sync, an eager warm-up and four captures) for single batches: an evicted shape
+                    # stays eager for the rest of this call
+                    evicted.add(graphs.popitem(last=False)[0])
             if fwd is not None:
                 graphs.move_to_end(key)
             if final is None and fwd is None:
@@ -308,6 +316,10 @@ def extract_descriptors(model, data_loader, vlad=True, pca=None, gpu=None, print
                 dst = None
                 if final is not None:
                     if row + n > final.shape[0]:       # the loader yields more than its sampler said
+                        # lane hand-offs into the old matrix may still be in flight (and the old block
+                        # goes back to the allocator of THIS stream): wait for every lane first
+                        if last_fwd is not None:
+                            last_fwd.wait()
                         final = torch.cat([final, torch.empty((row + n - final.shape[0], final.shape[1]),
                                                               dtype=final.dtype, device=dev)])
                     dst = final[row:row + n]

@@ -2,6 +2,8 @@
 reference's OWN examples/cluster.py (unmodified, from where it lies) against THIS repo's `ibl`
 package, runs its get_data() on a Pittsburgh-format synthetic dataset and builds the model the way
 its get_model() does (without the .cuda() / DataParallel wrap: no GPU here).  h5py is stubbed."""
+import sys
+sys.dont_write_bytecode = True   # nothing may be written under /root/reference
 import argparse
 import os
 import runpy

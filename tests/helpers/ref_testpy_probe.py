@@ -2,6 +2,8 @@
 reference's OWN examples/test.py (unmodified, from where it lies) against THIS repo's `ibl`
 package and runs its get_data() on a Pittsburgh-format synthetic dataset.  h5py (imported at the
 top of test.py, absent from the image) is stubbed; nothing else is."""
+import sys
+sys.dont_write_bytecode = True   # nothing may be written under /root/reference
 import argparse
 import os
 import runpy
