@@ -150,8 +150,11 @@ __device__ static inline float x3_load(const void* row, size_t c) {
 //   bytes   0.. 63  hi[0:32] fp16                       (k-chunks 0, 1: the two f16 MFMAs)
 //   bytes  64.. 79  first 16 bytes of q6(hi)            (slot 4)
 //   bytes  80.. 95  first 16 bytes of q6(lo)            (slot 5)
-//   bytes  96..111  last 8 bytes of q6(hi) | scale byte of q6(hi) | 7 x 0     (slot 6)
-//   bytes 112..127  last 8 bytes of q6(lo) | scale byte of q6(lo) | 7 x 0     (slot 7)
+//   bytes  96..111  last 8 bytes of q6(hi) | 4 x 0 | scale byte of q6(hi) | 3 x 0     (slot 6)
+//   bytes 112..127  last 8 bytes of q6(lo) | 4 x 0 | scale byte of q6(lo) | 3 x 0     (slot 7)
+// (the scale sits 12 bytes into its slot, not 8: the kernels fetch the tail as ds_read_b64 + ds_read_b32,
+//  and adjacent loads would be merged into one ds_read_b96 — twice the LDS cycles, and a merged load
+//  carries no alias information, so the compiler drains the LDS-DMA queue (vmcnt(0)) in front of it)
 // q6 = 32 x e2m3 packed 6 bits each (element e at bits 6e..6e+5, the order of
 // v_cvt_scalef32_pk32_fp6_f16), value = code * 2^(scale byte - 127).  A lane of the MX instruction
 // holds one row's 32 K elements of one 32-block (lanes 0-31: block 0, lanes 32-63: block 1): the A
@@ -205,8 +208,8 @@ __device__ static inline void mx_pack_line(const float (&v)[32], uint4 (&out)[8]
   for (int s = 0; s < 4; ++s) out[s] = make_uint4(hw[4 * s], hw[4 * s + 1], hw[4 * s + 2], hw[4 * s + 3]);
   out[4] = make_uint4(h6[0], h6[1], h6[2], h6[3]);
   out[5] = make_uint4(l6[0], l6[1], l6[2], l6[3]);
-  out[6] = make_uint4(h6[4], h6[5], (unsigned)bh, 0u);
-  out[7] = make_uint4(l6[4], l6[5], (unsigned)bl, 0u);
+  out[6] = make_uint4(h6[4], h6[5], 0u, (unsigned)bh);
+  out[7] = make_uint4(l6[4], l6[5], 0u, (unsigned)bl);
 #endif
 }
 
@@ -230,7 +233,7 @@ __host__ __device__ static inline void mx_line_decode(const void* line, int c, f
     }
     return (unsigned)(w >> (bit & 7)) & 63u;
   };
-  const float sh = __builtin_ldexpf(1.0f, (int)b[104] - 127), sl = __builtin_ldexpf(1.0f, (int)b[120] - 127);
+  const float sh = __builtin_ldexpf(1.0f, (int)b[108] - 127), sl = __builtin_ldexpf(1.0f, (int)b[124] - 127);
   hi6 = mx_e2m3_value(code(64, 96)) * sh;
   lo6 = mx_e2m3_value(code(80, 112)) * sl;
 }

@@ -1,6 +1,7 @@
 // VGG16 conv1_1..conv5_3 on gfx950: NHWC activations, 3x3 convolutions as implicit-GEMM on the
 // shared MFMA core (gemm_core.h), bias + ReLU + 2x2 max-pool fused into the epilogue.
 // Reference behaviour: ibl/models/vgg.py:40-42 (layer list), :61-70 (forward).
+#include "conv_halo.h"
 #include "conv_ring.h"
 #include "gemm_core.h"
 
@@ -823,12 +824,82 @@ static int launch_conv(const ConvParams& p, int pool, hipStream_t st) {
 
 // f16mx: the ring kernels are the only implementation (Cin % 64 == 0, Cout % 128 == 0 — every layer
 // of the backbone behind the stem)
-static int g_mx_variant = 0;  // test hook: 1 = LDS-DMA issue in the LOAD segment (RING_MX_EARLY)
+// Patch of the halo kernel (conv_halo.h) for an Hn x Wn map: PH, PW even, PH * PW <= 256 pixels,
+// (PH + 2) * (PW + 2) <= 344 halo lines; fewest patches first, then the smaller halo.
+static void halo_patch(int Hn, int Wn, int* PH, int* PW) {
+  long best = -1;
+  int bh = 2, bw = 2, bhalo = 0;
+  for (int ph = 2; ph <= 128; ph += 2) {
+    int pwmax = 256 / ph;
+    const int hcap = HALO_MAX_POS / (ph + 2) - 2;
+    if (hcap < pwmax) pwmax = hcap;
+    pwmax &= ~1;
+    if (pwmax < 2) continue;
+    const int tx = (Wn + pwmax - 1) / pwmax;
+    int pw = ((Wn + tx - 1) / tx + 1) & ~1;  // the narrowest even width that still needs tx patches
+    if (pw > pwmax) pw = pwmax;
+    const long cost = (long)((Hn + ph - 1) / ph) * tx;
+    const int halo = (ph + 2) * (pw + 2);
+    if (best < 0 || cost < best || (cost == best && halo < bhalo)) {
+      best = cost;
+      bh = ph;
+      bw = pw;
+      bhalo = halo;
+    }
+  }
+  *PH = bh;
+  *PW = bw;
+}
+
+template <bool POOL>
+static int launch_conv_halo(const ConvParams& p, hipStream_t st) {
+  using G = RingGeo<2>;
+  HaloParams q = {};
+  q.in = p.in;
+  q.w = p.w;
+  q.bias = p.bias;
+  q.out = p.out;
+  q.in_bytes = (unsigned)((size_t)p.N * p.H * p.W * p.cin * 4);
+  q.w_bytes = (unsigned)((size_t)9 * p.cout * p.cin * 4);
+  q.N = p.N;
+  q.H = p.H;
+  q.W = p.W;
+  q.cin = p.cin;
+  q.cout = p.cout;
+  const int Hn = POOL ? (p.H / 2) * 2 : p.H, Wn = POOL ? (p.W / 2) * 2 : p.W;
+  halo_patch(Hn, Wn, &q.PH, &q.PW);
+  q.tiles_y = (Hn + q.PH - 1) / q.PH;
+  q.tiles_x = (Wn + q.PW - 1) / q.PW;
+  const long tiles_m = (long)p.N * q.tiles_y * q.tiles_x;
+  q.tiles_n = p.cout / G::BN;
+  OIBL_REQUIRE(tiles_m * q.tiles_n <= 0x7fffffffL, "conv3x3 (halo): grid out of range");
+  q.tiles_m = (int)tiles_m;
+  q.raster = g_ring_raster;
+  ring_magic_u31((unsigned)(q.tiles_y * q.tiles_x), &q.img_mul, &q.img_sh);
+  ring_magic_u31((unsigned)q.tiles_x, &q.tx_mul, &q.tx_sh);
+  ring_magic_u31((unsigned)(POOL ? q.PW / 2 : q.PW), &q.pw_mul, &q.pw_sh);
+  ring_magic_u31((unsigned)(q.PW + 2), &q.hp_mul, &q.hp_sh);
+  q.relu = p.relu;
+  q.out_f32 = p.out_f32;
+  auto kern = conv3x3_halo_kernel<POOL, RING_MX_EARLY>;
+  OIBL_SET_MAX_LDS(kern, HALO_LDS);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * q.tiles_n)), dim3(512), HALO_LDS, st, q);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
+
+// f16mx: halo kernel (conv_halo.h) for the 256-channel-tile layers, ring kernels for the rest (Cin % 64 ==
+// 0, Cout % 128 == 0 — every layer of the backbone behind the stem).
+// g_mx_variant (test hook): 0 = that; 1 = ring kernels everywhere; 2 = ring kernels with the LDS-DMA issue
+// inside COMPUTE (RING_MX); 4..7 = timing experiments (wrong results).
+static int g_mx_variant = 0;
 static int launch_conv_mx(const ConvParams& p, int pool, hipStream_t st) {
   const int rv = (pool && p.out_f32) ? 0 : ring_variant(p, 4);
-  if (g_mx_variant == 1) {
-    if (rv == 2) return pool ? launch_conv_ring<2, true, RING_MX_EARLY>(p, st) : launch_conv_ring<2, false, RING_MX_EARLY>(p, st);
-    if (rv == 4) return pool ? launch_conv_ring<4, true, RING_MX_EARLY>(p, st) : launch_conv_ring<4, false, RING_MX_EARLY>(p, st);
+  if (g_mx_variant == 0 && rv == 2 && ((p.cin >> 5) & 1) == 0)
+    return pool ? launch_conv_halo<true>(p, st) : launch_conv_halo<false>(p, st);
+  if (g_mx_variant == 2) {
+    if (rv == 2) return pool ? launch_conv_ring<2, true, RING_MX>(p, st) : launch_conv_ring<2, false, RING_MX>(p, st);
+    if (rv == 4) return pool ? launch_conv_ring<4, true, RING_MX>(p, st) : launch_conv_ring<4, false, RING_MX>(p, st);
   }
   if (g_mx_variant >= 4 && g_mx_variant <= 7 && rv == 2 && !pool) {   // timing experiments (wrong results)
     switch (g_mx_variant) {
@@ -838,8 +909,8 @@ static int launch_conv_mx(const ConvParams& p, int pool, hipStream_t st) {
       default: return launch_conv_ring<2, false, RING_MX_NOBAR>(p, st);
     }
   }
-  if (rv == 2) return pool ? launch_conv_ring<2, true, RING_MX>(p, st) : launch_conv_ring<2, false, RING_MX>(p, st);
-  if (rv == 4) return pool ? launch_conv_ring<4, true, RING_MX>(p, st) : launch_conv_ring<4, false, RING_MX>(p, st);
+  if (rv == 2) return pool ? launch_conv_ring<2, true, RING_MX_EARLY>(p, st) : launch_conv_ring<2, false, RING_MX_EARLY>(p, st);
+  if (rv == 4) return pool ? launch_conv_ring<4, true, RING_MX_EARLY>(p, st) : launch_conv_ring<4, false, RING_MX_EARLY>(p, st);
   set_error("conv3x3 (f16mx): unsupported layer cin=%d cout=%d (needs Cin %% 64 == 0, Cout %% 128 == 0)", p.cin,
             p.cout);
   return OIBL_E_UNSUPPORTED;

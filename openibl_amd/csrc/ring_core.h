@@ -211,8 +211,11 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
   auto read_frag = [&](const char* s, int kk) __attribute__((always_inline)) -> bf16x8_t {
     if constexpr (MX) {
       if (kk == 3) {
-        const uint2 d = *reinterpret_cast<const uint2*>(s + frag_off[3]);
-        const unsigned sc = *reinterpret_cast<const unsigned*>(s + frag_off[3] + 8);
+        // (an ext_vector load, not HIP's uint2 struct: a struct load carries no TBAA, and the compiler
+        //  drains the LDS-DMA queue — s_waitcnt vmcnt(0) — in front of every LDS read without it)
+        typedef __attribute__((ext_vector_type(2))) unsigned u2;
+        const u2 d = *reinterpret_cast<const u2*>(s + frag_off[3]);
+        const unsigned sc = *reinterpret_cast<const unsigned*>(s + frag_off[3] + 12);
         typedef __attribute__((ext_vector_type(4))) unsigned u4;
         return __builtin_bit_cast(bf16x8_t, (u4){d.x, d.y, sc, 0u});
       }

@@ -62,6 +62,16 @@ def _mx_out(y, which=0):
     return ops.nhwc_to_nchw_f32(ops.mx_join(y, which)).cpu()
 
 
+@pytest.fixture(params=[0, 1, 2], ids=["halo", "ring", "ring-late"])
+def mx_variant(request):
+    """0 = default dispatch (halo kernel for the 256-channel-tile layers, ring kernels for the rest), 1 = ring
+    kernels everywhere, 2 = ring kernels with the LDS-DMA issue inside the COMPUTE segments."""
+    from openibl_amd import lib
+    lib.load().oibl_debug_set_mx_variant(request.param)
+    yield request.param
+    lib.load().oibl_debug_set_mx_variant(0)
+
+
 @pytest.mark.parametrize("N,H,W,cin,cout,relu,pool", [
     (1, 9, 7, 64, 128, True, False),      # 512 x 128 tile, one partial tile, 18 K-tiles
     (1, 9, 7, 128, 128, True, True),      # odd sizes + pooling floors
@@ -73,8 +83,12 @@ def _mx_out(y, which=0):
     (2, 40, 30, 256, 128, False, False),  # 512 x 128 tile: several M tiles
     (2, 40, 30, 64, 128, True, False),    # conv2_1 family
     (1, 17, 23, 128, 256, True, True),
+    (2, 30, 40, 512, 512, True, False),   # conv5 shape: 6 x 40 patches of the halo kernel, two images
+    (1, 60, 80, 256, 512, True, True),    # conv4_3-like: 12 x 20 patches, pooled
+    (2, 31, 45, 128, 256, True, True),    # odd sizes: patches cut by both borders, pooling floors
+    (1, 120, 160, 128, 256, True, False),  # conv3_1 shape: 8 x 32 patches
 ])
-def test_conv3x3_mx(dev, N, H, W, cin, cout, relu, pool):
+def test_conv3x3_mx(dev, N, H, W, cin, cout, relu, pool, mx_variant):
     x, w, b = _case(N, H, W, cin, cout, seed=H * 1000 + cin)
     wp = ops.pack_conv3x3(w.to(dev), "f16mx")
     assert wp.dtype == torch.int32 and tuple(wp.shape) == (9, cout, cin)
