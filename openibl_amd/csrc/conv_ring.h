@@ -290,7 +290,8 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
   }
 
   const unsigned long long t_loop = prof ? __builtin_amdgcn_s_memtime() : 0;
-  ring_mainloop<WM, ODD, !POOL, P>(acc, smem, wave, lane, la, lb, nsteps);
+  ring_mainloop<WM, ODD, !POOL, P>(acc, smem, wave, lane, la, lb, nsteps,
+                                   (P == RING_MX_PROF && blockIdx.x == 0 && p.prof) ? p.prof + 8 : nullptr);
   // (the main loop ends on a workgroup barrier: the staging LDS is free for the epilogue)
   const unsigned long long t_epi = prof ? __builtin_amdgcn_s_memtime() : 0;
 

@@ -65,6 +65,8 @@ constexpr int RING_MX = 2;    // f16mx rows (common.h), 32 K per K-tile, 4 f16 +
 constexpr int RING_MX_EARLY = 3;  // the same with the LDS-DMA issue in the LOAD segment (as bf16 / bf16x3)
 // timing experiments on the RING_MX_EARLY stream (WRONG results): one ingredient of the loop removed
 constexpr int RING_MX_NOMFMA = 4, RING_MX_NODMA = 5, RING_MX_NOREAD = 6, RING_MX_NOBAR = 7;
+// RING_MX_EARLY with shader-clock stamps of phases P0 / P1 of the last steady-state K-tile (diagnostic)
+constexpr int RING_MX_PROF = 8;
 
 // Geometry of one instantiation.  WM = wave rows (2 or 4); the 8 waves form a WM x (8 / WM) grid,
 // every wave owns 128 x 64 outputs, so the tile is 256 x 256 (WM = 2) or 512 x 128 (WM = 4).
@@ -162,7 +164,7 @@ struct RingRowLoader {
 // On return every wave has passed a workgroup barrier: the staging LDS is free.
 template <int WM, bool ODD, bool SWAP, int P = RING_BF16, typename LA, typename LB>
 __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, int wave, int lane,
-                                            LA& la, LB& lb, int nsteps) {
+                                            LA& la, LB& lb, int nsteps, unsigned long long* stamps = nullptr) {
   using G = RingGeo<WM>;
   constexpr int NA = G::NA, NB = G::NB;
   constexpr int OFF_A0 = 0, OFF_A1 = G::A_UNIT, OFF_B0 = 2 * G::A_UNIT,
@@ -187,12 +189,15 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
     lb.stage(h, st_base + buf * G::TILE + (h ? OFF_B1 : OFF_B0));
   };
 
-  constexpr bool X3 = P == RING_X3, MX = P >= RING_MX;
+  constexpr bool X3 = P == RING_X3, MX = P >= RING_MX;   // (every code >= RING_MX is an f16mx stream)
   // LATE: with 6 MFMAs (192 cycles) per phase the LOAD segment (fragment reads + 2-4 LDS-DMA issues at
   // 100-185 cycles each next to the reads) is longer than the COMPUTE segment it is paired with, so the
   // DMA issue moves into COMPUTE, between the MFMAs (~60 cycles each there); every counted wait then
   // sits BEFORE its phase's issues and allows that many fewer instructions in flight.
   constexpr bool LATE = P == RING_MX;
+  constexpr bool PROF = P == RING_MX_PROF;
+  unsigned long long st_[14] = {};
+#define RING_STAMP(i) do { if constexpr (PROF && TAIL == 0) st_[i] = __builtin_amdgcn_s_memtime(); } while (0)
   int frag_off[4];
   {
     const int row = lane & 31, half = lane >> 5, swz = (lane >> 1) & 7;
@@ -340,65 +345,74 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
     bf16x8_t(&b1)[4] = PAR ? fbx : fby;  // B1 of this tile; from P3 on: B0 of the next tile
     // A phase = reads; [early: issues;] counted wait; barrier; COMPUTE [late: issues inside]; barrier.
     // `cnt` = what the wait allows in flight when it stands AFTER the phase's `n_issue` instructions.
-    auto phase = [&](auto cnt_c, auto n_issue_c, auto h_c, auto j_c, const bf16x8_t (&fb)[4], auto&& issue)
-        __attribute__((always_inline)) {
+    auto phase = [&](auto cnt_c, auto n_issue_c, auto h_c, auto j_c, const bf16x8_t (&fb)[4], auto&& issue,
+                     auto sb_c) __attribute__((always_inline)) {
       constexpr int CNT = decltype(cnt_c)::value, NI = decltype(n_issue_c)::value;
+      constexpr int SB = decltype(sb_c)::value;   // first stamp slot of this phase, -1 = none
       if constexpr (!LATE) {
+        if constexpr (SB >= 0) RING_STAMP(SB + 1);       // reads issued
         issue();
+        if constexpr (SB >= 0) RING_STAMP(SB + 2);       // LDS-DMA issued
         if constexpr (CNT >= 0) wait_vmcnt<CNT>();
+        if constexpr (SB >= 0) RING_STAMP(SB + 3);       // counted wait passed
         bar();
+        if constexpr (SB >= 0) RING_STAMP(SB + 4);       // barrier passed: COMPUTE starts
         compute(h_c, j_c, fb, [] {});
+        if constexpr (SB >= 0) RING_STAMP(SB + 5);       // MFMAs issued
       } else {
         if constexpr (CNT >= 0) wait_vmcnt<(CNT - NI)>();
         bar();
         compute(h_c, j_c, fb, issue);
       }
       bar();
+      if constexpr (SB >= 0) RING_STAMP(SB + 6);         // closing barrier passed
     };
 #define RING_IC(x) std::integral_constant<int, (x)> {}
     constexpr int HA = SPLIT ? NA / 2 : NA;   // instructions of the A issue in P0 / P2
     constexpr int HB = SPLIT ? NA / 2 : 0;    // A instructions issued next to the B unit in P1 / P3
     // P0: A0 x B0
+    RING_STAMP(0);
     read_a(PAR, 0);
     if constexpr (TAIL <= 1)
       phase(RING_IC(3 * NA + 2 * NB - (SPLIT ? NA / 2 : 0)), RING_IC(HA), I0{}, I0{}, b0,
-            [&] { stage_a(PAR ^ 1, 1, 0); });  // A1(t+1) (SPLIT: its first half)
+            [&] { stage_a(PAR ^ 1, 1, 0); }, RING_IC(0));  // A1(t+1) (SPLIT: its first half)
     else
-      phase(RING_IC(NA), RING_IC(0), I0{}, I0{}, b0, [] {});
+      phase(RING_IC(NA), RING_IC(0), I0{}, I0{}, b0, [] {}, RING_IC(-1));
     // P1: A0 x B1
+    RING_STAMP(7);
     read_b(PAR, 1, b1);
     if constexpr (TAIL == 0)
       phase(RING_IC(2 * NA + 3 * NB), RING_IC(HB + NB), I0{}, I1{}, b1, [&] {
         stage_a(PAR ^ 1, 1, 1);  // SPLIT: second half of A1(t+1)
         lb.begin_tile();
         stage_b(PAR, 0);  // B0(t+2)
-      });
+      }, RING_IC(7));
     else if constexpr (TAIL == 1)
-      phase(RING_IC(2 * NA + 2 * NB), RING_IC(HB), I0{}, I1{}, b1, [&] { stage_a(PAR ^ 1, 1, 1); });
+      phase(RING_IC(2 * NA + 2 * NB), RING_IC(HB), I0{}, I1{}, b1, [&] { stage_a(PAR ^ 1, 1, 1); }, RING_IC(-1));
     else
-      phase(RING_IC(0), RING_IC(0), I0{}, I1{}, b1, [] {});
+      phase(RING_IC(0), RING_IC(0), I0{}, I1{}, b1, [] {}, RING_IC(-1));
     // P2: A1 x B1
     read_a(PAR, 1);
     if constexpr (TAIL == 0)
       phase(RING_IC(3 * NA + 2 * NB - (SPLIT ? NA / 2 : 0)), RING_IC(HA), I1{}, I1{}, b1, [&] {
         la.begin_tile();
         stage_a(PAR, 0, 0);  // A0(t+2) (SPLIT: its first half)
-      });
+      }, RING_IC(-1));
     else if constexpr (TAIL == 1)
-      phase(RING_IC(2 * NA + NB), RING_IC(0), I1{}, I1{}, b1, [] {});
+      phase(RING_IC(2 * NA + NB), RING_IC(0), I1{}, I1{}, b1, [] {}, RING_IC(-1));
     else
-      phase(RING_IC(-1), RING_IC(0), I1{}, I1{}, b1, [] {});
+      phase(RING_IC(-1), RING_IC(0), I1{}, I1{}, b1, [] {}, RING_IC(-1));
     // P3: A1 x B0   (B0 of the next tile goes into the register set B1 just vacated)
     if constexpr (TAIL <= 1) read_b(PAR ^ 1, 0, b1);
     if constexpr (TAIL == 0)
       phase(RING_IC(2 * NA + 3 * NB), RING_IC(HB + NB), I1{}, I0{}, b0, [&] {
         stage_a(PAR, 0, 1);  // SPLIT: second half of A0(t+2)
         stage_b(PAR, 1);     // B1(t+2)
-      });
+      }, RING_IC(-1));
     else if constexpr (TAIL == 1)
-      phase(RING_IC(NA + NB), RING_IC(0), I1{}, I0{}, b0, [] {});
+      phase(RING_IC(NA + NB), RING_IC(0), I1{}, I0{}, b0, [] {}, RING_IC(-1));
     else
-      phase(RING_IC(-1), RING_IC(0), I1{}, I0{}, b0, [] {});
+      phase(RING_IC(-1), RING_IC(0), I1{}, I0{}, b0, [] {}, RING_IC(-1));
 #undef RING_IC
   };
   for (int t = 0; t + 3 < nsteps; t += 2) {  // pairs of steady-state tiles
@@ -415,6 +429,13 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
   }
   if (group == 0) bar();
   __syncthreads();
+  if constexpr (PROF) {
+    if (stamps != nullptr && lane == 0 && (wave & 3) == 0) {
+#pragma unroll
+      for (int i = 0; i < 14; ++i) stamps[(wave >> 2) * 14 + i] = st_[i];
+    }
+  }
+#undef RING_STAMP
 }
 
 }  // namespace oibl
