@@ -851,6 +851,7 @@ static void halo_patch(int Hn, int Wn, int* PH, int* PW) {
   *PW = bw;
 }
 
+static int g_halo_var = 0;  // experiment: 3 = the waits that count the halo instructions (rarely wrong: conv_halo.h)
 template <bool POOL>
 static int launch_conv_halo(const ConvParams& p, hipStream_t st) {
   using G = RingGeo<2>;
@@ -881,9 +882,16 @@ static int launch_conv_halo(const ConvParams& p, hipStream_t st) {
   ring_magic_u31((unsigned)(q.PW + 2), &q.hp_mul, &q.hp_sh);
   q.relu = p.relu;
   q.out_f32 = p.out_f32;
-  auto kern = conv3x3_halo_kernel<POOL, RING_MX_EARLY>;
-  OIBL_SET_MAX_LDS(kern, HALO_LDS);
-  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * q.tiles_n)), dim3(512), HALO_LDS, st, q);
+  const dim3 grid((unsigned)(tiles_m * q.tiles_n));
+  if (g_halo_var == 3) {
+    auto kern = conv3x3_halo_kernel<POOL, RING_MX_EARLY, 3>;
+    OIBL_SET_MAX_LDS(kern, HALO_LDS);
+    hipLaunchKernelGGL(kern, grid, dim3(512), HALO_LDS, st, q);
+  } else {
+    auto kern = conv3x3_halo_kernel<POOL, RING_MX_EARLY>;
+    OIBL_SET_MAX_LDS(kern, HALO_LDS);
+    hipLaunchKernelGGL(kern, grid, dim3(512), HALO_LDS, st, q);
+  }
   OIBL_LAUNCH_CHECK();
   return OIBL_OK;
 }
@@ -2358,6 +2366,8 @@ int oibl_debug_set_conv_splitk(int on) {
 }
 
 int oibl_debug_set_mx_variant(int v) {
+  g_halo_var = v >= 16 ? v - 16 : 0;   // 19: halo kernel with the unsafe waits (experiment)
+  if (v >= 16) v = 0;
   g_mx_variant = v;
   return OIBL_OK;
 }
