@@ -896,14 +896,15 @@ static int launch_conv_halo(const ConvParams& p, hipStream_t st) {
   return OIBL_OK;
 }
 
-// f16mx: halo kernel (conv_halo.h) for the 256-channel-tile layers, ring kernels for the rest (Cin % 64 ==
-// 0, Cout % 128 == 0 — every layer of the backbone behind the stem).
-// g_mx_variant (test hook): 0 = that; 1 = ring kernels everywhere; 2 = ring kernels with the LDS-DMA issue
-// inside COMPUTE (RING_MX); 4..7 = timing experiments (wrong results).
+// f16mx: ring kernels (Cin % 64 == 0, Cout % 128 == 0 — every layer of the backbone behind the stem).
+// g_mx_variant (test hook): 0 = that; 3 = the halo kernel (conv_halo.h) for the 256-channel-tile layers —
+// 0.58x the LDS-DMA bytes, +5 % on conv3_x, -5 % on conv4_x / conv5_x since the ring's K cursor left its
+// LOAD segments (profiles/r03_*): kept as the tested alternative; 2 = ring kernels with the LDS-DMA issue
+// inside COMPUTE (RING_MX); 4..8 = timing experiments (wrong results) / stamps.
 static int g_mx_variant = 0;
 static int launch_conv_mx(const ConvParams& p, int pool, hipStream_t st) {
   const int rv = (pool && p.out_f32) ? 0 : ring_variant(p, 4);
-  if (g_mx_variant == 0 && rv == 2 && ((p.cin >> 5) & 1) == 0)
+  if (g_mx_variant == 3 && rv == 2 && ((p.cin >> 5) & 1) == 0)
     return pool ? launch_conv_halo<true>(p, st) : launch_conv_halo<false>(p, st);
   if (g_mx_variant == 2) {
     if (rv == 2) return pool ? launch_conv_ring<2, true, RING_MX>(p, st) : launch_conv_ring<2, false, RING_MX>(p, st);
@@ -2367,7 +2368,7 @@ int oibl_debug_set_conv_splitk(int on) {
 
 int oibl_debug_set_mx_variant(int v) {
   g_halo_var = v >= 16 ? v - 16 : 0;   // 19: halo kernel with the unsafe waits (experiment)
-  if (v >= 16) v = 0;
+  if (v >= 16) v = 3;
   g_mx_variant = v;
   return OIBL_OK;
 }

@@ -69,9 +69,9 @@ struct HaloParams {
 };
 
 // one phase's matrix work on two 32x32 accumulator tiles (ring_core.h, compute)
-template <int P, bool SWAP>
+template <int P, bool SWAP, typename Prep>
 __device__ static inline void halo_phase_mma(f32x16_t& acc0, f32x16_t& acc1, const bf16x8_t (&fa)[2][4],
-                                             const bf16x8_t (&fb)[4]) {
+                                             const bf16x8_t (&fb)[4], Prep&& prep) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_setprio(1);
@@ -92,6 +92,7 @@ __device__ static inline void halo_phase_mma(f32x16_t& acc0, f32x16_t& acc1, con
     };
     f16(acc0, 0, 0);
     f16(acc1, 1, 0);
+    prep();   // scalar work of the next LOAD segment, in the shadow of the matrix pipe (ring_core.h)
     f16(acc0, 0, 1);
     f16(acc1, 1, 1);
     mx(acc0, 0);
@@ -105,6 +106,7 @@ __device__ static inline void halo_phase_mma(f32x16_t& acc0, f32x16_t& acc1, con
     };
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
+      if (pr == 1) prep();
       mma(acc0, 0, pr + 2, pr);
       mma(acc1, 1, pr + 2, pr);
       mma(acc0, 0, pr, pr + 2);
@@ -349,26 +351,25 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(HaloParams p) {
     // waits allow only the 2 x NB younger WEIGHT instructions in flight — and every dummy is an in-range load.
     wait_vmcnt<(VAR == 3 ? 1 + 2 * NB + 1 : 2 * NB)>();
     bar();
-    halo_phase_mma<P, SWAP>(acc[0][0], acc[1][0], fa, b0);
-    bar();
+    halo_phase_mma<P, SWAP>(acc[0][0], acc[1][0], fa, b0, [&] { lb.begin_tile(); });  // (cursor -> K-tile t+2;
+    bar();                                      //  unconditional: advanced under a branch it ends up in a VGPR)
     // P1: A0 x B1
     read_b(PAR, 1, b1);
-    lb.begin_tile();        // (unconditional: a cursor advanced under a branch ends up in a VGPR)
     stage_b(PAR, 0, more);  // B0(t+2)
     bar();
-    halo_phase_mma<P, SWAP>(acc[0][1], acc[1][1], fa, b1);
+    halo_phase_mma<P, SWAP>(acc[0][1], acc[1][1], fa, b1, [] {});
     bar();
     // P2: A1 x B1
     read_a(hb, I1{}, tap_c);
     wait_vmcnt<(VAR == 3 ? 2 * NB + 1 : 2 * NB)>();
     bar();
-    halo_phase_mma<P, SWAP>(acc[2][1], acc[3][1], fa, b1);
+    halo_phase_mma<P, SWAP>(acc[2][1], acc[3][1], fa, b1, [] {});
     bar();
     // P3: A1 x B0   (B0 of the next K-tile goes into the register set B1 just vacated)
     read_b(PAR ^ 1, 0, b1);
     stage_b(PAR, 1, more);  // B1(t+2)
     bar();
-    halo_phase_mma<P, SWAP>(acc[2][0], acc[3][0], fa, b0);
+    halo_phase_mma<P, SWAP>(acc[2][0], acc[3][0], fa, b0, [] {});
     bar();
     (void)TAP;
   };

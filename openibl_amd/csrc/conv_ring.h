@@ -78,15 +78,15 @@ struct ConvRingALoader {
   __amdgpu_buffer_rsrc_t rsrc;
   unsigned base[2 * NA], mask[2 * NA], cur[2 * NA];
   unsigned soff, abl_piece;
-  int tap, cc, cchunks, W, pix_bytes, ablate, korder;
+  int in, out, per, W, pix_bytes, ablate, korder;   // K cursor: inner / outer counter, inner period
   __device__ inline void init(const RingParams& p, int m0, const int (&tile_row)[2 * NA], int piece) {
     korder = p.korder;
     rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
     pix_bytes = p.cin * (X3 ? 4 : 2);
-    cchunks = p.cin >> (X3 ? 5 : 6);
+    per = korder ? 9 : (p.cin >> (X3 ? 5 : 6));
     W = p.W;
-    tap = korder ? -1 : 0;
-    cc = korder ? 0 : -1;
+    in = -1;
+    out = -1;
     soff = 0;
     ablate = p.ablate & 1;
     abl_piece = (unsigned)piece;
@@ -119,31 +119,22 @@ struct ConvRingALoader {
     }
   }
   // K order.  korder 0 (default): tap outer, channel chunk inner — per K-tile only the scalar chunk
-  // offset changes, the per-lane offsets change once per tap.  korder 1 (test hook): chunk outer,
-  // tap inner — the nine taps of one 128-byte chunk are consecutive K-tiles, so horizontally
-  // adjacent taps re-read their lines from the XCD's L2.  Measured (profiles/r02_*): korder 1 cuts
-  // the fetched bytes 3-8x (every tap of korder 0 misses L2 once 32 workgroups x 9 taps of
-  // footprint exceed 4 MiB) and is nevertheless 3-12 % SLOWER in bf16 and 2-5 % slower in bf16x3
-  // on all layers but one: the kernels are not bound by fetch volume (Infinity-Cache hits are
-  // cheap), while korder 0 streams each pixel's channel run as consecutive lines.
+  // offset changes, the per-lane offsets change once per tap.  korder 1: chunk outer, tap inner — the
+  // nine taps of one 128-byte chunk are consecutive K-tiles, so horizontally adjacent taps re-read
+  // their lines from the XCD's L2.  Measured (profiles/r02_*): korder 1 cuts the fetched bytes 3-8x
+  // (every tap of korder 0 misses L2 once 32 workgroups x 9 taps of footprint exceed 4 MiB) and is
+  // nevertheless 3-12 % SLOWER in bf16 and 2-5 % slower in bf16x3 on all layers but one: the kernels are
+  // not bound by fetch volume (Infinity-Cache hits are cheap), while korder 0 streams each pixel's
+  // channel run as consecutive lines.
+  // The cursor is ONE inner counter with a period and an outer counter, advanced without branches
+  // (a handful of scalar instructions: this runs between the MFMAs of a COMPUTE segment, ring_core.h);
+  // only the per-lane tap offsets — 5 vector instructions per row, once per tap — sit behind a branch.
   __device__ inline void begin_tile() {
-    bool new_tap;
-    if (korder == 0) {
-      ++cc;
-      if (cc == cchunks) {
-        cc = 0;
-        ++tap;
-      }
-      new_tap = cc == 0;
-    } else {
-      ++tap;
-      if (tap == 9) {
-        tap = 0;
-        ++cc;
-      }
-      new_tap = true;
-    }
-    if (new_tap) {
+    const bool wrap = in == per - 1;
+    in = wrap ? 0 : in + 1;
+    out += (in == 0) ? 1 : 0;
+    const int tap = korder ? in : out, cc = korder ? out : in;
+    if (korder != 0 || in == 0) {
       const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
       const int toff = ((ky - 1) * W + (kx - 1)) * pix_bytes;
 #pragma unroll
@@ -168,42 +159,38 @@ template <int NB, bool X3 = false>
 struct ConvRingBLoader {
   __amdgpu_buffer_rsrc_t rsrc;
   unsigned off[2 * NB];
-  unsigned soff, tap_stride, abl_piece;
-  int tap, cc, cchunks, ablate, korder;
+  unsigned soff, step_in, step_wrap;   // K cursor as a running byte offset: + step_in, or + step_wrap when
+  int in, per;                         // the inner counter (period `per`) wraps — no branches
   __device__ inline void init(const RingParams& p, int n0, const int (&tile_row)[2 * NB], int piece) {
-    korder = p.korder;
     rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
     const unsigned pix_bytes = (unsigned)p.cin * (X3 ? 4u : 2u);
-    cchunks = p.cin >> (X3 ? 5 : 6);
-    tap_stride = (unsigned)p.cout * pix_bytes;
-    tap = korder ? -1 : 0;
-    cc = korder ? 0 : -1;
-    soff = 0;
-    ablate = p.ablate & 2;
-    abl_piece = (unsigned)piece;
+    const unsigned cchunks = (unsigned)(p.cin >> (X3 ? 5 : 6));
+    const unsigned tap_stride = (unsigned)p.cout * pix_bytes;
+    // offset of K-tile (tap, cc) = tap * tap_stride + cc * 128, same K order as the A loader
+    if (p.korder == 0) {   // (tap, chunk): chunk inner
+      per = (int)cchunks;
+      step_in = 128u;
+      step_wrap = tap_stride - (cchunks - 1u) * 128u;
+    } else {               // (chunk, tap): tap inner
+      per = 9;
+      step_in = tap_stride;
+      step_wrap = 128u - 8u * tap_stride;
+    }
+    in = -1;
+    soff = 0u - step_in;
 #pragma unroll
     for (int j = 0; j < 2 * NB; ++j) off[j] = (unsigned)(n0 + tile_row[j]) * pix_bytes + piece;
-  }
-  __device__ inline void begin_tile() {  // same K order as the A loader
-    if (korder == 0) {
-      ++cc;
-      if (cc == cchunks) {
-        cc = 0;
-        ++tap;
-      }
-    } else {
-      ++tap;
-      if (tap == 9) {
-        tap = 0;
-        ++cc;
-      }
-    }
-    soff = (unsigned)tap * tap_stride + (unsigned)cc * 128u;
-    if (ablate && (tap != 0 || cc != 0)) {
-      soff = 0;
+    if (p.ablate & 2) {    // timing experiment: every K-tile reads ONE line (wrong results)
+      step_in = step_wrap = 0u;
+      soff = 0u;
 #pragma unroll
-      for (int j = 0; j < 2 * NB; ++j) off[j] = abl_piece;
+      for (int j = 0; j < 2 * NB; ++j) off[j] = (unsigned)piece;
     }
+  }
+  __device__ inline void begin_tile() {
+    const bool wrap = in == per - 1;
+    in = wrap ? 0 : in + 1;
+    soff += wrap ? step_wrap : step_in;
   }
   __device__ inline void stage(int h, char* dst, int i0 = 0, int i1 = NB) const {
 #pragma unroll

@@ -284,6 +284,7 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
     } else if constexpr (X3) {
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {
+        if (pr == 1) issue();
 #pragma unroll
         for (int i2 = 0; i2 < 2; ++i2) mma(i2, pr + 2, pr);  // lo . hi
 #pragma unroll
@@ -293,9 +294,11 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
       }
     } else {
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
+      for (int kk = 0; kk < 4; ++kk) {
+        if (kk == 1) issue();
 #pragma unroll
         for (int i2 = 0; i2 < 2; ++i2) mma(i2, kk, kk);
+      }
     }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
@@ -345,8 +348,11 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
     bf16x8_t(&b1)[4] = PAR ? fbx : fby;  // B1 of this tile; from P3 on: B0 of the next tile
     // A phase = reads; [early: issues;] counted wait; barrier; COMPUTE [late: issues inside]; barrier.
     // `cnt` = what the wait allows in flight when it stands AFTER the phase's `n_issue` instructions.
+    // `prep` (EARLY schedules): the K-cursor advance of the NEXT phase's issue — scalar code with branches,
+    // ~100 cycles at the head of a LOAD segment (RING_MX_PROF: LDS-DMA issue 172 cycles in P1 against 64
+    // in P0) — runs between the MFMAs of this phase instead, where the wave waits for the matrix pipe anyway.
     auto phase = [&](auto cnt_c, auto n_issue_c, auto h_c, auto j_c, const bf16x8_t (&fb)[4], auto&& issue,
-                     auto sb_c) __attribute__((always_inline)) {
+                     auto sb_c, auto&& prep) __attribute__((always_inline)) {
       constexpr int CNT = decltype(cnt_c)::value, NI = decltype(n_issue_c)::value;
       constexpr int SB = decltype(sb_c)::value;   // first stamp slot of this phase, -1 = none
       if constexpr (!LATE) {
@@ -357,7 +363,7 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
         if constexpr (SB >= 0) RING_STAMP(SB + 3);       // counted wait passed
         bar();
         if constexpr (SB >= 0) RING_STAMP(SB + 4);       // barrier passed: COMPUTE starts
-        compute(h_c, j_c, fb, [] {});
+        compute(h_c, j_c, fb, prep);
         if constexpr (SB >= 0) RING_STAMP(SB + 5);       // MFMAs issued
       } else {
         if constexpr (CNT >= 0) wait_vmcnt<(CNT - NI)>();
@@ -375,44 +381,45 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
     read_a(PAR, 0);
     if constexpr (TAIL <= 1)
       phase(RING_IC(3 * NA + 2 * NB - (SPLIT ? NA / 2 : 0)), RING_IC(HA), I0{}, I0{}, b0,
-            [&] { stage_a(PAR ^ 1, 1, 0); }, RING_IC(0));  // A1(t+1) (SPLIT: its first half)
+            [&] { stage_a(PAR ^ 1, 1, 0); }, RING_IC(0),  // A1(t+1) (SPLIT: its first half)
+            [&] { if constexpr (TAIL == 0 && !LATE) lb.begin_tile(); });
     else
-      phase(RING_IC(NA), RING_IC(0), I0{}, I0{}, b0, [] {}, RING_IC(-1));
+      phase(RING_IC(NA), RING_IC(0), I0{}, I0{}, b0, [] {}, RING_IC(-1), [] {});
     // P1: A0 x B1
     RING_STAMP(7);
     read_b(PAR, 1, b1);
     if constexpr (TAIL == 0)
       phase(RING_IC(2 * NA + 3 * NB), RING_IC(HB + NB), I0{}, I1{}, b1, [&] {
         stage_a(PAR ^ 1, 1, 1);  // SPLIT: second half of A1(t+1)
-        lb.begin_tile();
+        if constexpr (LATE) lb.begin_tile();   // (EARLY: advanced in P0's COMPUTE)
         stage_b(PAR, 0);  // B0(t+2)
-      }, RING_IC(7));
+      }, RING_IC(7), [&] { if constexpr (!LATE) la.begin_tile(); });
     else if constexpr (TAIL == 1)
-      phase(RING_IC(2 * NA + 2 * NB), RING_IC(HB), I0{}, I1{}, b1, [&] { stage_a(PAR ^ 1, 1, 1); }, RING_IC(-1));
+      phase(RING_IC(2 * NA + 2 * NB), RING_IC(HB), I0{}, I1{}, b1, [&] { stage_a(PAR ^ 1, 1, 1); }, RING_IC(-1), [] {});
     else
-      phase(RING_IC(0), RING_IC(0), I0{}, I1{}, b1, [] {}, RING_IC(-1));
+      phase(RING_IC(0), RING_IC(0), I0{}, I1{}, b1, [] {}, RING_IC(-1), [] {});
     // P2: A1 x B1
     read_a(PAR, 1);
     if constexpr (TAIL == 0)
       phase(RING_IC(3 * NA + 2 * NB - (SPLIT ? NA / 2 : 0)), RING_IC(HA), I1{}, I1{}, b1, [&] {
-        la.begin_tile();
+        if constexpr (LATE) la.begin_tile();   // (EARLY: advanced in P1's COMPUTE)
         stage_a(PAR, 0, 0);  // A0(t+2) (SPLIT: its first half)
-      }, RING_IC(-1));
+      }, RING_IC(-1), [] {});
     else if constexpr (TAIL == 1)
-      phase(RING_IC(2 * NA + NB), RING_IC(0), I1{}, I1{}, b1, [] {}, RING_IC(-1));
+      phase(RING_IC(2 * NA + NB), RING_IC(0), I1{}, I1{}, b1, [] {}, RING_IC(-1), [] {});
     else
-      phase(RING_IC(-1), RING_IC(0), I1{}, I1{}, b1, [] {}, RING_IC(-1));
+      phase(RING_IC(-1), RING_IC(0), I1{}, I1{}, b1, [] {}, RING_IC(-1), [] {});
     // P3: A1 x B0   (B0 of the next tile goes into the register set B1 just vacated)
     if constexpr (TAIL <= 1) read_b(PAR ^ 1, 0, b1);
     if constexpr (TAIL == 0)
       phase(RING_IC(2 * NA + 3 * NB), RING_IC(HB + NB), I1{}, I0{}, b0, [&] {
         stage_a(PAR, 0, 1);  // SPLIT: second half of A0(t+2)
         stage_b(PAR, 1);     // B1(t+2)
-      }, RING_IC(-1));
+      }, RING_IC(-1), [] {});
     else if constexpr (TAIL == 1)
-      phase(RING_IC(NA + NB), RING_IC(0), I1{}, I0{}, b0, [] {}, RING_IC(-1));
+      phase(RING_IC(NA + NB), RING_IC(0), I1{}, I0{}, b0, [] {}, RING_IC(-1), [] {});
     else
-      phase(RING_IC(-1), RING_IC(0), I1{}, I0{}, b0, [] {}, RING_IC(-1));
+      phase(RING_IC(-1), RING_IC(0), I1{}, I0{}, b0, [] {}, RING_IC(-1), [] {});
 #undef RING_IC
   };
   for (int t = 0; t + 3 < nsteps; t += 2) {  // pairs of steady-state tiles

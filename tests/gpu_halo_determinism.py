@@ -10,7 +10,7 @@ dev = torch.device("cuda", 0)
 L = lib.load()
 g = torch.Generator(device=dev).manual_seed(5)
 import os
-VARIANT = int(os.environ.get("VARIANT", "0"))
+VARIANT = int(os.environ.get("VARIANT", "3"))   # 3 = halo kernel, 19 = its unsafe-wait variant, 0 = ring
 REPS = int(os.environ.get("REPS", "60"))
 print("variant", VARIANT)
 for (N, H, W, cin, cout, pool) in [(32, 120, 160, 256, 256, 1), (32, 60, 80, 512, 512, 0), (32, 60, 80, 512, 512, 1)]:
@@ -19,7 +19,7 @@ for (N, H, W, cin, cout, pool) in [(32, 120, 160, 256, 256, 1), (32, 60, 80, 512
     b = torch.randn((cout,), generator=g, device=dev) * 0.1
     x = ops.mx_split(xf)
     wp = ops.pack_conv3x3(w, "f16mx")
-    L.oibl_debug_set_mx_variant(1)
+    L.oibl_debug_set_mx_variant(0)
     ring = ops.conv3x3_nhwc(x, wp, b, True, bool(pool), "f16mx")
     L.oibl_debug_set_mx_variant(VARIANT)
     ref = ops.conv3x3_nhwc(x, wp, b, True, bool(pool), "f16mx")
