@@ -312,6 +312,7 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
     const long orow_bytes = (long)p.cout * 4;
     const float floor_v = p.relu ? 0.f : -INFINITY;
     unsigned long long t_copy = 0;
+    unsigned long long ep_[6] = {};
 #pragma unroll
     for (int pass = 0; pass < PASSES; ++pass) {
       if constexpr (POOL) {
@@ -347,6 +348,7 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
       }
       __syncthreads();
       if (pass == 0 && prof) t_copy = __builtin_amdgcn_s_memtime();
+      if (prof) ep_[3 * pass] = __builtin_amdgcn_s_memtime();       // staged
       if (!p.out_f32) {
 #pragma unroll 1
         for (int it = 0; it < ITEMS / 512; ++it) {
@@ -370,6 +372,7 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
         }
         __syncthreads();
       }
+      if (prof) ep_[3 * pass + 1] = __builtin_amdgcn_s_memtime();   // packed
 #pragma unroll
       for (int it0 = 0; it0 < ITERS; it0 += BATCH) {
         uint4 v[BATCH];
@@ -388,6 +391,7 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
             *reinterpret_cast<uint4*>(obase + grow * orow_bytes + (idx % CPR) * 16) = v[u];
         }
       }
+      if (prof) ep_[3 * pass + 2] = __builtin_amdgcn_s_memtime();   // stores issued
       if (pass + 1 < PASSES) __syncthreads();
     }
     if (prof) {
@@ -398,6 +402,10 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
         p.prof[1] = t_epi - t_loop;
         p.prof[2] = t_copy - t_epi;
         p.prof[3] = t_end - t_copy;
+        p.prof[4] = ep_[1] - ep_[0];   // pass 0: pack
+        p.prof[5] = ep_[2] - ep_[1];   //         copy-out (issue)
+        p.prof[6] = PASSES > 1 ? ep_[4] - ep_[3] : 0;
+        p.prof[7] = PASSES > 1 ? ep_[5] - ep_[4] : 0;
       }
     }
     return;

@@ -23,7 +23,8 @@ torch.cuda.synchronize()
 L.oibl_debug_set_prof_buffer(None)
 L.oibl_debug_set_mx_variant(0)
 t = buf.cpu().tolist()
-print("kernel sections (wave 0):", t[:4], " main loop per K-tile:", t[1] / 144.0)
+print("kernel sections (wave 0): prologue, loop, regs->LDS, rest of the epilogue:", t[:4], " main loop per K-tile:", t[1] / 144.0)
+print("epilogue, pass 0: pack", t[4], "copy-out (stores issued)", t[5], "| pass 1: pack", t[6], "copy-out", t[7])
 names = ["phase start", "reads issued", "LDS-DMA issued", "vmcnt wait passed", "barrier passed", "MFMAs issued", "closing barrier passed"]
 for gidx in (0, 1):
     st = t[8 + 14 * gidx: 8 + 14 * gidx + 14]
