@@ -13,7 +13,9 @@
  *     the name ends in _host.
  *   - `stream` is a hipStream_t passed as void*; every call is asynchronous and
  *     stream-ordered; re-entrant across streams (no hidden global state besides the
- *     thread-local error string).
+ *     thread-local error string: the shipping library has no mutable statics on any launch path — the
+ *     test hooks exist only in libopenibl_amd_dbg.so, built from the same sources with
+ *     -DOIBL_DEBUG_HOOKS).
  *   - no hidden allocation: outputs and scratch are caller-provided; scratch size comes
  *     from the matching *_workspace_bytes() query.  Workspace pointers must be 256-byte
  *     aligned.
@@ -352,6 +354,11 @@ int oibl_cluster_means(const float* x, const int32_t* labels, int n, int d, int 
                        float* centers, int32_t* counts, void* stream);
 
 /* ---- diagnostics ------------------------------------------------------------------ */
+
+/* Elapsed milliseconds between two recorded hipEvent_t (HOST pointer ms_host) — also when the events
+ * were recorded by event nodes of a replayed hipGraph, which torch's Event.elapsed_time refuses: how
+ * bench.py measures the span of the matrix-core launches inside the replayed forward. */
+int oibl_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_host);
 
 /* Plain C = A . B^T on the shared MFMA GEMM core (used by tests to validate the core and
  * its fragment layout independently of the operators above):

@@ -21,7 +21,9 @@ ROOT = PKG_DIR.parent
 CSRC = PKG_DIR / "csrc"
 INCLUDE = ROOT / "include"
 BUILD_DIR = ROOT / "build" / "obj"
-LIB_PATH = PKG_DIR / "libopenibl_amd.so"
+BUILD_DIR_DBG = ROOT / "build" / "obj_dbg"
+LIB_PATH = PKG_DIR / "libopenibl_amd.so"          # the product: what include/openibl_amd.h declares, nothing else
+LIB_PATH_DBG = PKG_DIR / "libopenibl_amd_dbg.so"  # same sources + -DOIBL_DEBUG_HOOKS: test hooks, experiment kernels
 ARCH = "gfx950"
 
 CXXFLAGS = [
@@ -59,11 +61,12 @@ def _digest() -> str:
 
 def is_current() -> bool:
     stamp = BUILD_DIR / "stamp"
-    return LIB_PATH.exists() and stamp.exists() and stamp.read_text() == _digest()
+    return LIB_PATH.exists() and LIB_PATH_DBG.exists() and stamp.exists() and stamp.read_text() == _digest()
 
 
 def build(force: bool = False, verbose: bool = True) -> Path:
-    """Compile every HIP source for gfx950 and link libopenibl_amd.so.  Returns its path.
+    """Compile every HIP source for gfx950 and link libopenibl_amd.so (and libopenibl_amd_dbg.so, the
+    same sources with the test hooks compiled in).  Returns the product's path.
 
     One process per GPU means several ranks may arrive here at once: the build is serialised with
     an exclusive file lock (the ranks that waited find the stamp current and return), and the
@@ -112,35 +115,44 @@ def resource_usage() -> dict:
 def _build_locked(verbose: bool) -> Path:
     hipcc = _hipcc()
     srcs = sources()
-    objs = [BUILD_DIR / (s.stem + ".o") for s in srcs]
+    BUILD_DIR_DBG.mkdir(parents=True, exist_ok=True)
+    jobs = [(s, BUILD_DIR / (s.stem + ".o"), False) for s in srcs] + \
+           [(s, BUILD_DIR_DBG / (s.stem + ".o"), True) for s in srcs]
 
-    def compile_one(pair):
-        src, obj = pair
+    def compile_one(job):
+        src, obj, dbg = job
         # -Rpass-analysis: the compiler's per-kernel register / scratch / LDS report, kept next to the
         # objects (build/resource_usage.json; tests/test_abi.py holds the hot kernels to their budgets)
-        cmd = [hipcc, *CXXFLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", str(src), "-o", str(obj)]
+        cmd = [hipcc, *CXXFLAGS, *(["-DOIBL_DEBUG_HOOKS"] if dbg else []),
+               "-Rpass-analysis=kernel-resource-usage", "-c", str(src), "-o", str(obj)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
-            raise RuntimeError(f"hipcc failed on {src.name}:\n{r.stdout}\n{r.stderr}")
+            raise RuntimeError(f"hipcc failed on {src.name}{' (debug hooks)' if dbg else ''}:\n{r.stdout}\n{r.stderr}")
         if verbose:
-            print(f"[openibl_amd.build] compiled {src.name}", file=sys.stderr)
-        return r.stderr
+            print(f"[openibl_amd.build] compiled {src.name}{' (debug hooks)' if dbg else ''}", file=sys.stderr)
+        return dbg, r.stderr
 
-    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        remarks = list(ex.map(compile_one, zip(srcs, objs)))
-    (BUILD_DIR / "resource_usage.json").write_text(json.dumps(_parse_resource_usage("\n".join(remarks)), indent=1))
+    # the big translation units first, so that the pool is never left with one long job at the end
+    jobs.sort(key=lambda j: -j[0].stat().st_size)
+    with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, len(jobs))) as ex:
+        results = list(ex.map(compile_one, jobs))
+    remarks = "\n".join(text for dbg, text in results if not dbg)
+    (BUILD_DIR / "resource_usage.json").write_text(json.dumps(_parse_resource_usage(remarks), indent=1))
+    (BUILD_DIR_DBG / "resource_usage.json").write_text(json.dumps(
+        _parse_resource_usage("\n".join(text for dbg, text in results if dbg)), indent=1))
 
-    tmp = LIB_PATH.with_name(LIB_PATH.name + f".tmp{os.getpid()}")
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fno-gpu-rdc",
-           *map(str, objs), "-o", str(tmp)]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        tmp.unlink(missing_ok=True)
-        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    os.replace(tmp, LIB_PATH)
+    for lib, objdir in ((LIB_PATH, BUILD_DIR), (LIB_PATH_DBG, BUILD_DIR_DBG)):
+        tmp = lib.with_name(lib.name + f".tmp{os.getpid()}")
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fno-gpu-rdc",
+               *[str(objdir / (s.stem + ".o")) for s in srcs], "-o", str(tmp)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            tmp.unlink(missing_ok=True)
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        os.replace(tmp, lib)
+        if verbose:
+            print(f"[openibl_amd.build] linked {lib}", file=sys.stderr)
     (BUILD_DIR / "stamp").write_text(_digest())
-    if verbose:
-        print(f"[openibl_amd.build] linked {LIB_PATH}", file=sys.stderr)
     return LIB_PATH
 
 

@@ -8,7 +8,9 @@
 namespace oibl {
 
 static thread_local char g_err[512] = "";
+#ifdef OIBL_DEBUG_HOOKS
 int g_regstage = 0;
+#endif
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -188,6 +190,7 @@ static int launch_gemm_nt(const void* A, int M, const void* B, int N, int K, flo
   return OIBL_OK;
 }
 
+#ifdef OIBL_DEBUG_HOOKS
 // Diagnostic: the matrix pipe with nothing else to do.  Every wave keeps four independent
 // v_mfma_f32_32x32x16_bf16 chains going on register operands (no LDS, no memory in the loop): what
 // the chip sustains here, at the clock its power management settles on, is the ceiling every
@@ -225,6 +228,7 @@ __global__ __launch_bounds__(512) void mfma_peak_kernel(long iters, float* out) 
     for (int r = 0; r < 16; ++r) s += acc[c][r];
   if (s == 12345.678f) out[0] = s;   // keeps the chains alive
 }
+#endif
 
 }  // namespace oibl
 
@@ -234,22 +238,24 @@ extern "C" {
 
 // diagnostic (not in the public header): `blocks` workgroups x 8 waves x `iters` x 16 MFMAs of
 // 32x32x16 bf16 (32768 flop each) on register operands
+#ifdef OIBL_DEBUG_HOOKS
 int oibl_debug_mfma_peak(long iters, int blocks, void* scratch, void* stream) {
   OIBL_REQUIRE(iters > 0 && blocks > 0 && scratch, "mfma_peak: bad arguments");
   hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, iters, (float*)scratch);
   OIBL_LAUNCH_CHECK();
   return OIBL_OK;
 }
+#endif
 
 // test hook (not in the public header): 1 = register-staged main loop, 0 = global_load_lds
+#ifdef OIBL_DEBUG_HOOKS
 int oibl_debug_set_regstage(int on) {
   g_regstage = on ? 1 : 0;
   return OIBL_OK;
 }
+#endif
 
-// diagnostic (not in the public header): elapsed milliseconds between two recorded hipEvents, also
-// when they were recorded by event nodes of a replayed hipGraph (bench.py's kernel-span timing)
-int oibl_debug_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_host) {
+int oibl_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_host) {
   OIBL_REQUIRE(ev_start && ev_stop && ms_host, "event_elapsed: null pointer");
   OIBL_HIP_CHECK(hipEventElapsedTime(ms_host, (hipEvent_t)ev_start, (hipEvent_t)ev_stop));
   return OIBL_OK;

@@ -259,8 +259,19 @@ struct Elem<bf16_t> {
   __device__ static inline float to_f32(bf16_t v) { return bf16_bits_to_f32(v.bits); }
 };
 
-// test hook: 1 = stage GEMM tiles through registers instead of global_load_lds
-extern int g_regstage;
+// Test hooks.  The shipping library (libopenibl_amd.so) is compiled WITHOUT OIBL_DEBUG_HOOKS: every hook
+// variable is then a compile-time constant holding its default — no mutable process-wide state on any
+// launch path, the experiment kernels behind the hooks are not even instantiated — and no oibl_debug_*
+// function exists.  libopenibl_amd_dbg.so (same sources, -DOIBL_DEBUG_HOOKS) carries the hooks for the
+// variant tests and the tests/gpu_* diagnostics; they are plain process-wide ints there: not
+// thread-safe, not stream-scoped, test infrastructure only.
+#ifdef OIBL_DEBUG_HOOKS
+#define OIBL_HOOK(type, name, dflt) static type name = dflt
+extern int g_regstage;   // 1 = stage GEMM tiles through registers instead of global_load_lds
+#else
+#define OIBL_HOOK(type, name, dflt) static constexpr type name = dflt
+constexpr int g_regstage = 0;
+#endif
 
 // 128 zero bytes: the source every out-of-image im2col tap points its load at.
 const void* zero_line_device_ptr();

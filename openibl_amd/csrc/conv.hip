@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void conv1_1_kernel(const float* __restrict__ 
 //   input patch (3 channels x 3 rows x 130 columns, zero padded) staged in LDS as fp32, rounded
 //   to bf16 when the fragments are built.
 // ---------------------------------------------------------------------------------------------
-static int g_conv11_valu = 0;  // test hook: force the vector-ALU conv1_1 in bf16 mode too
+OIBL_HOOK(int, g_conv11_valu, 0);  // test hook: force the vector-ALU conv1_1 in bf16 mode too
 constexpr int C11_TW = 128;
 constexpr int C11_PITCH = 132;
 constexpr int C11_ZERO = 9 * C11_PITCH;  // index of a zero float (k >= 27)
@@ -668,18 +668,18 @@ static int launch_conv_splitk(const ConvParams& p, hipStream_t st) {
   return OIBL_OK;
 }
 
-static int g_ring_raster = 0;                     // test hook: xcd_tile() mode of the ring kernels
+OIBL_HOOK(int, g_ring_raster, 0);                     // test hook: xcd_tile() mode of the ring kernels
 // K order of the implicit-GEMM convolutions: 0 = (tap, channel chunk), 1 = (channel chunk, tap), -1 = per
 // layer (default).  Order 1 cuts the fetched bytes 3-8x and is slower on every layer except
 // the one whose re-fetches run at HBM-class bandwidth: bf16x3 conv2_2 (128 -> 128 at 240 x 320: 11.3 GB
 // fetched per launch at 6.6 TB/s in order 0; 1.66 -> 1.54 ms in order 1).  The hook forces one order.
-static int g_conv_korder = -1;
+OIBL_HOOK(int, g_conv_korder, -1);
 static int conv_korder_for(int precision, int cin, int cout) {
   if (g_conv_korder >= 0) return g_conv_korder;
   return (precision == OIBL_BF16X3 || precision == OIBL_F16MX) && cin == 128 && cout == 128 ? 1 : 0;
 }
-static unsigned long long* g_prof_buf = nullptr;  // test hook: phase profile of block 0
-static int g_ring_ablate = 0;                     // test hook: see RingParams::ablate
+OIBL_HOOK(unsigned long long*, g_prof_buf, nullptr);  // test hook: phase profile of block 0
+OIBL_HOOK(int, g_ring_ablate, 0);                     // test hook: see RingParams::ablate
 
 // ring-schedule kernel (conv_ring.h): bf16, Cin % 64 == 0; WM = 2: 256 x 256 tile (Cout % 256 == 0),
 // WM = 4: 512 x 128 tile (Cout % 128 == 0)
@@ -751,9 +751,9 @@ static int ring_variant(const ConvParams& p, int es = 2) {
 // g_conv_tile (test hook): 0 = auto, 1 = 128x{128,64}, 2 = 256x{128,64}, 3 = 256x256 where legal,
 // 4 = ring schedule where legal.  Auto prefers the ring kernel whenever its 256x256 tiling gives
 // every CU at least one workgroup.
-static int g_conv_tile = 0;
-static long g_ring_min_tiles = 256;
-static int g_conv_ablate = 0;
+OIBL_HOOK(int, g_conv_tile, 0);
+OIBL_HOOK(long, g_ring_min_tiles, 256);
+OIBL_HOOK(int, g_conv_ablate, 0);
 
 template <typename T>
 static int launch_conv(const ConvParams& p, int pool, hipStream_t st) {
@@ -851,7 +851,7 @@ static void halo_patch(int Hn, int Wn, int* PH, int* PW) {
   *PW = bw;
 }
 
-static int g_halo_var = 0;  // experiment: 3 = the waits that count the halo instructions (rarely wrong: conv_halo.h)
+OIBL_HOOK(int, g_halo_var, 0);  // experiment: 3 = the waits that count the halo instructions (rarely wrong: conv_halo.h)
 template <bool POOL>
 static int launch_conv_halo(const ConvParams& p, hipStream_t st) {
   using G = RingGeo<2>;
@@ -901,7 +901,7 @@ static int launch_conv_halo(const ConvParams& p, hipStream_t st) {
 // 0.58x the LDS-DMA bytes, +5 % on conv3_x, -5 % on conv4_x / conv5_x since the ring's K cursor left its
 // LOAD segments (profiles/r03_*): kept as the tested alternative; 2 = ring kernels with the LDS-DMA issue
 // inside COMPUTE (RING_MX); 4..8 = timing experiments (wrong results) / stamps.
-static int g_mx_variant = 0;
+OIBL_HOOK(int, g_mx_variant, 0);
 static int launch_conv_mx(const ConvParams& p, int pool, hipStream_t st) {
   const int rv = (pool && p.out_f32) ? 0 : ring_variant(p, 4);
   if (g_mx_variant == 3 && rv == 2 && ((p.cin >> 5) & 1) == 0)
@@ -951,7 +951,7 @@ constexpr int C64_W_BYTES = 9 * 64 * 128;
 constexpr int C64_LDS_BYTES = C64_W_BYTES + 2 * C64_HALO_BYTES;
 constexpr int C64_HALO_LOADS = 11;                 // ceil(43 wave-instructions / 4 waves)
 constexpr int C64_WAVE_REGION = 10880;             // per-wave epilogue staging inside a halo buffer
-static int g_conv_c64 = 1;
+OIBL_HOOK(int, g_conv_c64, 1);
 
 struct C64Params {
   const char* in;
@@ -1233,8 +1233,8 @@ constexpr int ST_LUT_ENTRIES = 3 * 257;              // uint8 input: per channel
 constexpr int ST_LDS_BYTES_U8 = ST_LDS_BYTES + 1552;
 constexpr int ST_BLOCKS = (ST_HALO_PX + 31) / 32;    // 11 blocks of 32 halo pixels
 constexpr unsigned ST_OOB = 0xF0000000u;
-static int g_stem_fused = 1;
-static int g_stem3_prio = 0;  // bf16x3 stem, test hook: producer issue priority | consumer priority << 2
+OIBL_HOOK(int, g_stem_fused, 1);
+OIBL_HOOK(int, g_stem3_prio, 0);  // bf16x3 stem, test hook: producer issue priority | consumer priority << 2
 
 struct StemParams {
   const void* x;     // U8 = false: [N][3][H][W] fp32 (normalised); U8 = true: [N][H][W][3] uint8
@@ -2241,7 +2241,7 @@ static bool precision_ok(int precision) {
 }
 
 // out_f32 (bf16x3 only): write the output as plain fp32 NHWC
-static int g_conv_splitk = 1;  // test hook: 0 = never split K
+OIBL_HOOK(int, g_conv_splitk, 1);  // test hook: 0 = never split K
 
 // splitk_ws (optional): scratch for the split-K partials of layers with too few tiles
 // (conv_splitk_bytes); without it every layer runs one-pass
@@ -2309,15 +2309,19 @@ using namespace oibl;
 
 extern "C" {
 
+#ifdef OIBL_DEBUG_HOOKS
 int oibl_debug_set_prof_buffer(void* dev_u64x8) {
   g_prof_buf = (unsigned long long*)dev_u64x8;
   return OIBL_OK;
 }
+#endif
 
+#ifdef OIBL_DEBUG_HOOKS
 int oibl_debug_set_stem_fused(int on) {
   g_stem_fused = on ? 1 : 0;
   return OIBL_OK;
 }
+#endif
 
 int oibl_vgg16_stem_bf16(const float* x_nchw, int N, int H, int W, const float* w1_oihw,
                          const float* b1, const void* packed_w2, const float* b2, void* out,
@@ -2341,57 +2345,77 @@ int oibl_vgg16_stem_x3(const float* x_nchw, int N, int H, int W, const float* w1
   return launch_vgg_stem_x3(x_nchw, N, H, W, w1_oihw, b1, packed_w2, b2, out, (hipStream_t)stream);
 }
 
+#ifdef OIBL_DEBUG_HOOKS
 int oibl_debug_set_conv_c64(int on) {  // 0 = off, 1 = auto, 2 = every Cin = 64 layer
   g_conv_c64 = on < 0 ? 0 : (on > 2 ? 2 : on);
   return OIBL_OK;
 }
+#endif
 
+#ifdef OIBL_DEBUG_HOOKS
 int oibl_debug_set_conv_ablate(int mode) {
   g_conv_ablate = mode;
   return OIBL_OK;
 }
+#endif
 
+#ifdef OIBL_DEBUG_HOOKS
 int oibl_debug_set_ring_ablate(int mode) {
   g_ring_ablate = mode;
   return OIBL_OK;
 }
+#endif
 
+#ifdef OIBL_DEBUG_HOOKS
 int oibl_debug_set_stem3_prio(int prio) {
   g_stem3_prio = prio < 0 ? 0 : (prio & 15);
   return OIBL_OK;
 }
+#endif
 
+#ifdef OIBL_DEBUG_HOOKS
 int oibl_debug_set_conv_splitk(int on) {
   g_conv_splitk = on ? 1 : 0;
   return OIBL_OK;
 }
+#endif
 
+#ifdef OIBL_DEBUG_HOOKS
 int oibl_debug_set_mx_variant(int v) {
   g_halo_var = v >= 16 ? v - 16 : 0;   // 19: halo kernel with the unsafe waits (experiment)
   if (v >= 16) v = 3;
   g_mx_variant = v;
   return OIBL_OK;
 }
+#endif
 
+#ifdef OIBL_DEBUG_HOOKS
 int oibl_debug_set_conv_korder(int mode) {
   g_conv_korder = mode < 0 ? -1 : (mode ? 1 : 0);
   return OIBL_OK;
 }
+#endif
 
+#ifdef OIBL_DEBUG_HOOKS
 int oibl_debug_set_ring_raster(int mode) {
   g_ring_raster = mode;
   return OIBL_OK;
 }
+#endif
 
+#ifdef OIBL_DEBUG_HOOKS
 int oibl_debug_set_conv_tile(int mode) {
   g_conv_tile = mode;
   return OIBL_OK;
 }
+#endif
 
+#ifdef OIBL_DEBUG_HOOKS
 int oibl_debug_set_conv11_valu(int on) {
   g_conv11_valu = on ? 1 : 0;
   return OIBL_OK;
 }
+#endif
 
 size_t oibl_conv3x3_packed_bytes(int cout, int cin, int precision) {
   return (size_t)9 * cout * cin * oibl_elem_size(precision);

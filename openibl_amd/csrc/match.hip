@@ -821,24 +821,30 @@ using namespace oibl;
 
 extern "C" {
 
-static int g_match_ring = 1;  // test hook: 0 = never, 1 = auto, 2 = whenever legal
-static int g_match_group = 4;  // test hook: query tiles per ordering group of the ring kernel
-static int g_match_splitk = 1;  // test hook: 0 = never split the threshold sample's contraction
+OIBL_HOOK(int, g_match_ring, 1);  // test hook: 0 = never, 1 = auto, 2 = whenever legal
+OIBL_HOOK(int, g_match_group, 4);  // test hook: query tiles per ordering group of the ring kernel
+OIBL_HOOK(int, g_match_splitk, 1);  // test hook: 0 = never split the threshold sample's contraction
 
+#ifdef OIBL_DEBUG_HOOKS
 int oibl_debug_set_match_splitk(int on) {
   g_match_splitk = on ? 1 : 0;
   return OIBL_OK;
 }
+#endif
 
+#ifdef OIBL_DEBUG_HOOKS
 int oibl_debug_set_match_group(int g) {
   g_match_group = g < 1 ? 1 : g;
   return OIBL_OK;
 }
+#endif
 
+#ifdef OIBL_DEBUG_HOOKS
 int oibl_debug_set_match_ring(int mode) {
   g_match_ring = mode;
   return OIBL_OK;
 }
+#endif
 
 static size_t pw_off_yn(int m) { return align_up((size_t)m * sizeof(float), 256); }
 static size_t pw_off_xt(int m, int n) { return pw_off_yn(m) + align_up((size_t)n * sizeof(float), 256); }

@@ -11,7 +11,6 @@ from pathlib import Path
 
 from . import build as _build
 
-_LIB = None
 
 c_void_p, c_int, c_size_t, c_char_p = C.c_void_p, C.c_int, C.c_size_t, C.c_char_p
 
@@ -93,15 +92,16 @@ SIGNATURES = {
                                     c_void_p, c_void_p]),
     "oibl_gemm_nt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t,
                              c_void_p]),
+    "oibl_event_elapsed_ms": (c_int, [c_void_p, c_void_p, c_void_p]),
 }
-# test hooks exported by the library but deliberately absent from the public header
+# test hooks: exported ONLY by libopenibl_amd_dbg.so (the same sources compiled with -DOIBL_DEBUG_HOOKS);
+# the value after the signature is the default the hook is reset to between tests (None: no reset)
 _HOOKS = {"oibl_debug_set_regstage": (c_int, [c_int]),
           "oibl_debug_set_conv11_valu": (c_int, [c_int]),
           "oibl_debug_set_conv_tile": (c_int, [c_int]),
           "oibl_debug_set_conv_ablate": (c_int, [c_int]),
           "oibl_debug_set_conv_c64": (c_int, [c_int]),
           "oibl_debug_set_stem_fused": (c_int, [c_int]),
-          "oibl_debug_event_elapsed_ms": (c_int, [c_void_p, c_void_p, c_void_p]),
           "oibl_debug_mfma_peak": (c_int, [C.c_long, c_int, c_void_p, c_void_p]),
           "oibl_debug_set_match_ring": (c_int, [c_int]),
           "oibl_debug_set_ring_ablate": (c_int, [c_int]),
@@ -125,12 +125,22 @@ def lib_path() -> Path:
     return _build.LIB_PATH
 
 
-def load():
-    """Load (building first if the in-tree .so is missing or stale and hipcc is available)."""
-    global _LIB
-    if _LIB is not None:
-        return _LIB
-    path = lib_path()
+def debug_lib_path() -> Path:
+    return _build.LIB_PATH_DBG
+
+
+_LIBS = {"product": None, "debug": None}
+_ACTIVE = "product"
+_HOOK_DEFAULTS = {"oibl_debug_set_regstage": 0, "oibl_debug_set_conv11_valu": 0, "oibl_debug_set_conv_tile": 0,
+                  "oibl_debug_set_conv_ablate": 0, "oibl_debug_set_conv_c64": 1, "oibl_debug_set_stem_fused": 1,
+                  "oibl_debug_set_match_ring": 1, "oibl_debug_set_ring_ablate": 0, "oibl_debug_set_ring_raster": 0,
+                  "oibl_debug_set_conv_korder": -1, "oibl_debug_set_mx_variant": 0, "oibl_debug_set_conv_splitk": 1,
+                  "oibl_debug_set_stem3_prio": 0, "oibl_debug_set_match_group": 4, "oibl_debug_set_match_splitk": 1,
+                  "oibl_debug_set_prof_buffer": None}
+
+
+def _open(which: str):
+    path = lib_path() if which == "product" else debug_lib_path()
     if os.environ.get("OPENIBL_AMD_NO_BUILD", "0") != "1":
         try:
             if not _build.is_current():
@@ -150,7 +160,10 @@ def load():
         lib = C.CDLL(str(path))
     except OSError as e:
         raise OpenIBLAmdError(f"openibl_amd: cannot load {path}: {e}")
-    for name, (res, args) in {**SIGNATURES, **_HOOKS}.items():
+    table = dict(SIGNATURES)
+    if which == "debug":
+        table.update(_HOOKS)
+    for name, (res, args) in table.items():
         try:
             fn = getattr(lib, name)
         except AttributeError:
@@ -160,8 +173,38 @@ def load():
     if lib.oibl_abi_version() != ABI_VERSION:
         raise OpenIBLAmdError(
             f"openibl_amd: ABI version {lib.oibl_abi_version()} != expected {ABI_VERSION}")
-    _LIB = lib
     return lib
+
+
+def load():
+    """The library every call goes through: libopenibl_amd.so — the product, no test hooks, no mutable
+    process state — unless debug_hooks() switched this process to libopenibl_amd_dbg.so (same kernels,
+    plus the oibl_debug_* hooks).  Builds first if the in-tree libraries are missing or stale and hipcc is
+    available."""
+    if _LIBS[_ACTIVE] is None:
+        _LIBS[_ACTIVE] = _open(_ACTIVE)
+    return _LIBS[_ACTIVE]
+
+
+def debug_hooks():
+    """Switch this process to the debug-hook library and return its handle (test infrastructure: variant
+    tests, tests/gpu_* diagnostics).  Sticky until use_product_library()."""
+    global _ACTIVE
+    _ACTIVE = "debug"
+    return load()
+
+
+def use_product_library(reset_hooks: bool = True) -> None:
+    """Back to the product library; the hooks of an already loaded debug library return to their defaults."""
+    global _ACTIVE
+    if reset_hooks and _LIBS["debug"] is not None:
+        for name, dflt in _HOOK_DEFAULTS.items():
+            getattr(_LIBS["debug"], name)(dflt)
+    _ACTIVE = "product"
+
+
+def active_library() -> str:
+    return _ACTIVE
 
 
 def check(rc: int, what: str = "") -> None:

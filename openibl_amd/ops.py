@@ -175,42 +175,42 @@ def x3_join(x: torch.Tensor) -> torch.Tensor:
 
 def set_regstage(on: bool) -> None:
     """Test hook: run the GEMM main loops register-staged instead of through global_load_lds."""
-    _lib.load().oibl_debug_set_regstage(1 if on else 0)
+    _lib.debug_hooks().oibl_debug_set_regstage(1 if on else 0)
 
 
 def set_conv_tile(mode: int) -> None:
     """Test hook: 0 = auto tile choice, 1 = 128-row tiles, 2 = 256x{128,64}, 3 = 256x256."""
-    _lib.load().oibl_debug_set_conv_tile(int(mode))
+    _lib.debug_hooks().oibl_debug_set_conv_tile(int(mode))
 
 
 def set_ring_raster(mode: int) -> None:
     """Test hook: tile rasterisation of the ring convolutions (0 = contiguous ids per XCD, 1 = one
     N-tile per XCD, see xcd_tile in csrc/common.h).  Results do not depend on it."""
-    _lib.load().oibl_debug_set_ring_raster(int(mode))
+    _lib.debug_hooks().oibl_debug_set_ring_raster(int(mode))
 
 
 def set_conv_korder(mode: int) -> None:
     """Test hook: K order of the implicit-GEMM convolutions, 0 = (tap, channel chunk), 1 = (channel
     chunk, tap): 3-8x fewer fetched bytes, slower on all layers but bf16x3 conv2_2; -1 = the per-layer
     default (order 1 for that layer, 0 elsewhere; see csrc/conv.hip)."""
-    _lib.load().oibl_debug_set_conv_korder(int(mode))
+    _lib.debug_hooks().oibl_debug_set_conv_korder(int(mode))
 
 
 def set_conv_splitk(on: bool) -> None:
     """Test hook: allow / forbid split-K for the backbone layers whose tiling leaves the chip idle
     (small batches: conv4 / conv5 of a single image)."""
-    _lib.load().oibl_debug_set_conv_splitk(1 if on else 0)
+    _lib.debug_hooks().oibl_debug_set_conv_splitk(1 if on else 0)
 
 
 def set_conv_c64(on) -> None:
     """Test hook: resident-weights kernel for Cin = 64 layers (bf16): False/0 = never, True/1 = auto
     (Cout = 64 only; wider layers go to the ring kernel), 2 = every Cin = 64 layer."""
-    _lib.load().oibl_debug_set_conv_c64(int(on))
+    _lib.debug_hooks().oibl_debug_set_conv_c64(int(on))
 
 
 def set_conv11_valu(on: bool) -> None:
     """Test hook: run conv1_1 on the vector ALU (exact fp32) also in bf16 mode."""
-    _lib.load().oibl_debug_set_conv11_valu(1 if on else 0)
+    _lib.debug_hooks().oibl_debug_set_conv11_valu(1 if on else 0)
 
 
 # ---- backbone -------------------------------------------------------------------------------
@@ -267,7 +267,7 @@ def conv1_1_nchw(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, precision
 
 def set_stem_fused(on: bool) -> None:
     """Test hook: use / bypass the fused conv1_1+conv1_2+pool stem kernel inside vgg16_conv5 (bf16)."""
-    _lib.load().oibl_debug_set_stem_fused(1 if on else 0)
+    _lib.debug_hooks().oibl_debug_set_stem_fused(1 if on else 0)
 
 
 def vgg16_stem(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, packed_w2: torch.Tensor,
@@ -638,19 +638,19 @@ def event_elapsed_ms(start: "torch.cuda.Event", stop: "torch.cuda.Event") -> flo
     """hipEventElapsedTime on the raw handles — works for events recorded by the event nodes of a
     replayed hipGraph, which torch's own bookkeeping does not see."""
     ms = C.c_float(0.0)
-    _lib.check(_lib.load().oibl_debug_event_elapsed_ms(int(start.cuda_event), int(stop.cuda_event),
+    _lib.check(_lib.load().oibl_event_elapsed_ms(int(start.cuda_event), int(stop.cuda_event),
                                                        C.byref(ms)), "event_elapsed_ms")
     return float(ms.value)
 
 
 def set_match_ring(mode: int) -> None:
     """Test hook: ring-schedule distance kernel 0 = never, 1 = auto, 2 = whenever legal."""
-    _lib.load().oibl_debug_set_match_ring(int(mode))
+    _lib.debug_hooks().oibl_debug_set_match_ring(int(mode))
 
 
 def set_match_splitk(on: bool) -> None:
     """Test hook: allow / forbid the 2-way split-K contraction of the fused path's threshold sample."""
-    _lib.load().oibl_debug_set_match_splitk(1 if on else 0)
+    _lib.debug_hooks().oibl_debug_set_match_splitk(1 if on else 0)
 
 
 def sqdist_topk(x: torch.Tensor, y: torch.Tensor, k: int, index_base: int = 0, precision=F32,

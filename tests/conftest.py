@@ -26,6 +26,16 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _product_library_with_default_hooks():
+    """Every test starts on libopenibl_amd.so (the product); a test that touches a hook switches the process
+    to libopenibl_amd_dbg.so (openibl_amd.lib.debug_hooks) and is switched back, hooks at their defaults."""
+    from openibl_amd import lib
+    lib.use_product_library()
+    yield
+    lib.use_product_library()
+
+
 def load_golden(name):
     return dict(np.load(GOLDEN / f"{name}.npz", allow_pickle=False))
 

@@ -6,7 +6,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from openibl_amd import ops, lib
 
 dev = torch.device("cuda", 0)
-L = lib.load()
+L = lib.debug_hooks()
 buf = torch.zeros(8, dtype=torch.int64, device=dev)
 names = ["issue_halo", "mfma loop", "wait vm/lgkm", "barrier A", "epilogue", "barrier B"]
 for (N, H, W, cout, pool) in [(32, 480, 640, 64, True), (32, 240, 320, 128, False)]:

@@ -50,7 +50,7 @@ def main():
         outs, times = {}, {m: [] for m in modes}
         def select(m):
             ops.set_conv_tile(0 if m >= 100 else m)
-            _l.load().oibl_debug_set_ring_ablate(m - 100 if m >= 100 else 0)
+            _l.debug_hooks().oibl_debug_set_ring_ablate(m - 100 if m >= 100 else 0)
         for m in modes:
             select(m)
             outs[m] = ops.conv3x3_nhwc(x, wp, b, bool(relu), bool(pool), "bf16")

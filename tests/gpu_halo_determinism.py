@@ -7,7 +7,7 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from openibl_amd import ops, lib  # noqa: E402
 dev = torch.device("cuda", 0)
-L = lib.load()
+L = lib.debug_hooks()
 g = torch.Generator(device=dev).manual_seed(5)
 import os
 VARIANT = int(os.environ.get("VARIANT", "3"))   # 3 = halo kernel, 19 = its unsafe-wait variant, 0 = ring

@@ -46,7 +46,7 @@ def main():
     for (h, w) in ((480, 640), (479, 637), (640, 480), (224, 224)):
         x_host = synth.images(1, h, w, seed=5).pin_memory()
         x = x_host.to(dev)
-        for prec in ("bf16", "bf16x3", "fp32"):
+        for prec in ("bf16", "f16mx", "bf16x3", "fp32"):
             model.set_precision(prec)
             with torch.no_grad():
                 e_med, e_min = med(lambda: model(x))

@@ -57,10 +57,10 @@ def main():
     if a.groups:
         from openibl_amd import lib as _l
         for gm in [int(v) for v in a.groups.split(",")]:
-            _l.load().oibl_debug_set_match_group(gm)
+            _l.debug_hooks().oibl_debug_set_match_group(gm)
             t = timed(lambda: ops.pairwise_sqdist(q, g, "bf16", out=out), a.iters)
             rows.append((f"pairwise ring, group_m={gm}", t))
-        _l.load().oibl_debug_set_match_group(8)
+        _l.debug_hooks().oibl_debug_set_match_group(8)
     for n, t in rows:
         print(f"  {n:48s} {t:8.3f} ms  {fl / t / 1e9:8.1f} TFLOP/s-equivalent  {a.q * a.g / t / 1e6:9.1f} Gpairs/s")
 

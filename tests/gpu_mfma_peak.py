@@ -15,7 +15,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from openibl_amd import lib  # noqa: E402
 
 dev = torch.device("cuda", 0)
-L = lib.load()
+L = lib.debug_hooks()
 scratch = torch.zeros(64, dtype=torch.float32, device=dev)
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 6.0
 rows, stop = [], [False]

@@ -13,7 +13,7 @@ w = torch.randn((cout, cin, 3, 3), generator=g, device=dev) * (2.0 / (9 * cin)) 
 b = torch.zeros((cout,), device=dev)
 x = ops.mx_split(xf)
 wp = ops.pack_conv3x3(w, "f16mx")
-L = lib.load()
+L = lib.debug_hooks()
 names = {0: "late (default)", 1: "early", 4: "early, no MFMA", 5: "early, no LDS-DMA", 6: "early, no fragment reads", 7: "early, no barriers"}
 for abl in (0, 3):
     L.oibl_debug_set_ring_ablate(abl)

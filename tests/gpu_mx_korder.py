@@ -11,7 +11,7 @@ m = hubconf.vgg16_netvlad(pretrained=False)
 m.load_state_dict(synth.embednetpca_state(0))
 m = m.to(dev).eval()
 x = synth.images(32, 480, 640, seed=100).to(dev)
-L = lib.load()
+L = lib.debug_hooks()
 for prec in ("f16mx", "bf16x3", "bf16"):
     m.set_precision(prec)
     for variant in ((0, 1) if prec == "f16mx" else (0,)):

@@ -6,7 +6,7 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from openibl_amd import ops, lib  # noqa: E402
 dev = torch.device("cuda", 0)
-L = lib.load()
+L = lib.debug_hooks()
 buf = torch.zeros(8 + 28, dtype=torch.int64, device=dev)
 N, H, W, cin, cout = 32, 60, 80, 512, 512
 g = torch.Generator(device=dev).manual_seed(5)

@@ -19,7 +19,7 @@ PRECS = ("bf16", "bf16x3", "f16mx", "f16mx-halo")
 
 def sel(p):
     from openibl_amd import lib
-    lib.load().oibl_debug_set_mx_variant(3 if p.endswith("halo") else 0)
+    lib.debug_hooks().oibl_debug_set_mx_variant(3 if p.endswith("halo") else 0)
 
 
 def main():

@@ -7,7 +7,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from openibl_amd import ops, lib
 
 dev = torch.device("cuda", 0)
-L = lib.load()
+L = lib.debug_hooks()
 buf = torch.zeros(8, dtype=torch.int64, device=dev)
 prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 kdiv = 32 if prec == "bf16x3" else 64

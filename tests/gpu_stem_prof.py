@@ -6,7 +6,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from openibl_amd import ops, lib
 
 dev = torch.device("cuda", 0)
-L = lib.load()
+L = lib.debug_hooks()
 buf = torch.zeros(8, dtype=torch.int64, device=dev)
 N, H, W = 32, 480, 640
 x = torch.randn((N, 3, H, W), device=dev) * 50

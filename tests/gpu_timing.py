@@ -49,7 +49,7 @@ def main():
     ops.set_ring_raster(a.raster)
     ops.set_conv_korder(a.korder)
     from openibl_amd import lib as _l
-    _l.load().oibl_debug_set_conv_ablate(a.ablate)
+    _l.debug_hooks().oibl_debug_set_conv_ablate(a.ablate)
     sd = synth.embednetpca_state(0)
     N, H, W, p = a.batch, a.height, a.width, a.precision
     x = synth.images(min(N, 4), H, W, seed=1)

@@ -36,6 +36,29 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert sorted(lib.SIGNATURES) == names, "lib.SIGNATURES and the header disagree"
 
 
+def _exported(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", str(path)], capture_output=True, text=True, check=True).stdout
+    return sorted({ln.split()[-1] for ln in out.splitlines() if len(ln.split()) >= 3 and ln.split()[-2] in "TDB"})
+
+
+def test_product_library_exports_the_header_and_nothing_else():
+    """libopenibl_amd.so exports exactly the functions the header declares: no oibl_debug_* hook, no test
+    entry, no mutable hook variable (they are compile-time constants in this build); the hooks live in
+    libopenibl_amd_dbg.so, which exports the same public surface plus them."""
+    from openibl_amd import lib
+    names = declared_functions()
+    prod = [n for n in _exported(lib.lib_path()) if n.startswith("oibl_")]
+    assert prod == names, sorted(set(prod) ^ set(names))
+    dbg = [n for n in _exported(lib.debug_lib_path()) if n.startswith("oibl_")]
+    assert sorted(set(dbg) - set(names)) == sorted(lib._HOOKS), "debug library: unexpected extra exports"
+    assert set(names) <= set(dbg)
+    # no writable hook state in the product: the hook variables are g_* statics in the debug build only
+    import subprocess
+    syms = subprocess.run(["nm", str(lib.lib_path())], capture_output=True, text=True).stdout
+    assert not [ln for ln in syms.splitlines() if " g_" in ln and ln.split()[-2] in "bBdD" and "g_zero_line" not in ln and "g_err" not in ln]
+
+
 def test_header_is_plain_c(tmp_path):
     """The boundary is C: the header must compile as C with no HIP / C++ / torch includes."""
     import shutil

@@ -67,9 +67,9 @@ def mx_variant(request):
     """0 = default dispatch (ring kernels), 3 = halo kernel for the 256-channel-tile layers, 2 = ring kernels
     with the LDS-DMA issue inside the COMPUTE segments."""
     from openibl_amd import lib
-    lib.load().oibl_debug_set_mx_variant(request.param)
+    lib.debug_hooks().oibl_debug_set_mx_variant(request.param)
     yield request.param
-    lib.load().oibl_debug_set_mx_variant(0)
+    lib.debug_hooks().oibl_debug_set_mx_variant(0)
 
 
 @pytest.mark.parametrize("N,H,W,cin,cout,relu,pool", [
@@ -284,7 +284,7 @@ def test_conv_mx_repeatable_under_load(dev):
     big = torch.randn((4096, 4096), device=dev)
     side = torch.cuda.Stream()
     for variant in (0, 3):
-        lib.load().oibl_debug_set_mx_variant(variant)
+        lib.debug_hooks().oibl_debug_set_mx_variant(variant)
         try:
             ref = ops.conv3x3_nhwc(x, wp, b, True, True, "f16mx")
             for _ in range(25):
@@ -293,4 +293,4 @@ def test_conv_mx_repeatable_under_load(dev):
                 assert torch.equal(ops.conv3x3_nhwc(x, wp, b, True, True, "f16mx"), ref)
             torch.cuda.synchronize()
         finally:
-            lib.load().oibl_debug_set_mx_variant(0)
+            lib.debug_hooks().oibl_debug_set_mx_variant(0)

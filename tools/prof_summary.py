@@ -69,7 +69,7 @@ def main():
                     "over gloo (not a performance number)\n"
                     + "\n".join(l[:600] for l in (d / "bench_2ranks_shared.json").read_text().splitlines()
                                 if l.startswith("{")) + "\n\n")
-        for n in ("gpu.txt", "timing_bf16x3.log", "timing_bf16.log", "timing_bf16x3_raster1.log",
+        for n in ("gpu.txt", "precbench.log", "mx_stamps.log", "mx_probe.log", "timing_bf16x3.log", "timing_bf16.log", "timing_bf16x3_raster1.log",
                   "timing_bf16_raster1.log", "timing_fp32.log", "pcie.log", "convbench.log", "shardbench.log"):
             if (d / n).exists():
                 f.write(f"==== {n}\n" + (d / n).read_text() + "\n")
@@ -90,6 +90,7 @@ def main():
     skip = "--no-pipeline --skip-matching --skip-cpu-baseline --skip-api --skip-fast-mode"
     for sub, name, title in (
             ("prof_stats", f"{tag}_kernel_stats.md", "python bench.py --steps 40 --warmup 5 --skip-matching --skip-cpu-baseline"),
+            ("prof_stats_f16mx", f"{tag}_kernel_stats_f16mx.md", f"python bench.py --precision f16mx --steps 40 --warmup 5 {skip}"),
             ("prof_stats_bf16x3", f"{tag}_kernel_stats_bf16x3.md", f"python bench.py --precision bf16x3 --steps 40 --warmup 5 {skip}"),
             ("prof_stats_bf16", f"{tag}_kernel_stats_bf16.md", f"python bench.py --precision bf16 --steps 40 --warmup 5 {skip}"),
             ("prof_match", f"{tag}_kernel_stats_matching.md", "python bench.py --steps 2 --warmup 1 --skip-cpu-baseline --skip-api (with matching, both modes)")):
@@ -98,7 +99,7 @@ def main():
             lines = [f"# {tag}: rocprofv3 --kernel-trace --stats -- {title}", "", a.note, ""] + kernel_stats(p)
             (prof / name).write_text("\n".join(lines) + "\n")
     digest = {}
-    for prec in ("", "bf16x3", "bf16"):
+    for prec in ("", "f16mx", "bf16x3", "bf16"):
         sfx = f"_{prec}" if prec else ""
         fp = d / f"prof_fetch{sfx}" / "bench_counter_collection.csv"
         wp = d / f"prof_write{sfx}" / "bench_counter_collection.csv"
@@ -108,14 +109,20 @@ def main():
                 digest[prec or "bf16"] = ent
     if digest:
         import json
-        (prof / "hbm_traffic_latest.json").write_text(json.dumps(digest, indent=1) + "\n")
+        latest = prof / "hbm_traffic_latest.json"
+        try:
+            old = json.loads(latest.read_text())
+        except Exception:
+            old = {}
+        old.update(digest)        # precisions not measured in this set keep their last digest
+        latest.write_text(json.dumps(old, indent=1) + "\n")
     print("wrote", sorted(p.name for p in prof.glob(f"{tag}_*")))
 
 
 def sustain_md(d, prof, tag):
     import json
     out = []
-    for prec in ("bf16x3", "bf16"):
+    for prec in ("f16mx", "bf16x3", "bf16"):
         p = d / f"sustain_{prec}.json"
         if not p.exists():
             continue
