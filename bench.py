@@ -513,6 +513,8 @@ def main():
         with torch.no_grad():
             api[args.precision] = time_api(c, model, args.precision, args.batch, args.api_batches, u8=False)
             if args.precision != "bf16":
+                api[args.precision + "_uint8_input"] = time_api(c, model, args.precision, args.batch,
+                                                                args.api_batches, u8=True)
                 api["bf16"] = time_api(c, model, "bf16", args.batch, args.api_batches, u8=False)
                 api["bf16_uint8_input"] = time_api(c, model, "bf16", args.batch, args.api_batches, u8=True)
     barrier()

@@ -131,24 +131,44 @@ class VGG(_PrecisionMixin, nn.Module):
     def _convs(self) -> List[nn.Conv2d]:
         return [m for m in self.base if isinstance(m, nn.Conv2d)]
 
-    def _packed(self, device: torch.device):
+    # f16mx has ring kernels only (256-pixel tiles, no split-K): a batch whose conv4 layers give fewer
+    # than F16MX_MIN_TILES tiles leaves most of the chip idle, and the backbone then runs in bf16x3 — the
+    # other mode inside the 1e-4 tolerance, with small-problem kernels (a single 480x640 image: 1.04 ms
+    # against 1.37 ms; profiles/r03_c_latency.md).  conv4 of N images of H x W has N (H/8) (W/8) / 256 x 2 tiles.
+    F16MX_MIN_TILES = 256
+
+    def effective_precision(self, x: torch.Tensor) -> str:
+        """The arithmetic the backbone runs this input in: the module's precision, except that small
+        f16mx batches run in bf16x3 (see F16MX_MIN_TILES)."""
+        p = self.precision
+        if ops.precision_code(p) != ops.F16MX:
+            return p
+        n = int(x.shape[0])
+        h, w = (int(x.shape[1]), int(x.shape[2])) if x.dtype == torch.uint8 else (int(x.shape[2]), int(x.shape[3]))
+        tiles = -(-(n * (h // 8) * (w // 8)) // 256) * 2
+        return p if tiles >= self.F16MX_MIN_TILES else "bf16x3"
+
+    def _packed(self, device: torch.device, precision: str = None):
+        precision = precision or self.precision
         convs = self._convs()
         params = [c.weight for c in convs] + [c.bias for c in convs]
         if params[0].device != device:
             raise RuntimeError(f"VGG: parameters are on {params[0].device}, input on {device}")
-        key = (self.precision, _fingerprint(params))
-        hit = self._cache.get("packed")
-        if hit is None or hit[0] != key:
+        key = _fingerprint(params)
+        if self._cache.get("packed_key") != key:      # weights changed: every precision's packing is stale
+            self._cache["packed_key"] = key
+            self._cache["packed"] = {}
+        hit = self._cache["packed"].get(precision)
+        if hit is None:
             ws = [convs[0].weight.detach().float().contiguous()]
             # f16mx: conv1_1 + conv1_2 + pool run in split bf16 (K = 27 / Cout = 64 fit no MX tile)
-            prec = [("bf16x3" if (i == 1 and ops.precision_code(self.precision) == ops.F16MX) else self.precision)
+            prec = [("bf16x3" if (i == 1 and ops.precision_code(precision) == ops.F16MX) else precision)
                     for i in range(len(convs))]
             ws += [ops.pack_conv3x3(c.weight.detach().float().contiguous(), prec[i])
                    for i, c in enumerate(convs) if i >= 1]
             bs = [c.bias.detach().float().contiguous() for c in convs]
-            self._cache["packed"] = (key, ws, bs)
-            hit = self._cache["packed"]
-        return hit[1], hit[2]
+            hit = self._cache["packed"][precision] = (ws, bs)
+        return hit
 
     def features_nhwc(self, x: torch.Tensor) -> torch.Tensor:
         """[N][3][H][W] fp32 (normalised) or [N][H][W][3] uint8 (raw image; the loader's
@@ -157,8 +177,9 @@ class VGG(_PrecisionMixin, nn.Module):
         if x.dtype != torch.uint8 and x.dtype != torch.float32:
             x = x.float()
         x = x.contiguous()
-        ws, bs = self._packed(x.device)
-        return ops.vgg16_conv5(x, ws, bs, self.precision, events=getattr(self, "profile_events", None))
+        prec = self.effective_precision(x)
+        ws, bs = self._packed(x.device, prec)
+        return ops.vgg16_conv5(x, ws, bs, prec, events=getattr(self, "profile_events", None))
 
     @torch.no_grad()
     def forward(self, x):

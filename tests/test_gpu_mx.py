@@ -133,7 +133,9 @@ def model(state_dict, dev):
     import hubconf
     m = hubconf.vgg16_netvlad(pretrained=False)
     m.load_state_dict(state_dict)
-    return m.to(dev).eval().set_precision("f16mx")
+    m = m.to(dev).eval().set_precision("f16mx")
+    m.base_model.F16MX_MIN_TILES = 0     # these tests are about the f16mx kernels: no small-batch switch to bf16x3
+    return m
 
 
 def _assert_desc(name, got, want):
@@ -160,6 +162,7 @@ def test_embednetpca_mx_matches_reference(name, model, dev):
     assert_rel_l2(f"{name} pool_x (f16mx)", pool_x.cpu(), g["pool_x"], TOL_DESC)
     from ibl import models
     emb = models.create("embednet", model.base_model, model.net_vlad).eval().set_precision("f16mx")
+    emb.base_model.F16MX_MIN_TILES = 0
     _, vlad = emb(x)
     _assert_desc(f"{name} vlad_norm (f16mx)", vlad.cpu(), g["vlad_norm"])
     from ibl.evaluators import extract_cnn_feature
@@ -294,3 +297,20 @@ def test_conv_mx_repeatable_under_load(dev):
             torch.cuda.synchronize()
         finally:
             lib.debug_hooks().oibl_debug_set_mx_variant(0)
+
+
+def test_small_f16mx_batches_run_in_bf16x3(dev, state_dict):
+    """The f16mx kernels are ring kernels only; a batch too small to fill the chip with their tiles is served
+    by bf16x3 (the other mode inside the tolerance, with split-K / small tiles): same bits as an explicit
+    bf16x3 model, the switch is visible through effective_precision()."""
+    import hubconf
+    m = hubconf.vgg16_netvlad(pretrained=False)
+    m.load_state_dict(state_dict)
+    m = m.to(dev).eval().set_precision("f16mx")
+    one = synth.images(1, 480, 640, seed=3).to(dev)
+    many = torch.empty((8, 3, 480, 640), device=dev)
+    assert m.base_model.effective_precision(one) == "bf16x3"
+    assert m.base_model.effective_precision(many) == "f16mx"
+    got = m(one).clone()
+    m.set_precision("bf16x3")
+    assert torch.equal(m(one), got)
