@@ -191,8 +191,9 @@ int oibl_vgg16_stem_x3(const float* x_nchw, int N, int H, int W, const float* w1
  * oibl_pack_conv3x3_weights; bias entries are [Cout] fp32.
  * OIBL_BF16X3: activations between the layers are (hi, lo) split elements, but `feat` is written as
  * plain fp32 (the head consumes it with OIBL_F32).
- * OIBL_F16MX: entry 1 (conv1_2) is packed with OIBL_BF16X3 — conv1_1 + conv1_2 + pool run in split
- * bf16 (K = 27 and Cout = 64 fit no MX tile) — entries 2..12 with OIBL_F16MX; `feat` is plain fp32.
+ * OIBL_F16MX: entries 1 and 2 (conv1_2, conv2_1) are packed with OIBL_BF16X3 — conv1_1 + conv1_2 + pool
+ * run in split bf16 (K = 27 and Cout = 64 fit no MX tile) and conv2_1 reads that map as it is, writing
+ * f16mx lines — entries 3..12 with OIBL_F16MX; `feat` is plain fp32.
  * The workspace holds the two ping-pong activation buffers and, for small batches, the fp32
  * partial tiles of the layers that run split-K (a layer whose 128-row tiling gives <= 192 tiles is
  * contracted by 2-8 workgroups per tile and reduced in a fixed order: deterministic, equal to

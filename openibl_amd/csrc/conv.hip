@@ -349,6 +349,7 @@ struct ConvParams {
   int ablate;  // timing experiments only (wrong results): 1 = A loads only at tap 0, 2 = B loads
                // only at the first step, 3 = both
   int out_f32;  // bf16x3 only: the output is written as plain fp32 NHWC (the layer feeding the head)
+  int out_mx;   // bf16x3 operands, f16mx output lines (the layer between the bf16x3 stem and the f16mx layers)
   int korder;   // K order of the implicit GEMM (test hook, see ConvRingALoader::begin_tile)
   // split-K (layers with too few tiles to fill the chip, e.g. conv5 of a single image: 40 tiles):
   // gridDim.y = ksplit workgroups share a tile, each contracts steps/ksplit K-steps from zero and
@@ -683,7 +684,7 @@ OIBL_HOOK(int, g_ring_ablate, 0);                     // test hook: see RingPara
 
 // ring-schedule kernel (conv_ring.h): bf16, Cin % 64 == 0; WM = 2: 256 x 256 tile (Cout % 256 == 0),
 // WM = 4: 512 x 128 tile (Cout % 128 == 0)
-template <int WM, bool POOL, bool ODD, int P = RING_BF16>
+template <int WM, bool POOL, bool ODD, int P = RING_BF16, bool OUTMX = (P >= RING_MX)>
 static int launch_conv_ring_impl(const ConvParams& p, hipStream_t st) {
   using G = RingGeo<WM>;
   constexpr bool X3 = P != RING_BF16;  // 4-byte elements
@@ -716,8 +717,8 @@ static int launch_conv_ring_impl(const ConvParams& p, hipStream_t st) {
   q.tiles_m = (int)tiles_m;
   q.raster = g_ring_raster;
   q.korder = p.korder;
-  constexpr int lds = ring_lds_bytes<WM, POOL, P>();
-  auto kern = conv3x3_ring_kernel<WM, POOL, ODD, P>;
+  constexpr int lds = ring_lds_bytes<WM, POOL, P, OUTMX>();
+  auto kern = conv3x3_ring_kernel<WM, POOL, ODD, P, OUTMX>;
   OIBL_SET_MAX_LDS(kern, lds);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, q);
   OIBL_LAUNCH_CHECK();
@@ -774,6 +775,12 @@ static int launch_conv(const ConvParams& p, int pool, hipStream_t st) {
     using C512x64 = GemmCfg<T, 8, 1, 2, 2>;  // Cout = 64 (conv1_2): 64 x 64 per wave instead of 64 x 32
     using C256x64w4 = GemmCfg<T, 4, 1, 2, 2>;  // the same wave tile with 4 waves: 80 KB, two workgroups per CU
     const int rv = (g_regstage || p.ablate || (pool && p.out_f32)) ? 0 : ring_variant(p, 4);
+    if (p.out_mx) {   // bf16x3 in, f16mx out: ring kernels only (conv2_1: 512 x 128 tile, no pooling)
+      if (rv == 4 && !pool) return launch_conv_ring_impl<4, false, false, RING_X3, true>(p, st);
+      if (rv == 2 && !pool) return launch_conv_ring_impl<2, false, false, RING_X3, true>(p, st);
+      set_error("conv3x3 (bf16x3 -> f16mx): unsupported layer cin=%d cout=%d pool=%d", p.cin, p.cout, pool);
+      return OIBL_E_UNSUPPORTED;
+    }
     const long t256 = (p.m_total + 255) / 256;
     const long ring_tiles = rv == 2 ? t256 * (p.cout / 256) : ((p.m_total + 511) / 512) * (p.cout / 128);
     int mode = g_conv_tile;
@@ -2254,7 +2261,7 @@ static size_t conv_splitk_bytes(long m_total, int cin, int cout, int precision) 
 
 static int conv3x3_impl(const void* in, int N, int H, int W, int cin, const void* packed_w,
                         const float* bias, int cout, int relu, int pool, int precision, void* out,
-                        hipStream_t st, int out_f32 = 0, void* splitk_ws = nullptr) {
+                        hipStream_t st, int out_f32 = 0, void* splitk_ws = nullptr, int out_mx = 0) {
   OIBL_REQUIRE(in && packed_w && bias && out, "conv3x3: null pointer");
   OIBL_REQUIRE(precision_ok(precision), "conv3x3: bad precision %d", precision);
   const int bk = precision == OIBL_BF16 ? 64 : 32;
@@ -2285,6 +2292,7 @@ static int conv3x3_impl(const void* in, int N, int H, int W, int cin, const void
   p.relu = relu;
   p.ablate = g_conv_ablate;
   p.out_f32 = (precision == OIBL_BF16X3 || precision == OIBL_F16MX) ? out_f32 : 0;
+  p.out_mx = precision == OIBL_BF16X3 ? out_mx : 0;
   p.korder = conv_korder_for(precision, cin, cout);
   p.tiles_n = 0;
   if (pool) {
@@ -2296,7 +2304,7 @@ static int conv3x3_impl(const void* in, int N, int H, int W, int cin, const void
   }
   p.ksplit = 0;
   p.partial = (float*)splitk_ws;
-  if (splitk_ws && g_conv_splitk && precision != OIBL_F16MX)
+  if (splitk_ws && g_conv_splitk && precision != OIBL_F16MX && !p.out_mx)
     p.ksplit = conv_splitk_factor(p.m_total, cout, 9 * (cin / bk));
   if (precision == OIBL_F16MX) return launch_conv_mx(p, pool, st);
   if (precision == OIBL_BF16X3) return launch_conv<bf16x3_t>(p, pool, st);
@@ -2663,21 +2671,17 @@ static int vgg_forward_impl(const void* x, int u8, const float* mean3, const flo
       l0 = 2;
     }
   }
-  if (mx) {
-    // f16mx: conv1_1 + conv1_2 + pool run in bf16x3 (K = 27 and Cout = 64 fit no MX ring tile; 12.6 % of the
-    // FLOPs); the pooled map [N][H/2][W/2][64] is re-packed from (hi, lo) groups to f16mx lines in place
-    const size_t lines = (size_t)N * h * w * 2;
-    unsigned b = (unsigned)((lines + 255) / 256);
-    hipLaunchKernelGGL(mx_pack_rows_kernel<1>, dim3(b > 16384 ? 16384 : b), dim3(256), 0, st, (const char*)cur,
-                       (char*)cur, lines);
-    OIBL_LAUNCH_CHECK();
-  }
+  // f16mx: conv1_1 + conv1_2 + pool run in bf16x3 (K = 27 and Cout = 64 fit no MX tile), and so does conv2_1,
+  // which reads the stem's (hi, lo) map as it is and WRITES f16mx lines (its ring kernel with the f16mx
+  // epilogue): no re-pack pass over the 629 MB map (0.26 ms per batch); 0.93 ms in bf16x3 against 0.79 ms
+  // in f16mx for the layer itself.  conv2_2 .. conv5_3 are f16mx.
   for (int l = l0; l < OIBL_VGG16_NUM_CONV; ++l) {
     void* dst = (l == OIBL_VGG16_NUM_CONV - 1) ? feat : (l % 2 == 0 ? (void*)bufA : (void*)bufB);
     // bf16x3: the last layer hands the head a plain fp32 map
+    const bool bridge = mx && l == 2;   // conv2_1 of an f16mx forward
     rc = conv3x3_impl(cur, N, h, w, kVgg[l].cin, packed_w_host[l], bias_host[l], kVgg[l].cout,
-                      kVgg[l].relu, kVgg[l].pool, precision, dst, st,
-                      l == OIBL_VGG16_NUM_CONV - 1, splitk);
+                      kVgg[l].relu, kVgg[l].pool, bridge ? OIBL_BF16X3 : precision, dst, st,
+                      l == OIBL_VGG16_NUM_CONV - 1, bridge ? nullptr : splitk, bridge ? 1 : 0);
     if (rc) return rc;
     if (kVgg[l].pool) {
       h /= 2;

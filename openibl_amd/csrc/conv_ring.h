@@ -61,12 +61,12 @@ __device__ static inline unsigned ring_div_u31(unsigned m, unsigned mul, unsigne
 }
 
 // epilogue staging: the output tile (X3 without pooling: one half of its rows at a time)
-template <int WM, bool POOL, int P = RING_BF16>
+template <int WM, bool POOL, int P = RING_BF16, bool OUTMX = (P >= RING_MX)>
 constexpr int ring_lds_bytes() {
   using G = RingGeo<WM>;
   constexpr bool E4 = P != RING_BF16;
   constexpr int rows = POOL ? G::BM / 4 : (E4 ? G::BM / 2 : G::BM);
-  constexpr int epi = rows * (G::BN * (E4 ? 4 : 2) + (P >= RING_MX ? 0 : 16));
+  constexpr int epi = rows * (G::BN * (E4 ? 4 : 2) + (OUTMX ? 0 : 16));
   return epi > G::MAIN_LDS ? epi : G::MAIN_LDS;
 }
 
@@ -213,12 +213,15 @@ __device__ static inline void ring_split4(float a0, float a1, float a2, float a3
   lo.y = __builtin_bit_cast(uint32_t, __builtin_convertvector((f2){r2, r3}, bf2));
 }
 
-template <int WM, bool POOL, bool ODD, int P = RING_BF16>
+// OUTMX: the OUTPUT is written as f16mx lines although the operands are bf16x3 (P = RING_X3): the layer
+// that takes the bf16x3 stem's map into the f16mx part of the backbone (conv2_1) — no re-pack pass.
+template <int WM, bool POOL, bool ODD, int P = RING_BF16, bool OUTMX = (P >= RING_MX)>
 __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
   using G = RingGeo<WM>;
   constexpr int NA = G::NA, NB = G::NB;
   constexpr bool X3 = P != RING_BF16;   // 4-byte elements, 32 channels per K-tile (bf16x3 and f16mx)
-  constexpr bool MX = P >= RING_MX;
+  constexpr bool MX = P >= RING_MX;     // f16mx operands
+  static_assert(!OUTMX || X3, "f16mx output needs 4-byte elements");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
   ConvRingALoader<NA, POOL, X3> la;
   ConvRingBLoader<NB, X3> lb;
   la.init(p, m0, rows_a, piece);
-  lb.init(p, n0, rows_b, MX ? ring_piece_mxb(wave, lane) : piece);
+  lb.init(p, n0, rows_b, MX ? ring_piece_mxb(wave, lane) : piece);   // (operand format, not output format)
 
   // The accumulators start at the bias (the fma chain of every output begins with it), laid out
   // like the results: natural layout = one channel per lane and column tile, transposed layout
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
   //      X3   : an output element is 4 bytes — the (hi, lo) pair at x3_off(channel) / + 64, or the
   //             fp32 value when out_f32 is set; without pooling the tile is staged in two passes of
   //             BM / 2 rows (accumulator row tiles {0, 1}, then {2, 3} of every wave).
-  if constexpr (MX) {
+  if constexpr (OUTMX) {
     // ---- f16mx epilogue.  The tile (without pooling: one half of its rows at a time) is staged as
     // fp32, rows of BN floats = CPR 16-byte chunks, chunk q of row r at physical chunk q ^ (r % CPR):
     // the 8 chunks of a (row, 32-channel group) item stay inside one aligned 128-byte block, 16

@@ -161,8 +161,9 @@ class VGG(_PrecisionMixin, nn.Module):
         hit = self._cache["packed"].get(precision)
         if hit is None:
             ws = [convs[0].weight.detach().float().contiguous()]
-            # f16mx: conv1_1 + conv1_2 + pool run in split bf16 (K = 27 / Cout = 64 fit no MX tile)
-            prec = [("bf16x3" if (i == 1 and ops.precision_code(precision) == ops.F16MX) else precision)
+            # f16mx: conv1_1 + conv1_2 + pool run in split bf16 (K = 27 / Cout = 64 fit no MX tile) and conv2_1
+            # reads their map as it is (its kernel writes f16mx lines): both are packed for bf16x3
+            prec = [("bf16x3" if (i in (1, 2) and ops.precision_code(precision) == ops.F16MX) else precision)
                     for i in range(len(convs))]
             ws += [ops.pack_conv3x3(c.weight.detach().float().contiguous(), prec[i])
                    for i, c in enumerate(convs) if i >= 1]

@@ -76,3 +76,13 @@ def assert_rel_l2(name, got, want, tol):
     msg = report(name, got, want)
     assert torch.isfinite(torch.as_tensor(got).float()).all(), f"{name}: non-finite values; {msg}"
     assert rel_l2(got, want) <= tol, f"{msg} > tol {tol:g}"
+
+
+def assert_desc(name, got, want, tol):
+    """A descriptor bound as north_star states it ("within 1e-4 relative"): rel-L2 over the batch AND, per
+    image, max |diff| against the image's largest entry — one bad lane cannot hide in 4096 good ones."""
+    got, want = torch.as_tensor(got).double().cpu(), torch.as_tensor(want).double().cpu()
+    assert_rel_l2(name, got, want, tol)
+    worst = float(((got - want).abs().amax(-1) / want.abs().amax(-1)).max())
+    print(f"{name}: worst image max|diff| / max|want| = {worst:.3e}")
+    assert worst <= tol, f"{name}: per-image max-abs criterion {worst:.3e} > {tol:g}"

@@ -201,7 +201,8 @@ def test_vgg16_backbone_mx_stem_toggle(dev, state_dict):
     x = synth.images(2, 64, 96, seed=4).to(dev)
     ws = [state_dict[f"base_model.base.{i}.weight"].to(dev) for i in synth.CONV_IDX]
     bs = [state_dict[f"base_model.base.{i}.bias"].to(dev) for i in synth.CONV_IDX]
-    packed = [ws[0], ops.pack_conv3x3(ws[1], "bf16x3")] + [ops.pack_conv3x3(w, "f16mx") for w in ws[2:]]
+    packed = [ws[0], ops.pack_conv3x3(ws[1], "bf16x3"), ops.pack_conv3x3(ws[2], "bf16x3")] + \
+        [ops.pack_conv3x3(w, "f16mx") for w in ws[3:]]
     a = ops.vgg16_conv5(x, packed, bs, "f16mx")
     ops.set_stem_fused(False)
     try:

@@ -7,7 +7,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import assert_rel_l2, load_golden, rel_l2
+from conftest import assert_desc, assert_rel_l2, load_golden, rel_l2
 from openibl_amd import ops, synth
 from oracle import descriptor as od
 from oracle import matching as om
@@ -149,7 +149,7 @@ def test_embednetpca_x3_matches_reference(name, model, dev):
     x = synth.images(n, h, w, seed=int(g["image_seed"])).to(dev)
     desc = model(x)
     assert tuple(desc.shape) == (n, 4096) and desc.dtype == torch.float32
-    assert_rel_l2(f"{name} desc (bf16x3)", desc.cpu(), g["desc"], TOL_DESC)
+    assert_desc(f"{name} desc (bf16x3)", desc.cpu(), g["desc"], TOL_DESC)
     pool_x, feat = model.base_model(x)
     s = int(g["feat_stride"])
     assert_rel_l2(f"{name} feat (bf16x3)", feat.cpu()[:, ::s], g["feat"], TOL_DESC)
@@ -167,7 +167,7 @@ def test_embednetpca_x3_vs_fp64_oracle(model, dev, state_dict):
     x = synth.images(2, 80, 112, seed=77)
     want = od.embednetpca(x, state_dict, dtype=torch.float64)
     got = model(x.to(dev)).cpu()
-    assert_rel_l2("desc bf16x3 vs fp64 oracle", got, want, TOL_DESC)
+    assert_desc("desc bf16x3 vs fp64 oracle", got, want, TOL_DESC)
     model.set_precision("fp32")
     try:
         ref32 = model(x.to(dev)).cpu()
