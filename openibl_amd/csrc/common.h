@@ -183,29 +183,45 @@ __device__ static inline void mx_pack_line(const float (&v)[32], uint4 (&out)[8]
   typedef __attribute__((ext_vector_type(2))) _Float16 h2;
   typedef __attribute__((ext_vector_type(32))) _Float16 h32;
   typedef __attribute__((ext_vector_type(6))) unsigned u6;
-  h32 h;
-  f32x16_t le, lo;   // remainders of the even / odd elements (the fp32 convert interleaves its inputs)
+  typedef __attribute__((ext_vector_type(16))) unsigned u16v_;
+  u16v_ hw_;           // hi[2i], hi[2i + 1] as one dword each
+  f32x16_t le, lo;     // remainders of the even / odd elements (the fp32 convert interleaves its inputs)
+  // Largest |v| of the group (16 x v_max3_f32 with |.| modifiers); the largest |hi| is its fp16 rounding
+  // (rounding is monotonic).  ~70 vector instructions per line instead of ~135: the epilogues of the f16mx
+  // kernels spend most of their time here.
   float amax = 0.f;
 #pragma unroll
-  for (int e = 0; e < 32; e += 2) {
-    const float c0 = __builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
-    const float c1 = __builtin_amdgcn_fmed3f(v[e + 1], -65504.f, 65504.f);
-    const h2 p = __builtin_convertvector((f2){c0, c1}, h2);
-    h[e] = p[0];
-    h[e + 1] = p[1];
-    const float h0 = (float)p[0], h1 = (float)p[1];
-    le[e >> 1] = v[e] - h0;
-    lo[e >> 1] = v[e + 1] - h1;
-    amax = fmaxf(amax, fmaxf(__builtin_fabsf(h0), __builtin_fabsf(h1)));
+  for (int e = 0; e < 32; e += 2) asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(v[e]), "v"(v[e + 1]));
+  // beyond fp16 (never seen on this model): hi saturates at +-65504, the excess goes to lo.  Wave-uniform
+  // branch, so that the 32 clamps are not if-converted into the common path.
+  float c[32];
+#pragma unroll
+  for (int e = 0; e < 32; ++e) c[e] = v[e];
+  if (__builtin_amdgcn_ballot_w64(amax > 65504.f) != 0) {
+#pragma unroll
+    for (int e = 0; e < 32; ++e) c[e] = __builtin_amdgcn_fmed3f(c[e], -65504.f, 65504.f);
   }
+#pragma unroll
+  for (int e = 0; e < 32; e += 2) {
+    const h2 p = __builtin_convertvector((f2){c[e], c[e + 1]}, h2);
+    const unsigned pw = __builtin_bit_cast(unsigned, p);
+    hw_[e >> 1] = pw;
+    // v - hi in ONE instruction: v_fma_mix_f32 reads the fp16 half of its first operand directly (op_sel
+    // picks the half); exact like convert + subtract.  (Written as fmaf the compiler folds the -1 into a
+    // subtraction and converts first.)
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(pw), "v"(v[e]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(pw), "v"(v[e + 1]));
+    le[e >> 1] = r0;
+    lo[e >> 1] = r1;
+  }
+  const h32 h = __builtin_bit_cast(h32, hw_);
+  amax = (float)(_Float16)fminf(amax, 65504.f);
   const int bh = mx_scale_byte(amax), bl = bh - 11;
   const u6 h6 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(h, __builtin_bit_cast(float, (uint32_t)bh << 23));
   const u6 l6 = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(le, lo, __builtin_bit_cast(float, (uint32_t)bl << 23));
-  typedef __attribute__((ext_vector_type(4))) unsigned u4;
-  typedef __attribute__((ext_vector_type(16))) unsigned u16v;
-  const u16v hw = __builtin_bit_cast(u16v, h);
 #pragma unroll
-  for (int s = 0; s < 4; ++s) out[s] = make_uint4(hw[4 * s], hw[4 * s + 1], hw[4 * s + 2], hw[4 * s + 3]);
+  for (int s = 0; s < 4; ++s) out[s] = make_uint4(hw_[4 * s], hw_[4 * s + 1], hw_[4 * s + 2], hw_[4 * s + 3]);
   out[4] = make_uint4(h6[0], h6[1], h6[2], h6[3]);
   out[5] = make_uint4(l6[0], l6[1], l6[2], l6[3]);
   out[6] = make_uint4(h6[4], h6[5], 0u, (unsigned)bh);
