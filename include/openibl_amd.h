@@ -185,15 +185,24 @@ int oibl_vgg16_stem_x3(const float* x_nchw, int N, int H, int W, const float* w1
                        const float* b1, const void* packed_w2, const float* b2, void* out,
                        void* stream);
 
+/* The same fusion in OIBL_F16MX: out [N][H/2][W/2][64] as f16mx lines; packed_w2 from
+ * oibl_pack_conv3x3_weights(..., OIBL_F16MX).  conv1_1 (K = 27) is computed in split bf16, its output is
+ * packed into f16mx lines inside LDS, conv1_2 runs in the f16mx arithmetic (2 fp16 + 1 scaled-fp6 MFMA per 32
+ * channels) and the pooled map leaves as f16mx lines.  The e2m3 image of a lo part is rounded through fp16
+ * here (the other f16mx producers convert it from fp32): its codes can differ by one step from
+ * oibl_mx_split_rows of the same values.  Used automatically by oibl_vgg16_conv5_forward in OIBL_F16MX. */
+int oibl_vgg16_stem_mx(const float* x_nchw, int N, int H, int W, const float* w1_oihw,
+                       const float* b1, const void* packed_w2, const float* b2, void* out,
+                       void* stream);
+
 /* Whole backbone: x [N][3][H][W] fp32 -> feat [N][P][512] T, P = (H/16)*(W/16) (floor at
  * every pool).  packed_w_host / bias_host are HOST arrays of 13 DEVICE pointers: entry 0
  * is the plain [64][3][3][3] fp32 conv1_1 weight, entries 1..12 are packed by
  * oibl_pack_conv3x3_weights; bias entries are [Cout] fp32.
  * OIBL_BF16X3: activations between the layers are (hi, lo) split elements, but `feat` is written as
  * plain fp32 (the head consumes it with OIBL_F32).
- * OIBL_F16MX: entries 1 and 2 (conv1_2, conv2_1) are packed with OIBL_BF16X3 — conv1_1 + conv1_2 + pool
- * run in split bf16 (K = 27 and Cout = 64 fit no MX tile) and conv2_1 reads that map as it is, writing
- * f16mx lines — entries 3..12 with OIBL_F16MX; `feat` is plain fp32.
+ * OIBL_F16MX: every entry packed with OIBL_F16MX (conv1_1 + conv1_2 + pool = oibl_vgg16_stem_mx; the
+ * mode has no unfused front: inputs of 3.5 GB and more are refused); `feat` is plain fp32.
  * The workspace holds the two ping-pong activation buffers and, for small batches, the fp32
  * partial tiles of the layers that run split-K (a layer whose 128-row tiling gives <= 192 tiles is
  * contracted by 2-8 workgroups per tile and reduced in a fixed order: deterministic, equal to

@@ -229,6 +229,73 @@ __device__ static inline void mx_pack_line(const float (&v)[32], uint4 (&out)[8]
 #endif
 }
 
+// The same for ONE LANE'S HALF of a group: 16 elements here, the other 16 in lane ^ 32 — the accumulator
+// layout of a 32x32 MFMA with the group along the rows (lane half hp, registers 4g + r <-> row 8g + 4hp + r).
+// Out: the fp16 hi parts (8 dwords), the e2m3 images of hi and lo (3 dwords each: element e at bits 6e), the
+// two scale bytes (the block's: both lanes compute the same).  ONE convert instruction makes both images:
+// lo goes in as fp16(lo * 2^11) beside hi (|lo| 2^11 <= |hi|: same block scale, and a full 16-register
+// source instead of two half-used ones — these callers have no registers to give away).  lo is thereby
+// rounded twice (fp16, then e2m3; mx_pack_line converts it from fp32): a code can move by one step where
+// the fp16 rounding crosses an e2m3 midpoint — 2^-12 of a term that is itself 2^-11 of the product.
+// CLAMP = false: the caller guarantees |v| <= 65504 (the stems fold the bound into their ReLU).
+template <bool CLAMP = true>
+__device__ static inline void mx_pack_half(const float (&v)[16], unsigned (&h16)[8], unsigned (&h6)[3],
+                                           unsigned (&l6)[3], unsigned& bh, unsigned& bl) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef __attribute__((ext_vector_type(2))) float f2;
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  typedef __attribute__((ext_vector_type(32))) _Float16 h32;
+  typedef __attribute__((ext_vector_type(6))) unsigned u6;
+  typedef __attribute__((ext_vector_type(16))) unsigned u16v_;
+  float amax = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; e += 2) asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(v[e]), "v"(v[e + 1]));
+  {  // the other half's maximum.  v_permlane32_swap exchanges the upper half of its first register with the
+     // lower half of its second: with the maximum in both, every lane finds its partner's in one of them.
+     // (Inline asm: through __builtin_amdgcn_permlane32_swap(x, x) hipcc 7.2 drops the second result — the
+     //  lower lanes then see only their own value.  s_nop: the VALU-write -> permlane hazard is the
+     //  compiler's to handle for the builtin, ours here.)
+    unsigned a = __builtin_bit_cast(unsigned, amax), b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    asm("v_max3_f32 %0, %0, %1, %2" : "+v"(amax) : "v"(a), "v"(b));
+  }
+  float c[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) c[e] = v[e];
+  if constexpr (CLAMP) {
+    if (__builtin_amdgcn_ballot_w64(amax > 65504.f) != 0) {   // never seen on this model; wave-uniform
+#pragma unroll
+      for (int e = 0; e < 16; ++e) c[e] = __builtin_amdgcn_fmed3f(c[e], -65504.f, 65504.f);
+    }
+  }
+  u16v_ w_;   // dwords 0..7: hi pairs, 8..15: fp16(lo * 2^11) pairs
+#pragma unroll
+  for (int e = 0; e < 16; e += 2) {
+    const h2 p = __builtin_convertvector((f2){c[e], c[e + 1]}, h2);
+    const unsigned pw = __builtin_bit_cast(unsigned, p);
+    w_[e >> 1] = pw;
+    h16[e >> 1] = pw;
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(pw), "v"(v[e]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(pw), "v"(v[e + 1]));
+    const h2 q = __builtin_convertvector((f2){r0, r1} * 2048.f, h2);
+    w_[8 + (e >> 1)] = __builtin_bit_cast(unsigned, q);
+  }
+  amax = (float)(_Float16)(CLAMP ? fminf(amax, 65504.f) : amax);
+  const int b = mx_scale_byte(amax);
+  bh = (unsigned)b;
+  bl = (unsigned)(b - 11);
+  const u6 o = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(h32, w_),
+                                                          __builtin_bit_cast(float, (uint32_t)b << 23));
+  h6[0] = o[0];
+  h6[1] = o[1];
+  h6[2] = o[2];
+  l6[0] = o[3];
+  l6[1] = o[4];
+  l6[2] = o[5];
+#endif
+}
+
 // value of e2m3 code c (sign, 2 exponent bits, 3 mantissa bits; bias 1)
 __host__ __device__ static inline float mx_e2m3_value(unsigned c) {
   const int e = (c >> 3) & 3, m = c & 7;

@@ -349,7 +349,6 @@ struct ConvParams {
   int ablate;  // timing experiments only (wrong results): 1 = A loads only at tap 0, 2 = B loads
                // only at the first step, 3 = both
   int out_f32;  // bf16x3 only: the output is written as plain fp32 NHWC (the layer feeding the head)
-  int out_mx;   // bf16x3 operands, f16mx output lines (the layer between the bf16x3 stem and the f16mx layers)
   int korder;   // K order of the implicit GEMM (test hook, see ConvRingALoader::begin_tile)
   // split-K (layers with too few tiles to fill the chip, e.g. conv5 of a single image: 40 tiles):
   // gridDim.y = ksplit workgroups share a tile, each contracts steps/ksplit K-steps from zero and
@@ -775,12 +774,6 @@ static int launch_conv(const ConvParams& p, int pool, hipStream_t st) {
     using C512x64 = GemmCfg<T, 8, 1, 2, 2>;  // Cout = 64 (conv1_2): 64 x 64 per wave instead of 64 x 32
     using C256x64w4 = GemmCfg<T, 4, 1, 2, 2>;  // the same wave tile with 4 waves: 80 KB, two workgroups per CU
     const int rv = (g_regstage || p.ablate || (pool && p.out_f32)) ? 0 : ring_variant(p, 4);
-    if (p.out_mx) {   // bf16x3 in, f16mx out: ring kernels only (conv2_1: 512 x 128 tile, no pooling)
-      if (rv == 4 && !pool) return launch_conv_ring_impl<4, false, false, RING_X3, true>(p, st);
-      if (rv == 2 && !pool) return launch_conv_ring_impl<2, false, false, RING_X3, true>(p, st);
-      set_error("conv3x3 (bf16x3 -> f16mx): unsupported layer cin=%d cout=%d pool=%d", p.cin, p.cout, pool);
-      return OIBL_E_UNSUPPORTED;
-    }
     const long t256 = (p.m_total + 255) / 256;
     const long ring_tiles = rv == 2 ? t256 * (p.cout / 256) : ((p.m_total + 511) / 512) * (p.cout / 128);
     int mode = g_conv_tile;
@@ -1542,7 +1535,7 @@ __global__ __launch_bounds__(512) void vgg_stem_kernel(StemParams p) {
   auto store_px = [&](int e) __attribute__((always_inline)) {
     __builtin_amdgcn_raw_buffer_store_b32(pend[e], rs_o, (int)(poff + 256u * e), 0, 0);
   };
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), as the builtin: see the f16mx consumers
   __builtin_amdgcn_s_barrier();
   for (int it = 0; it < niter; ++it) {
     const unsigned long long c0 = cprof ? __builtin_amdgcn_s_memtime() : 0;
@@ -1694,9 +1687,22 @@ __device__ static inline void x3_split_pair(float v0, float v1, uint32_t& hi, ui
 }
 
 constexpr int S3_W_BYTES = 2 * 9 * 32 * 128;
-constexpr int S3_BIAS_OFF = S3_W_BYTES + 2 * ST_HALO_BYTES;   // conv1_1 bias: 64 floats
-constexpr int S3_LDS_BYTES = S3_BIAS_OFF + 256;
+constexpr int S3_BIAS_OFF = S3_W_BYTES + 2 * ST_HALO_BYTES;   // conv1_1 bias: 64 floats; MX: + this half's 32 of conv1_2
+constexpr int S3_LDS_BYTES = S3_BIAS_OFF + 256 + 128;
 
+// MX = true: the f16mx stem.  Same roles, tiles, passes and hand-overs; what changes is the arithmetic of
+// conv1_2 (2 f16 + 1 scaled-fp6 MFMA per 32 K instead of 6 bf16 ones) and therefore every format:
+//   * the halo buffers hold f16mx lines (common.h) of conv1_1's output.  A 32-channel group lies along the
+//     ROWS of conv1_1's accumulator tile — a lane holds 16 of a pixel's 32 channels, lane ^ 32 the rest — and
+//     which channel sits in which row is free: row 8g + 4hp + r carries channel 16hp + 4g + r, so that a lane
+//     owns 16 CONSECUTIVE elements of the line and packs them alone (mx_pack_half: one cross-lane maximum);
+//   * conv1_2 runs transposed for the same reason — A = weights (rows = output channels, in the same row
+//     order), B = halo pixels — its 2x2 max-pool is two DPP quad steps over lanes, and the pooled pixel's
+//     32 channels are again one lane pair: the f16mx lines of the output map are written straight from
+//     registers (a workgroup's 32 output channels are exactly one group);
+//   * conv1_2's weights are the packed f16mx tensor of oibl_pack_conv3x3_weights(OIBL_F16MX).
+// conv1_1 itself stays split bf16 (K = 27: 6 MFMAs per 32 pixels x 32 channels, a quarter of a pass).
+template <bool MX>
 __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const wl = smem;                 // [pass h][tap][32 cout][32 hi | 32 lo of input channels 32h..]
@@ -1712,6 +1718,8 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
   const int Ho = p.H >> 1, Wo = p.W >> 1;
   // conv1_1's bias lives in LDS (the producers have no registers to spare for 2 x 16 values per lane)
   if (threadIdx.x < 64) reinterpret_cast<float*>(smem + S3_BIAS_OFF)[threadIdx.x] = p.b1[threadIdx.x];
+  if (MX && threadIdx.x >= 64 && threadIdx.x < 96)
+    reinterpret_cast<float*>(smem + S3_BIAS_OFF)[threadIdx.x] = p.b2[co0 + threadIdx.x - 64];
   __syncthreads();
 
   if (wave >= 4) {
@@ -1742,7 +1750,8 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
         const int k = 16 * s + 8 * half + e;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const float v = k < 27 ? p.w1[(32 * h + l31) * 27 + k] : 0.f;
+          const int ch = MX ? 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3) : l31;   // channel of row l31
+          const float v = k < 27 ? p.w1[(32 * h + ch) * 27 + k] : 0.f;
           uint16_t hi, lo;
           x3_split(v, hi, lo);
           wh[h][s][e] = (short)hi;
@@ -1750,7 +1759,8 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
         }
       }
     // accumulator rows of this lane: channels 8 j + 4 half + 0..3 (j = 0..3) of the pass's 32
-    const float* const bias_l = reinterpret_cast<const float*>(smem + S3_BIAS_OFF) + 4 * half;
+    // (MX: registers 4 j + r = channels 16 half + 4 j + r)
+    const float* const bias_l = reinterpret_cast<const float*>(smem + S3_BIAS_OFF) + (MX ? 16 : 4) * half;
     const int plane = p.H * p.W;
 
     // tile-independent lane geometry (as in vgg_stem_kernel)
@@ -1870,7 +1880,7 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
         f32x16_t acc;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float4 b = *reinterpret_cast<const float4*>(bias_l + 32 * h + 8 * j);
+          const float4 b = *reinterpret_cast<const float4*>(bias_l + 32 * h + (MX ? 4 : 8) * j);
           acc[4 * j] = b.x;
           acc[4 * j + 1] = b.y;
           acc[4 * j + 2] = b.z;
@@ -1895,7 +1905,35 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
           const int y = y0 + hy, x = x0 + hx;
           pix_ok = y >= 0 && y < p.H && x >= 0 && x < p.W;
         }
-        if (row_of(bi) < ST_HALO_PX) {
+        if constexpr (MX) {
+          // this lane's 16 consecutive elements of the pixel's line: fp16 parts = 16-B slots 2 half, 2 half + 1;
+          // e2m3 images = dwords 3 half .. 3 half + 2 of the 6-dword strings, which the line keeps as
+          // slot 4 / 5 (hi / lo: dwords 0-3) and slot 6 / 7 (dwords 4, 5, zero, scale byte)
+          typedef __attribute__((ext_vector_type(4))) unsigned u4;
+          typedef __attribute__((ext_vector_type(3))) unsigned u3;
+          // ReLU, the fp16 bound and conv1_2's zero padding (a halo pixel outside the image) in ONE v_med3
+          float c[16];
+          const float lim = pix_ok ? 65504.f : 0.f;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) c[j] = __builtin_amdgcn_fmed3f(acc[j], 0.f, lim);
+          unsigned h16[8], h6[3], l6[3], bh, bl;
+          mx_pack_half<false>(c, h16, h6, l6, bh, bl);
+          if (row_of(bi) < ST_HALO_PX) {
+            char* row = buf + row_of(bi) * 128;
+            const int sw = g_swz[bi];
+            *reinterpret_cast<u4*>(row + (((2 * half) ^ sw) << 4)) = (u4){h16[0], h16[1], h16[2], h16[3]};
+            *reinterpret_cast<u4*>(row + (((2 * half + 1) ^ sw) << 4)) = (u4){h16[4], h16[5], h16[6], h16[7]};
+            if (half == 0) {
+              *reinterpret_cast<u3*>(row + ((4 ^ sw) << 4)) = (u3){h6[0], h6[1], h6[2]};
+              *reinterpret_cast<u3*>(row + ((5 ^ sw) << 4)) = (u3){l6[0], l6[1], l6[2]};
+            } else {
+              *reinterpret_cast<unsigned*>(row + ((4 ^ sw) << 4) + 12) = h6[0];
+              *reinterpret_cast<unsigned*>(row + ((5 ^ sw) << 4) + 12) = l6[0];
+              *reinterpret_cast<u4*>(row + ((6 ^ sw) << 4)) = (u4){h6[1], h6[2], 0u, bh};
+              *reinterpret_cast<u4*>(row + ((7 ^ sw) << 4)) = (u4){l6[1], l6[2], 0u, bl};
+            }
+          }
+        } else if (row_of(bi) < ST_HALO_PX) {
           char* row = buf + row_of(bi) * 128 + 8 * half;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
@@ -1961,6 +1999,243 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
   }
 
   // ================================== consumers ================================================
+  if constexpr (MX) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u4;
+    typedef __attribute__((ext_vector_type(2))) unsigned u2;
+    typedef __attribute__((ext_vector_type(4))) int i4;
+    {
+      const int cprio = (p.prod_prio >> 2) & 3;   // test hook: the consumers' issue priority
+      if (cprio == 1) __builtin_amdgcn_s_setprio(1);
+      else if (cprio == 2) __builtin_amdgcn_s_setprio(2);
+      else if (cprio == 3) __builtin_amdgcn_s_setprio(3);
+    }
+    {
+      // conv1_2's weights: LDS row (h * 9 + tap) * 32 + m = the f16mx line of output channel co0 + chan(m),
+      // input group h; 16-byte slots swizzled by (m >> 1) & 7
+      const int piece = ((lane & 7) ^ (4 * (wave & 1) + (lane >> 4))) * 16;
+#pragma unroll
+      for (int j = 0; j < 18; ++j) {
+        const int q = j * 4 + wave;
+        const int r = q * 8 + (lane >> 3);
+        const int h = r / 288, rem = r - 288 * h;
+        const int tap = rem >> 5, m = rem & 31;
+        const int ch = 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3);
+        glds16(p.w2 + ((long)(tap * 64 + co0 + ch) * 256 + h * 128) + piece, wl + q * 1024);
+      }
+    }
+    // Pixel (B) fragments: the bf16x3 consumers' addressing (below): lane (pixel l31 of block i, k-half hc)
+    // reads fp16 slot 2 s + hc for the two f16 MFMAs and — the B side of the scaled MFMA pairs q6(lo) with
+    // the weights' q6(hi) in K-block 0 and the other way round in block 1 — slots 5 - hc / 7 - hc: all of
+    // them (e_kx ^ const) + pc, the constants 0, 32, 80, 112 (^ 64 on odd tap rows).
+    int e_kx[3], pxb;
+    {
+      const int ly = 2 * wave + ((l31 >> 1) & 1);
+      const int lx = 2 * (l31 >> 2) + (l31 & 1);
+      const int fix = half ^ ((ly & 1) << 2);
+      e_kx[0] = (fix ^ ((lx >> 1) & 7)) << 4;
+      e_kx[2] = (fix ^ (((lx >> 1) + 1) & 7)) << 4;
+      e_kx[1] = (lx & 1) ? e_kx[2] : e_kx[0];
+      pxb = (ly * C64_HW + lx) * 128;
+    }
+    int w_off[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) w_off[kk] = l31 * 128 + (((2 * kk + half) ^ ((l31 >> 1) & 7)) << 4);
+    // (the builtin, not inline asm: the compiler models a pending global_load_lds as a FLAT access and turns
+    //  every later lgkmcnt wait into lgkmcnt(0) until IT has seen vmcnt(0))
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    const bool cprof = p.prof != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0;
+    unsigned long long ct[3] = {0, 0, 0};
+    f32x16_t acc[2];
+    // operand registers, single-buffered: a fragment is reloaded for the next tap right behind the last
+    // MFMA that reads it, and the MFMA order (w0.b0, w0.b1, w1.b0, w1.b1, wm.b0, wm.b1 — accumulators
+    // alternate) leaves every reload at least four MFMAs (128 cycles) before its first use
+    f16x8_t w0, w1, b0[2], b1[2];
+    u4 wma, bma[2];
+    u2 wmd, bmd[2];
+    unsigned wms, bms[2];
+    auto run_pass = [&](auto h_c) __attribute__((always_inline)) {
+      constexpr int h = decltype(h_c)::value;
+      const unsigned long long c0 = cprof ? __builtin_amdgcn_s_memtime() : 0;
+      const int pc = pxb + S3_W_BYTES + h * ST_HALO_BYTES;
+      if (h == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+      }
+      auto paddr = [&](int tap, int part) __attribute__((always_inline)) {
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        const int c = (part == 0 ? 0 : part == 1 ? 32 : part == 2 ? 80 : 112) ^ ((ky & 1) << 6);
+        int a;
+        asm("v_xad_u32 %0, %1, %2, %3" : "=v"(a) : "v"(e_kx[kx]), "s"(c), "v"(pc));
+        return a;
+      };
+      auto pbase = [&](int tap, int i) __attribute__((always_inline)) {
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        return smem + (ky * C64_HW + kx) * 128 + i * 2048;
+      };
+      auto ld_b0 = [&](int tap, int i, int a) __attribute__((always_inline)) { b0[i] = *reinterpret_cast<const f16x8_t*>(pbase(tap, i) + a); };
+      auto ld_b1 = [&](int tap, int i, int a) __attribute__((always_inline)) { b1[i] = *reinterpret_cast<const f16x8_t*>(pbase(tap, i) + a); };
+      auto ld_bm = [&](int tap, int i, int a2, int a3) __attribute__((always_inline)) {
+        bma[i] = *reinterpret_cast<const u4*>(pbase(tap, i) + a2);
+        bmd[i] = *reinterpret_cast<const u2*>(pbase(tap, i) + a3);
+        bms[i] = *reinterpret_cast<const unsigned*>(pbase(tap, i) + a3 + 12);
+      };
+      auto ld_w0 = [&](int tap) __attribute__((always_inline)) { w0 = *reinterpret_cast<const f16x8_t*>(smem + tap * 4096 + w_off[0]); };
+      auto ld_w1 = [&](int tap) __attribute__((always_inline)) { w1 = *reinterpret_cast<const f16x8_t*>(smem + tap * 4096 + w_off[1]); };
+      auto ld_wm = [&](int tap) __attribute__((always_inline)) {
+        wma = *reinterpret_cast<const u4*>(smem + tap * 4096 + w_off[2]);
+        wmd = *reinterpret_cast<const u2*>(smem + tap * 4096 + w_off[3]);
+        wms = *reinterpret_cast<const unsigned*>(smem + tap * 4096 + w_off[3] + 12);
+      };
+      auto mx = [&](int i) __attribute__((always_inline)) {
+        const i32x8_t a8 = __builtin_shufflevector(__builtin_bit_cast(i4, wma),
+                                                   __builtin_bit_cast(i4, (u4){wmd.x, wmd.y, wms, 0u}), 0, 1, 2, 3, 4, 5, 6, 7);
+        const i32x8_t b8 = __builtin_shufflevector(__builtin_bit_cast(i4, bma[i]),
+                                                   __builtin_bit_cast(i4, (u4){bmd[i].x, bmd[i].y, bms[i], 0u}), 0, 1, 2, 3, 4, 5, 6, 7);
+        acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[i], 2, 2, 0, a8[6], 0, b8[6]);
+      };
+      {
+        const int a0 = paddr(0, 0), a1 = paddr(0, 1), a2 = paddr(0, 2), a3 = paddr(0, 3);
+        ld_w0(0);
+        ld_b0(0, 0, a0);
+        ld_b0(0, 1, a0);
+        ld_w1(0);
+        ld_b1(0, 0, a1);
+        ld_b1(0, 1, a1);
+        ld_wm(0);
+        ld_bm(0, 0, a2, a3);
+        ld_bm(0, 1, a2, a3);
+      }
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        // (sched_barrier: the order below IS the schedule — left alone, the scheduler sinks every reload to
+        //  just in front of its use, for register pressure it does not have, and waits lgkmcnt(0) per MFMA)
+        const bool more = tap + 1 < 9;
+        const int n = tap + 1;
+        int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, b0[0], acc[0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (tap > 0) ld_wm(tap);   // (not behind the previous tap's last MFMA: 15 reads in flight there, and the
+                                   //  compiler answers a full lgkmcnt counter with lgkmcnt(0))
+        if (more) {
+          a0 = paddr(n, 0);
+          ld_b0(n, 0, a0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, b0[1], acc[1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+          ld_w0(n);
+          ld_b0(n, 1, a0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b1[0], acc[0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+          a1 = paddr(n, 1);
+          ld_b1(n, 0, a1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, b1[1], acc[1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+          ld_w1(n);
+          ld_b1(n, 1, a1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mx(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+          a2 = paddr(n, 2);
+          a3 = paddr(n, 3);
+          ld_bm(n, 0, a2, a3);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mx(1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) ld_bm(n, 1, a2, a3);
+      }
+      // every fragment read of this halo buffer has been consumed: hand it back
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const unsigned long long c1 = cprof ? __builtin_amdgcn_s_memtime() : 0;
+      __builtin_amdgcn_s_barrier();
+      if (cprof) {
+        ct[0] += c1 - c0;
+        ct[1] += __builtin_amdgcn_s_memtime() - c1;
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) w_off[kk] += h == 0 ? 9 * 32 * 128 : -(9 * 32 * 128);
+    };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    const float* const bias2 = reinterpret_cast<const float*>(smem + S3_BIAS_OFF) + 64 + 16 * half;
+    for (int it = 0; it < niter; ++it) {
+      run_pass(C0{});
+      run_pass(C1{});
+      const unsigned long long e0 = cprof ? __builtin_amdgcn_s_memtime() : 0;
+      // 2x2 max-pool (the window = the lane quad: two DPP steps), bias, ReLU, pack, store.  Lane quad q of
+      // block i is pooled pixel (wave, 8 i + q) of the tile's 4 x 16.
+      const int tile = first + it * stride;
+      const unsigned r2 = (unsigned)tile / (unsigned)p.tiles_x;
+      const int tx = tile - (int)r2 * p.tiles_x;
+      const int n = (int)(r2 / (unsigned)p.tiles_y), ty = (int)r2 - n * p.tiles_y;
+      const int oy = ty * 4 + wave;
+      // ONE OUTPUT ROW of the map as the buffer: a pixel right of the map, a row below it (zero records) and
+      // the three non-leader lanes of a quad (offset 2^31) are dropped by the hardware — no branch
+      const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(
+          p.out + ((long)n * Ho + oy) * Wo * 256, 0, oy < Ho ? Wo * 256 : 0, 0x00020000);
+      float bv[16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 b = *reinterpret_cast<const float4*>(bias2 + 4 * j);
+        bv[4 * j] = b.x;
+        bv[4 * j + 1] = b.y;
+        bv[4 * j + 2] = b.z;
+        bv[4 * j + 3] = b.w;
+      }
+      {
+        // pooling: the window's x pair first (lane ^ 1), then the two blocks merge — even lanes keep block 0,
+        // odd lanes block 1 — and the y pair (lane ^ 2) follows on the merged values: ONE line per lane pair
+        float v[16];
+        const bool odd = l31 & 1;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          float t0 = acc[0][j], t1 = acc[1][j];
+          t0 = fmaxf(t0, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, t0), 0xB1, 0xF, 0xF, true)));
+          t1 = fmaxf(t1, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, t1), 0xB1, 0xF, 0xF, true)));
+          float t = odd ? t1 : t0;
+          t = fmaxf(t, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, t), 0x4E, 0xF, 0xF, true)));
+          v[j] = __builtin_amdgcn_fmed3f(t + bv[j], 0.f, 65504.f);   // bias, ReLU, the fp16 bound
+        }
+        unsigned h16[8], h6[3], l6[3], bh, bl;
+        mx_pack_half<false>(v, h16, h6, l6, bh, bl);
+        // lanes 0, 1 of a quad store: pooled pixel 8 (l31 & 1) + (l31 >> 2) of the tile row
+        const unsigned off = (l31 & 2) ? 0x80000000u
+                                       : (unsigned)(tx * 16 + 8 * (l31 & 1) + (l31 >> 2)) * 256u + blockIdx.y * 128u;
+        __builtin_amdgcn_raw_buffer_store_b128((u4){h16[0], h16[1], h16[2], h16[3]}, rs_o, (int)(off + 32 * half), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128((u4){h16[4], h16[5], h16[6], h16[7]}, rs_o, (int)(off + 32 * half + 16), 0, 0);
+        // e2m3 strings: this lane's dwords 3 half .. 3 half + 2; dwords 0-3 in slot 4 / 5, dwords 4, 5 in slot 6 / 7
+        const unsigned oa = off + (half ? 76u : 64u), ob = off + (half ? 96u : 68u);
+        __builtin_amdgcn_raw_buffer_store_b32(h6[0], rs_o, (int)oa, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64((u2){h6[1], h6[2]}, rs_o, (int)ob, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(l6[0], rs_o, (int)(oa + 16), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64((u2){l6[1], l6[2]}, rs_o, (int)(ob + 16), 0, 0);
+        const unsigned ot = half ? off + 104u : 0x80000000u;   // the tails' zero dword + scale byte
+        __builtin_amdgcn_raw_buffer_store_b64((u2){0u, bh}, rs_o, (int)ot, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64((u2){0u, bl}, rs_o, (int)(ot + 16), 0, 0);
+      }
+      if (cprof) ct[2] += __builtin_amdgcn_s_memtime() - e0;
+    }
+    if (cprof && lane == 0) {
+      p.prof[0] = ct[0];
+      p.prof[1] = ct[1];
+      p.prof[2] = ct[2];
+    }
+    return;
+  }
   {
     const int cprio = (p.prod_prio >> 2) & 3;   // test hook: the consumers' issue priority
     if (cprio == 1) __builtin_amdgcn_s_setprio(1);
@@ -2019,7 +2294,7 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
   auto store_px = [&](int e) __attribute__((always_inline)) {
     __builtin_amdgcn_raw_buffer_store_b32(pend[e], rs_o, (int)(poff + 512u * e), 0, 0);
   };
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), as the builtin: see the f16mx consumers
   __builtin_amdgcn_s_barrier();
   const bool cprof = p.prof != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0;
   unsigned long long ct[3] = {0, 0, 0};
@@ -2131,7 +2406,8 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
 }
 
 static int launch_vgg_stem_x3(const float* x, int N, int H, int W, const float* w1, const float* b1,
-                              const void* packed_w2, const float* b2, void* out, hipStream_t st) {
+                              const void* packed_w2, const float* b2, void* out, hipStream_t st,
+                              bool mx = false) {
   StemParams p = {};
   p.x = x;
   p.w1 = w1;
@@ -2149,12 +2425,20 @@ static int launch_vgg_stem_x3(const float* x, int N, int H, int W, const float* 
   OIBL_REQUIRE(nt < 0x7fffffffL, "vgg stem: too many tiles");
   p.ntiles = (int)nt;
   p.prof = g_prof_buf;
-  p.prod_prio = g_stem3_prio;
+  // f16mx: producers at priority 2, consumers at 3 unless the hook says otherwise (tests/gpu_stem_mx_bench.py:
+  // 1.72 ms against 1.80 ms with equal priorities; the bf16x3 roles are at their best with equal ones)
+  p.prod_prio = (mx && g_stem3_prio == 0) ? 14 : g_stem3_prio;
   int gx = 128;  // two workgroups (output-channel halves) per tile range: one persistent workgroup per CU
   if (gx > p.ntiles) gx = p.ntiles;
-  auto kern = vgg_stem_x3_kernel;
-  OIBL_SET_MAX_LDS(kern, S3_LDS_BYTES);
-  hipLaunchKernelGGL(kern, dim3(gx, 2), dim3(1024), S3_LDS_BYTES, st, p);
+  if (mx) {
+    auto kern = vgg_stem_x3_kernel<true>;
+    OIBL_SET_MAX_LDS(kern, S3_LDS_BYTES);
+    hipLaunchKernelGGL(kern, dim3(gx, 2), dim3(1024), S3_LDS_BYTES, st, p);
+  } else {
+    auto kern = vgg_stem_x3_kernel<false>;
+    OIBL_SET_MAX_LDS(kern, S3_LDS_BYTES);
+    hipLaunchKernelGGL(kern, dim3(gx, 2), dim3(1024), S3_LDS_BYTES, st, p);
+  }
   OIBL_LAUNCH_CHECK();
   return OIBL_OK;
 }
@@ -2261,7 +2545,7 @@ static size_t conv_splitk_bytes(long m_total, int cin, int cout, int precision) 
 
 static int conv3x3_impl(const void* in, int N, int H, int W, int cin, const void* packed_w,
                         const float* bias, int cout, int relu, int pool, int precision, void* out,
-                        hipStream_t st, int out_f32 = 0, void* splitk_ws = nullptr, int out_mx = 0) {
+                        hipStream_t st, int out_f32 = 0, void* splitk_ws = nullptr) {
   OIBL_REQUIRE(in && packed_w && bias && out, "conv3x3: null pointer");
   OIBL_REQUIRE(precision_ok(precision), "conv3x3: bad precision %d", precision);
   const int bk = precision == OIBL_BF16 ? 64 : 32;
@@ -2292,7 +2576,6 @@ static int conv3x3_impl(const void* in, int N, int H, int W, int cin, const void
   p.relu = relu;
   p.ablate = g_conv_ablate;
   p.out_f32 = (precision == OIBL_BF16X3 || precision == OIBL_F16MX) ? out_f32 : 0;
-  p.out_mx = precision == OIBL_BF16X3 ? out_mx : 0;
   p.korder = conv_korder_for(precision, cin, cout);
   p.tiles_n = 0;
   if (pool) {
@@ -2304,7 +2587,7 @@ static int conv3x3_impl(const void* in, int N, int H, int W, int cin, const void
   }
   p.ksplit = 0;
   p.partial = (float*)splitk_ws;
-  if (splitk_ws && g_conv_splitk && precision != OIBL_F16MX && !p.out_mx)
+  if (splitk_ws && g_conv_splitk && precision != OIBL_F16MX)
     p.ksplit = conv_splitk_factor(p.m_total, cout, 9 * (cin / bk));
   if (precision == OIBL_F16MX) return launch_conv_mx(p, pool, st);
   if (precision == OIBL_BF16X3) return launch_conv<bf16x3_t>(p, pool, st);
@@ -2351,6 +2634,16 @@ int oibl_vgg16_stem_x3(const float* x_nchw, int N, int H, int W, const float* w1
   OIBL_REQUIRE((uintptr_t)packed_w2 % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)x_nchw % 4 == 0,
                "vgg16_stem_x3: packed weights / output must be 16-byte aligned");
   return launch_vgg_stem_x3(x_nchw, N, H, W, w1_oihw, b1, packed_w2, b2, out, (hipStream_t)stream);
+}
+
+int oibl_vgg16_stem_mx(const float* x_nchw, int N, int H, int W, const float* w1_oihw, const float* b1,
+                       const void* packed_w2, const float* b2, void* out, void* stream) {
+  OIBL_REQUIRE(x_nchw && w1_oihw && b1 && packed_w2 && b2 && out, "vgg16_stem_mx: null pointer");
+  OIBL_REQUIRE(N > 0 && H >= 2 && W >= 2, "vgg16_stem_mx: bad shape N=%d H=%d W=%d", N, H, W);
+  OIBL_REQUIRE(stem_eligible(N, H, W), "vgg16_stem_mx: input of %d x 3 x %d x %d exceeds 3.5 GB", N, H, W);
+  OIBL_REQUIRE((uintptr_t)packed_w2 % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)x_nchw % 4 == 0,
+               "vgg16_stem_mx: packed weights / output must be 16-byte aligned");
+  return launch_vgg_stem_x3(x_nchw, N, H, W, w1_oihw, b1, packed_w2, b2, out, (hipStream_t)stream, true);
 }
 
 #ifdef OIBL_DEBUG_HOOKS
@@ -2634,11 +2927,13 @@ static int vgg_forward_impl(const void* x, int u8, const float* mean3, const flo
   const bool mx = precision == OIBL_F16MX;
   const bool fused3 = (precision == OIBL_BF16X3 || mx) && g_stem_fused && stem_eligible(N, H, W) && !g_regstage &&
                       !g_conv_ablate && g_conv_tile == 0;
+  // f16mx has no unfused front (Cout = 64 fits no f16mx tile): conv1_2's weights are packed for the stem
+  OIBL_REQUIRE(!mx || fused3, "vgg16: the f16mx backbone needs the fused stem (input below 3.5 GB, no stem / tile hooks)");
   if (fused3) {
-    // bf16x3: conv1_1 + conv1_2 + pool in one launch (the uint8 entry has normalised into x_f32)
+    // bf16x3 / f16mx: conv1_1 + conv1_2 + pool in one launch (the uint8 entry has normalised into x_f32)
     if (ev_igemm_begin) OIBL_HIP_CHECK(hipEventRecord((hipEvent_t)ev_igemm_begin, st));
     rc = launch_vgg_stem_x3(x_f32, N, H, W, (const float*)packed_w_host[0], bias_host[0], packed_w_host[1],
-                            bias_host[1], bufB, st);
+                            bias_host[1], bufB, st, mx);
     if (rc) return rc;
     h /= 2;
     w /= 2;
@@ -2657,31 +2952,15 @@ static int vgg_forward_impl(const void* x, int u8, const float* mean3, const flo
     cur = bufB;
     l0 = 2;
   } else {
-    rc = oibl_conv1_1_nchw(x_f32, N, H, W, (const float*)packed_w_host[0], bias_host[0],
-                           mx ? OIBL_BF16X3 : precision, bufA, stream);
+    rc = oibl_conv1_1_nchw(x_f32, N, H, W, (const float*)packed_w_host[0], bias_host[0], precision, bufA, stream);
     if (rc) return rc;
     if (ev_igemm_begin) OIBL_HIP_CHECK(hipEventRecord((hipEvent_t)ev_igemm_begin, st));
-    if (mx) {  // conv1_2 in bf16x3 as well (Cout = 64: no ring tile), see below
-      rc = conv3x3_impl(bufA, N, h, w, kVgg[1].cin, packed_w_host[1], bias_host[1], kVgg[1].cout, kVgg[1].relu,
-                        kVgg[1].pool, OIBL_BF16X3, bufB, st);
-      if (rc) return rc;
-      h /= 2;
-      w /= 2;
-      cur = bufB;
-      l0 = 2;
-    }
   }
-  // f16mx: conv1_1 + conv1_2 + pool run in bf16x3 (K = 27 and Cout = 64 fit no MX tile), and so does conv2_1,
-  // which reads the stem's (hi, lo) map as it is and WRITES f16mx lines (its ring kernel with the f16mx
-  // epilogue): no re-pack pass over the 629 MB map (0.26 ms per batch); 0.93 ms in bf16x3 against 0.79 ms
-  // in f16mx for the layer itself.  conv2_2 .. conv5_3 are f16mx.
   for (int l = l0; l < OIBL_VGG16_NUM_CONV; ++l) {
     void* dst = (l == OIBL_VGG16_NUM_CONV - 1) ? feat : (l % 2 == 0 ? (void*)bufA : (void*)bufB);
-    // bf16x3: the last layer hands the head a plain fp32 map
-    const bool bridge = mx && l == 2;   // conv2_1 of an f16mx forward
+    // bf16x3 / f16mx: the last layer hands the head a plain fp32 map
     rc = conv3x3_impl(cur, N, h, w, kVgg[l].cin, packed_w_host[l], bias_host[l], kVgg[l].cout,
-                      kVgg[l].relu, kVgg[l].pool, bridge ? OIBL_BF16X3 : precision, dst, st,
-                      l == OIBL_VGG16_NUM_CONV - 1, bridge ? nullptr : splitk, bridge ? 1 : 0);
+                      kVgg[l].relu, kVgg[l].pool, precision, dst, st, l == OIBL_VGG16_NUM_CONV - 1, splitk);
     if (rc) return rc;
     if (kVgg[l].pool) {
       h /= 2;

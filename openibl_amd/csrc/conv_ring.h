@@ -213,8 +213,9 @@ __device__ static inline void ring_split4(float a0, float a1, float a2, float a3
   lo.y = __builtin_bit_cast(uint32_t, __builtin_convertvector((f2){r2, r3}, bf2));
 }
 
-// OUTMX: the OUTPUT is written as f16mx lines although the operands are bf16x3 (P = RING_X3): the layer
-// that takes the bf16x3 stem's map into the f16mx part of the backbone (conv2_1) — no re-pack pass.
+// OUTMX: the output is written as f16mx lines (always with f16mx operands; the parameter exists because the
+// epilogue only depends on it: bf16x3 operands with f16mx output compile too — round 3 ran conv2_1 that way
+// until the stem itself became f16mx).
 template <int WM, bool POOL, bool ODD, int P = RING_BF16, bool OUTMX = (P >= RING_MX)>
 __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
   using G = RingGeo<WM>;

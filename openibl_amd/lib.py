@@ -46,6 +46,8 @@ SIGNATURES = {
                                      c_void_p, c_void_p, c_void_p]),
     "oibl_vgg16_stem_x3": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p]),
+    "oibl_vgg16_stem_mx": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p]),
     "oibl_netvlad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "oibl_netvlad_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                      c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t,

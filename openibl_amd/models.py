@@ -146,6 +146,8 @@ class VGG(_PrecisionMixin, nn.Module):
         n = int(x.shape[0])
         h, w = (int(x.shape[1]), int(x.shape[2])) if x.dtype == torch.uint8 else (int(x.shape[2]), int(x.shape[3]))
         tiles = -(-(n * (h // 8) * (w // 8)) // 256) * 2
+        if n * 3 * h * w * 4 >= 0xE0000000:      # beyond the fused stem's 32-bit offsets: f16mx has no other front
+            return "bf16x3"
         return p if tiles >= self.F16MX_MIN_TILES else "bf16x3"
 
     def _packed(self, device: torch.device, precision: str = None):
@@ -161,12 +163,7 @@ class VGG(_PrecisionMixin, nn.Module):
         hit = self._cache["packed"].get(precision)
         if hit is None:
             ws = [convs[0].weight.detach().float().contiguous()]
-            # f16mx: conv1_1 + conv1_2 + pool run in split bf16 (K = 27 / Cout = 64 fit no MX tile) and conv2_1
-            # reads their map as it is (its kernel writes f16mx lines): both are packed for bf16x3
-            prec = [("bf16x3" if (i in (1, 2) and ops.precision_code(precision) == ops.F16MX) else precision)
-                    for i in range(len(convs))]
-            ws += [ops.pack_conv3x3(c.weight.detach().float().contiguous(), prec[i])
-                   for i, c in enumerate(convs) if i >= 1]
+            ws += [ops.pack_conv3x3(c.weight.detach().float().contiguous(), precision) for c in convs[1:]]
             bs = [c.bias.detach().float().contiguous() for c in convs]
             hit = self._cache["packed"][precision] = (ws, bs)
         return hit

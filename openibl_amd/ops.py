@@ -302,6 +302,23 @@ def vgg16_stem_x3(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, packed_w2
     return out
 
 
+def vgg16_stem_mx(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, packed_w2: torch.Tensor,
+                  b2: torch.Tensor) -> torch.Tensor:
+    """Fused f16mx stem: x [N][3][H][W] fp32 -> [N][H//2][W//2][64] f16mx lines (int32 container);
+    packed_w2 = pack_conv3x3(conv1_2, "f16mx")."""
+    dev = _need_cuda(x, w1, b1, packed_w2, b2)
+    if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3:
+        raise ValueError("vgg16_stem_mx expects a float32 [N][3][H][W] tensor")
+    if tuple(w1.shape) != (64, 3, 3, 3) or tuple(packed_w2.shape) != (9, 64, 64) \
+            or packed_w2.dtype != torch.int32:
+        raise ValueError("vgg16_stem_mx: conv1_1 must be [64][3][3][3] fp32, conv1_2 packed f16mx [9][64][64]")
+    N, _, H, W = map(int, x.shape)
+    out = torch.empty((N, H // 2, W // 2, 64), dtype=torch.int32, device=dev)
+    _lib.check(_lib.load().oibl_vgg16_stem_mx(_ptr(x), N, H, W, _ptr(w1), _ptr(b1), _ptr(packed_w2),
+                                              _ptr(b2), _ptr(out), _stream(dev)), "vgg16_stem_mx")
+    return out
+
+
 def vgg16_feature_hw(H: int, W: int) -> Tuple[int, int]:
     for _ in range(4):
         H, W = H // 2, W // 2

@@ -196,21 +196,36 @@ def test_mx_batch_rows_independent_and_graphed(model, dev):
     assert torch.equal(a, want) and torch.equal(b, want)
 
 
-def test_vgg16_backbone_mx_stem_toggle(dev, state_dict):
-    """The backbone entry with and without the fused (bf16x3) stem in front of the f16mx layers."""
-    x = synth.images(2, 64, 96, seed=4).to(dev)
-    ws = [state_dict[f"base_model.base.{i}.weight"].to(dev) for i in synth.CONV_IDX]
-    bs = [state_dict[f"base_model.base.{i}.bias"].to(dev) for i in synth.CONV_IDX]
-    packed = [ws[0], ops.pack_conv3x3(ws[1], "bf16x3"), ops.pack_conv3x3(ws[2], "bf16x3")] + \
-        [ops.pack_conv3x3(w, "f16mx") for w in ws[3:]]
-    a = ops.vgg16_conv5(x, packed, bs, "f16mx")
-    ops.set_stem_fused(False)
-    try:
-        b = ops.vgg16_conv5(x, packed, bs, "f16mx")
-    finally:
-        ops.set_stem_fused(True)
-    assert a.dtype == torch.float32
-    assert_rel_l2("backbone f16mx, fused vs unfused stem", a.cpu(), b.cpu(), 6e-5)
+@pytest.mark.parametrize("N,H,W", [(1, 8, 32), (2, 16, 64), (1, 21, 45), (3, 30, 70), (1, 2, 2),
+                                   (2, 9, 33), (1, 64, 96), (5, 40, 136)])
+def test_vgg_stem_mx_fused(dev, N, H, W):
+    """f16mx: conv1_1 (split bf16) + conv1_2 (f16mx arithmetic on f16mx lines packed inside LDS) + pool in one
+    launch, output = f16mx lines packed from registers.  Against the fp64 host convolutions (one f16mx
+    contraction + two line roundings), and the stored lines against the format: every line must be what
+    mx_split makes of its own fp16 parts (slots, element order, block scale, the e2m3 image of hi), with
+    |q6(lo)| inside half an fp16 ulp of the group's largest element."""
+    x, w1, b1 = _case(N, H, W, 3, 64, seed=5 * H + W)
+    x = x * 60.0
+    _, w2, b2 = _case(1, 4, 4, 64, 64, seed=H + 9 * W)
+    wp2 = ops.pack_conv3x3(w2.to(dev), "f16mx")
+    y = ops.vgg16_stem_mx(x.to(dev), w1.to(dev), b1.to(dev), wp2, b2.to(dev))
+    assert tuple(y.shape) == (N, H // 2, W // 2, 64) and y.dtype == torch.int32
+    h1 = F.relu(F.conv2d(x.double(), w1.double(), b1.double(), padding=1))
+    want = F.max_pool2d(F.relu(F.conv2d(h1, w2.double(), b2.double(), padding=1)), 2, 2)
+    if not want.numel():
+        return
+    assert_rel_l2("fused f16mx stem vs host", _mx_out(y), want, 6e-5)
+    hi = ops.mx_join(y, 1)
+    again = ops.mx_split(hi)
+    assert torch.equal(ops.mx_join(again, 1), hi)
+    assert torch.equal(ops.mx_join(again, 2), ops.mx_join(y, 2))
+    gmax = hi.abs().reshape(-1, 32).amax(-1, keepdim=True)
+    lo6 = ops.mx_join(y, 3).reshape(-1, 32)
+    assert (lo6.abs() <= gmax * 2.0 ** -11 * 1.07 + 1e-30).all()
+    # the value a line carries is within ~2^-15 of its group's largest element of the true one
+    err = (_mx_out(y).double() - want).abs().reshape(N, 2, 32, -1).amax(2)
+    ref = want.abs().reshape(N, 2, 32, -1).amax(2)
+    assert (err <= 3e-4 * ref + 1e-6).all(), float((err / (ref + 1e-9)).max())
 
 
 # ---- matching -------------------------------------------------------------------------------------
