@@ -32,7 +32,8 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
                 `frac` stays the algorithmic figure.
   fast_mode     the same step in plain bf16 with its own roofline.
   api           images/s THROUGH `ibl.evaluators.extract_features` on an in-memory loader of pinned
-                host batches (PCIe copy, per-batch launch work, gather and the fname dict included).
+                host batches (PCIe copy, per-batch launch work, gather and the fname dict included; a
+                3-batch warm-up call comes first, whose captured graphs the timed call replays).
   cpu_baseline  the CPU oracle (a port of the reference's path onto plain torch-CPU ops) timed on
                 this box's host cores on a bounded sample of the same workload (rank 0, N=1 only);
                 `matching.cpu_baseline` is the same for pairwise_distance + evaluate_all.

@@ -334,3 +334,56 @@ def test_replayed_extraction_equals_batch_by_batch(group, state_dict, dev, preci
             assert torch.equal(m8, want8)
         else:
             want8 = m8
+
+
+def test_captured_forwards_survive_between_extractions_and_die_with_their_state(group, state_dict, dev):
+    """The graphs an extraction captured are kept on the model for the next one (same shapes: no eager batch,
+    no capture), serve its FIRST batch too, and are dropped the moment anything they were captured for
+    changes: a parameter written in place, the precision, the head's options."""
+    import hubconf
+    from openibl_amd import evaluators as ev
+    from openibl_amd.extract import unwrap_model
+    model = hubconf.vgg16_netvlad(pretrained=False)
+    model.load_state_dict(state_dict)
+    model = model.to(dev).eval().set_precision("bf16x3")
+    core = unwrap_model(model)
+
+    class Loader:
+        def __init__(self, batches):
+            self.batches = batches
+            self.sampler = range(sum(int(b[0].shape[0]) for b in batches))
+
+        def __iter__(self):
+            return iter(self.batches)
+
+        def __len__(self):
+            return len(self.batches)
+
+    def run(seed, **kw):
+        batches = [(synth.images(3, 64, 96, seed=seed + k), [f"s{seed}_{k}_{i}" for i in range(3)]) for k in range(4)]
+        names = [(f, 0, 0.0, 0.0) for b in batches for f in b[1]]
+        feats = ev.extract_features(model, Loader(batches), names, gpu=dev.index, **kw)
+        eager = torch.cat([ev.extract_cnn_feature(model, b[0], gpu=dev.index).cpu() for b in batches])
+        if kw.get("store_dtype") is not None:
+            eager = eager.to(kw["store_dtype"])
+        assert torch.equal(torch.stack(list(feats.values())), eager)
+
+    run(700)
+    store = core.__dict__["_oibl_graph_store"]
+    assert len(store[1]) == 1
+    fwd = next(iter(store[1].values()))
+    calls = fwd.calls
+    run(800)                                            # other images, same shape: all four batches replayed
+    assert core.__dict__["_oibl_graph_store"] is store and next(iter(store[1].values())) is fwd
+    assert fwd.calls == calls + 4
+    run(900, store_dtype=torch.float16)                 # another head: another store
+    assert core.__dict__["_oibl_graph_store"] is not store
+    store = core.__dict__["_oibl_graph_store"]
+    with torch.no_grad():
+        core.net_vlad.centroids.mul_(1.0)               # written in place: the version counter moves
+    run(1000, store_dtype=torch.float16)
+    assert core.__dict__["_oibl_graph_store"] is not store
+    store = core.__dict__["_oibl_graph_store"]
+    model.set_precision("fp32")
+    run(1100, store_dtype=torch.float16)
+    assert core.__dict__["_oibl_graph_store"] is not store
