@@ -104,10 +104,14 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void netvlad_assign_kernel(
 
 // vlad_raw[n][k][c0..c0+63] for one image n and one 64-channel slice; K = 64 clusters.
 // 4 waves as 2 (clusters) x 2 (channels), one 32x32 fp32 accumulator tile each.
+// gridDim.z > 1 (few images: N x C / 64 workgroups walking all P pixels one chunk after the other is a
+// latency chain on 8 CUs): workgroup z takes the pixels [z pchunk, (z + 1) pchunk) and writes its partial
+// sum — the expression is linear in the pixels — to slab z of `vlad_raw` (slab stride N K C);
+// netvlad_rowstats_kernel adds the slabs in fixed order.
 template <typename T>
 __global__ __launch_bounds__(256) void netvlad_aggregate_kernel(
     const T* __restrict__ feat, const float* __restrict__ inv, const float* __restrict__ a,
-    const float* __restrict__ centroids, float* __restrict__ vlad_raw, int P, int C) {
+    const float* __restrict__ centroids, float* __restrict__ vlad_raw, int P, int C, int pchunk) {
   __shared__ __attribute__((aligned(16))) float a_s[32][64];
   __shared__ __attribute__((aligned(16))) float x_s[32][64];
   __shared__ float s_sum[64];
@@ -115,9 +119,12 @@ __global__ __launch_bounds__(256) void netvlad_aggregate_kernel(
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const T* fbase = feat + (size_t)n * P * C + c0;
-  const float* abase = a + (size_t)n * P * 64;
-  const float* ibase = inv + (size_t)n * P;
+  const int pz = blockIdx.z * pchunk;                       // first pixel of this workgroup
+  const T* fbase = feat + ((size_t)n * P + pz) * C + c0;
+  const float* abase = a + ((size_t)n * P + pz) * 64;
+  const float* ibase = inv + (size_t)n * P + pz;
+  vlad_raw += (size_t)blockIdx.z * gridDim.x * 64 * C;
+  P = P - pz < pchunk ? P - pz : pchunk;                   // pixels of this workgroup (<= 0: a zero slab)
 
   f32x16_t acc;
 #pragma unroll
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(256) void netvlad_aggregate_kernel(
       if constexpr (sizeof(T) == 4) px1 = *reinterpret_cast<const uint4*>(src + 4);
     }
   };
-  prefetch(0);
+  if (P > 0) prefetch(0);
   for (int p0 = 0; p0 < P; p0 += 32) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -204,14 +211,24 @@ __global__ __launch_bounds__(256) void netvlad_aggregate_kernel(
 // Two launches with one wave per (image, cluster) row — N*K/4 workgroups instead of N:
 //   rowstats: iv = 1 / max(|r|, eps) and s2 = |r * iv|^2 of every row;
 //   apply   : ginv = 1 / max(sqrt(sum_k s2[n][k]), eps) (fixed-order wave reduction), out = r * iv * ginv.
-__global__ __launch_bounds__(256) void netvlad_rowstats_kernel(const float* __restrict__ raw,
+// slabs > 1: `parts` holds that many partial sums of the raw rows (netvlad_aggregate_kernel with
+// gridDim.z > 1); this kernel adds them in slab order, writes the row to `raw` and goes on with it.
+__global__ __launch_bounds__(256) void netvlad_rowstats_kernel(float* __restrict__ raw,
+                                                               const float* __restrict__ parts, int slabs,
                                                                float* __restrict__ stats, long rows,
                                                                int C) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const float* r = raw + row * C;
+  float* r = raw + row * C;
   float s = 0.f;
+  if (slabs > 1) {
+    for (int i = lane; i < C; i += 64) {
+      float v = parts[row * C + i];
+      for (int z = 1; z < slabs; ++z) v += parts[((size_t)z * rows + row) * C + i];
+      r[i] = v;   // read back below by this same thread
+    }
+  }
   for (int i = lane; i < C; i += 64) s = fmaf(r[i], r[i], s);
   s = wave_sum(s);
   const float iv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
@@ -253,6 +270,8 @@ __global__ __launch_bounds__(256) void netvlad_apply_kernel(const float* __restr
 
 using namespace oibl;
 
+OIBL_HOOK(int, g_nv_slabs, 1);   // test hook: 0 = never split the aggregation over the pixels
+
 extern "C" {
 
 static size_t nv_off_a(int N, int P) { return align_up((size_t)N * P * sizeof(float), 256); }
@@ -267,9 +286,17 @@ static size_t nv_off_stats(int N, int P, int K, int C) {
   return nv_off_w(N, P, K, C) + align_up((size_t)K * C * sizeof(uint16_t), 256);
 }
 
+// pixel split of the aggregation for few images (the same for every N it applies to: a row's result must
+// not depend on its batch mates within a kernel selection)
+static int nv_pixel_slabs(int N, int P) { return (N <= 4 && P >= 256) ? 4 : 1; }
+static size_t nv_off_parts(int N, int P, int K, int C) {
+  return nv_off_stats(N, P, K, C) + align_up((size_t)N * K * 2 * sizeof(float), 256);
+}
+
 size_t oibl_netvlad_workspace_bytes(int N, int P, int K, int C) {
   if (N <= 0 || P <= 0 || K <= 0 || C <= 0) return 0;
-  return nv_off_stats(N, P, K, C) + align_up((size_t)N * K * 2 * sizeof(float), 256);
+  const int slabs = nv_pixel_slabs(N, P);
+  return nv_off_parts(N, P, K, C) + (slabs > 1 ? align_up((size_t)slabs * N * K * C * sizeof(float), 256) : 0);
 }
 
 int oibl_netvlad_forward(const void* feat, int N, int P, int K, int C, int precision,
@@ -297,6 +324,11 @@ int oibl_netvlad_forward(const void* feat, int N, int P, int K, int C, int preci
   float* raw = vlad_raw ? vlad_raw : (float*)(wsb + nv_off_raw(N, P));
   void* w_t = wsb + nv_off_w(N, P, K, C);
   const long rows = (long)N * P;
+  // few images: the aggregation is split over the pixels (only when the normalised output is wanted: the
+  // kernel that normalises is the one that adds the slabs)
+  const int slabs = (vlad_norm && g_nv_slabs) ? nv_pixel_slabs(N, P) : 1;
+  float* agg_out = slabs > 1 ? (float*)(wsb + nv_off_parts(N, P, K, C)) : raw;
+  const int pchunk = slabs > 1 ? (((P + slabs - 1) / slabs + 31) / 32) * 32 : P;
 
   const unsigned inv_grid = (unsigned)((rows + 3) / 4);
   const unsigned asg_grid = (unsigned)((rows + 127) / 128);
@@ -314,8 +346,8 @@ int oibl_netvlad_forward(const void* feat, int N, int P, int K, int C, int preci
       hipLaunchKernelGGL((netvlad_assign_kernel<Cfg, true>), dim3(asg_grid), dim3(256),
                          Cfg::MAIN_LDS_BYTES, st, feat, (const void*)w_t, inv, a, rows, C);
     OIBL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(netvlad_aggregate_kernel<bf16_t>, dim3(N, C / 64), dim3(256), 0, st,
-                       (const bf16_t*)feat, inv, a, centroids, raw, P, C);
+    hipLaunchKernelGGL(netvlad_aggregate_kernel<bf16_t>, dim3(N, C / 64, slabs), dim3(256), 0, st,
+                       (const bf16_t*)feat, inv, a, centroids, agg_out, P, C, pchunk);
     OIBL_LAUNCH_CHECK();
   } else {
     OIBL_REQUIRE((uintptr_t)assign_w % 16 == 0, "netvlad: assign_w must be 16-byte aligned");
@@ -330,15 +362,16 @@ int oibl_netvlad_forward(const void* feat, int N, int P, int K, int C, int preci
       hipLaunchKernelGGL((netvlad_assign_kernel<Cfg, true>), dim3(asg_grid), dim3(256),
                          Cfg::MAIN_LDS_BYTES, st, feat, (const void*)assign_w, inv, a, rows, C);
     OIBL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(netvlad_aggregate_kernel<float>, dim3(N, C / 64), dim3(256), 0, st,
-                       (const float*)feat, inv, a, centroids, raw, P, C);
+    hipLaunchKernelGGL(netvlad_aggregate_kernel<float>, dim3(N, C / 64, slabs), dim3(256), 0, st,
+                       (const float*)feat, inv, a, centroids, agg_out, P, C, pchunk);
     OIBL_LAUNCH_CHECK();
   }
   if (vlad_norm) {
     float* stats = (float*)(wsb + nv_off_stats(N, P, K, C));
     const long vrows = (long)N * K;
     const unsigned fgrid = (unsigned)((vrows + 3) / 4);
-    hipLaunchKernelGGL(netvlad_rowstats_kernel, dim3(fgrid), dim3(256), 0, st, raw, stats, vrows, C);
+    hipLaunchKernelGGL(netvlad_rowstats_kernel, dim3(fgrid), dim3(256), 0, st, raw, (const float*)agg_out, slabs,
+                       stats, vrows, C);
     OIBL_LAUNCH_CHECK();
     hipLaunchKernelGGL(netvlad_apply_kernel, dim3(fgrid), dim3(256), 0, st, raw, stats, vlad_norm,
                        vrows, K, C);
@@ -346,5 +379,12 @@ int oibl_netvlad_forward(const void* feat, int N, int P, int K, int C, int preci
   }
   return OIBL_OK;
 }
+
+#ifdef OIBL_DEBUG_HOOKS
+int oibl_debug_set_netvlad_slabs(int on) {
+  g_nv_slabs = on ? 1 : 0;
+  return OIBL_OK;
+}
+#endif
 
 }  // extern "C"

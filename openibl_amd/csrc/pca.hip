@@ -94,6 +94,64 @@ __global__ __launch_bounds__(256) void pca_scale_kernel(float* __restrict__ out,
   if (j < d) out[(size_t)n * d + j] *= inv;
 }
 
+// Few rows (N <= 8, fp32): a streaming kernel instead of the MFMA tile — with a handful of images the
+// contraction is a matrix-VECTOR product, 2 flop per 4 bytes of W, and the only thing that matters is
+// how many bytes of W a CU keeps in flight.  A wave owns PS_ROWS output dims over one K range of W:
+// every lane streams 16-byte pieces of those rows (non-temporal: W is read once) against the matching
+// piece of the N input rows (L2-resident), 16 + 2 N loads in flight per lane; per-lane fp32 sums in a
+// fixed order, one wave reduction at the end, partials [split][n][j] for pca_reduce_kernel.
+// 537 MB of fp32 W: 125 us through the MFMA tile (4.3 TB/s), 86 us here (6.2 TB/s) for N = 1, 2.  From
+// N = 4 on the input pieces — the same addresses from every workgroup of a split — cost more than the
+// tile's LDS staging (tests/gpu_pca_bench.py: 140 us at N = 4): the tile keeps N > 2.
+constexpr int PS_ROWS = 8, PS_SPLITS = 8, PS_MAXN = 2;
+template <int NB>
+__global__ __launch_bounds__(256) void pca_small_kernel(const float* __restrict__ v, const float* __restrict__ w,
+                                                        float* __restrict__ part, int N, int D, int d, int kper) {
+  typedef __attribute__((ext_vector_type(4))) float f4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j0 = (blockIdx.x * 4 + wave) * PS_ROWS;
+  const long k0 = (long)blockIdx.y * kper;
+  const float* wp = w + (long)j0 * D + k0 + lane * 4;
+  const float* vp = v + k0 + lane * 4;
+  float acc[PS_ROWS][NB];
+#pragma unroll
+  for (int r = 0; r < PS_ROWS; ++r)
+#pragma unroll
+    for (int n = 0; n < NB; ++n) acc[r][n] = 0.f;
+  for (int k = 0; k < kper; k += 512) {
+    f4 xv[2][NB], wv[2][PS_ROWS];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int r = 0; r < PS_ROWS; ++r)
+        wv[u][r] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(wp + (long)r * D + k + u * 256));
+#pragma unroll
+      for (int n = 0; n < NB; ++n)
+        xv[u][n] = n < N ? *reinterpret_cast<const f4*>(vp + (long)n * D + k + u * 256) : (f4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < PS_ROWS; ++r)
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[r][n] = fmaf(wv[u][r][e], xv[u][n][e], acc[r][n]);
+  }
+#pragma unroll
+  for (int r = 0; r < PS_ROWS; ++r)
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      const float t = wave_sum(acc[r][n]);
+      if (lane == 0 && n < N) part[((size_t)blockIdx.y * N + n) * d + j0 + r] = t;
+    }
+}
+
+OIBL_HOOK(int, g_pca_small, 1);   // test hook: 0 = the MFMA tile for every N
+static bool pca_small_ok(int N, int D, int d, int precision) {
+  return precision == OIBL_F32 && N <= PS_MAXN && d % (4 * PS_ROWS) == 0 && D % (PS_SPLITS * 512) == 0;
+}
+
 static int pca_splits(int N, int D, int d, int precision) {
   const int bk = precision == OIBL_BF16 ? 64 : 32;
   const int ksteps = D / bk;
@@ -112,7 +170,8 @@ extern "C" {
 
 size_t oibl_pca_workspace_bytes(int N, int D, int d, int precision) {
   if (N <= 0 || D <= 0 || d <= 0) return 0;
-  const int s = pca_splits(N, D, d, precision);
+  int s = pca_splits(N, D, d, precision);
+  if (pca_small_ok(N, D, d, precision) && s < PS_SPLITS) s = PS_SPLITS;
   return align_up((size_t)N * D * oibl_elem_size(precision), 256) +
          align_up((size_t)s * N * d * sizeof(float), 256) +
          align_up((size_t)N * ((d + 255) / 256) * sizeof(float), 256);
@@ -153,7 +212,15 @@ int oibl_pca_forward(const float* v, int N, int D, const void* w, const float* b
   p.splits = pca_splits(N, D, d, precision);
   p.ksteps_per_split = D / bk / p.splits;
   const unsigned grid = (unsigned)(((N + 31) / 32) * p.tiles_n * p.splits);
-  if (precision == OIBL_BF16) {
+  if (pca_small_ok(N, D, d, precision) && g_pca_small && !g_regstage) {
+    p.splits = PS_SPLITS;
+    const dim3 sg((unsigned)(d / (4 * PS_ROWS)), PS_SPLITS);
+    const int kper = D / PS_SPLITS;
+    const float* vf = (const float*)v_t;
+    const float* wf = (const float*)w;
+    if (N == 1) hipLaunchKernelGGL(pca_small_kernel<1>, sg, dim3(256), 0, st, vf, wf, p.part, N, D, d, kper);
+    else hipLaunchKernelGGL(pca_small_kernel<2>, sg, dim3(256), 0, st, vf, wf, p.part, N, D, d, kper);
+  } else if (precision == OIBL_BF16) {
     using Cfg = GemmCfg<bf16_t, 1, 4, 1, 1>;
     if (g_regstage)
       hipLaunchKernelGGL((pca_partial_kernel<Cfg, false>), dim3(grid), dim3(Cfg::NTHREADS),
@@ -182,5 +249,12 @@ int oibl_pca_forward(const float* v, int N, int D, const void* w, const float* b
   }
   return OIBL_OK;
 }
+
+#ifdef OIBL_DEBUG_HOOKS
+int oibl_debug_set_pca_small(int on) {
+  g_pca_small = on ? 1 : 0;
+  return OIBL_OK;
+}
+#endif
 
 }  // extern "C"

@@ -114,6 +114,8 @@ _HOOKS = {"oibl_debug_set_regstage": (c_int, [c_int]),
           "oibl_debug_set_stem3_prio": (c_int, [c_int]),
           "oibl_debug_set_match_group": (c_int, [c_int]),
           "oibl_debug_set_match_splitk": (c_int, [c_int]),
+          "oibl_debug_set_pca_small": (c_int, [c_int]),
+          "oibl_debug_set_netvlad_slabs": (c_int, [c_int]),
           "oibl_debug_set_prof_buffer": (c_int, [c_void_p])}
 
 ABI_VERSION = 2
@@ -138,6 +140,7 @@ _HOOK_DEFAULTS = {"oibl_debug_set_regstage": 0, "oibl_debug_set_conv11_valu": 0,
                   "oibl_debug_set_match_ring": 1, "oibl_debug_set_ring_ablate": 0, "oibl_debug_set_ring_raster": 0,
                   "oibl_debug_set_conv_korder": -1, "oibl_debug_set_mx_variant": 0, "oibl_debug_set_conv_splitk": 1,
                   "oibl_debug_set_stem3_prio": 0, "oibl_debug_set_match_group": 4, "oibl_debug_set_match_splitk": 1,
+                  "oibl_debug_set_pca_small": 1, "oibl_debug_set_netvlad_slabs": 1,
                   "oibl_debug_set_prof_buffer": None}
 
 

@@ -66,3 +66,53 @@ def test_pca_full_size(dev, N, precision):
     raw = ops.pca(v.to(dev), ops.cast(w.to(dev), precision), b.to(dev), l2norm=False)
     assert_rel_l2("pca without normalize", torch.nn.functional.normalize(raw.cpu().double(), dim=1),
                   want, 5e-6)
+
+
+def test_pca_few_rows_streaming_kernel(dev):
+    """N <= 2 in fp32 runs the streaming (matrix-vector) kernel: within the tolerance of the MFMA tile it
+    replaces (hook off); a row's result does not depend on whether a second row travels with it."""
+    from openibl_amd import lib
+    sd = synth.pca_state(0)
+    w = sd["pca_layer.weight"].reshape(4096, 32768).to(dev)
+    b = sd["pca_layer.bias"].to(dev)
+    g = torch.Generator().manual_seed(77)
+    v = torch.nn.functional.normalize(torch.randn((8, 32768), generator=g), dim=1).to(dev)
+    want = od.pca_project(v.cpu().double(), w.cpu().double(), b.cpu().double())
+    outs = {n: ops.pca(v[:n].contiguous(), w, b) for n in (1, 2, 3, 8)}
+    for n, o in outs.items():
+        assert_rel_l2(f"pca N={n}", o.cpu(), want[:n], 5e-6)
+    assert torch.equal(outs[1], outs[2][:1]), "row 0 of N=2 differs from N=1"
+    lib.debug_hooks().oibl_debug_set_pca_small(0)
+    try:
+        tile = ops.pca(v[:2].contiguous(), w, b)
+    finally:
+        lib.debug_hooks().oibl_debug_set_pca_small(1)
+    assert not torch.equal(outs[2], tile)          # (the hook did select the other kernel)
+    assert_rel_l2("streaming kernel vs MFMA tile", outs[2].cpu(), tile.cpu(), 2e-6)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_netvlad_pixel_slabs_for_few_images(dev, precision):
+    """Up to four images: the aggregation is split over the pixels (4 slabs, added in fixed order by the
+    normalising kernel).  Same numbers as the unsplit kernel up to the summation order, raw output included;
+    an image's result does not depend on its batch mates; five images run unsplit."""
+    from openibl_amd import lib
+    sd = synth.netvlad_state(0)
+    cw, cent = sd["net_vlad.conv.weight"].reshape(64, 512).contiguous().to(dev), sd["net_vlad.centroids"].to(dev)
+    feat = ops.nchw_f32_to_nhwc(_feat(5, 30, 37, seed=11).to(dev), precision)      # P = 1110: a ragged last slab
+    outs = {n: ops.netvlad(feat[:n].contiguous(), cw, cent, True, want_raw=True, want_norm=True) for n in (1, 2, 4, 5)}
+    lib.debug_hooks().oibl_debug_set_netvlad_slabs(0)
+    try:
+        whole = {n: ops.netvlad(feat[:n].contiguous(), cw, cent, True, want_raw=True, want_norm=True) for n in (4, 5)}
+    finally:
+        lib.debug_hooks().oibl_debug_set_netvlad_slabs(1)
+    assert_rel_l2("slabs vs whole, raw", outs[4][0].cpu(), whole[4][0].cpu(), 2e-6)
+    assert_rel_l2("slabs vs whole, normalised", outs[4][1].cpu(), whole[4][1].cpu(), 2e-6)
+    assert not torch.equal(outs[4][0], whole[4][0])
+    assert torch.equal(outs[5][0], whole[5][0]) and torch.equal(outs[5][1], whole[5][1])
+    for n in (1, 2):
+        assert torch.equal(outs[n][0], outs[4][0][:n]) and torch.equal(outs[n][1], outs[4][1][:n])
+    only_norm = ops.netvlad(feat[:2].contiguous(), cw, cent, True, want_raw=False, want_norm=True)[1]
+    assert torch.equal(only_norm, outs[2][1])
+    only_raw = ops.netvlad(feat[:2].contiguous(), cw, cent, True, want_raw=True, want_norm=False)[0]
+    assert_rel_l2("raw only (unsplit)", only_raw.cpu(), outs[2][0].cpu(), 2e-6)
