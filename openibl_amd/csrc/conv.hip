@@ -904,7 +904,11 @@ static int launch_conv_halo(const ConvParams& p, hipStream_t st) {
 OIBL_HOOK(int, g_mx_variant, 0);
 static int launch_conv_mx(const ConvParams& p, int pool, hipStream_t st) {
   const int rv = (pool && p.out_f32) ? 0 : ring_variant(p, 4);
-  if (g_mx_variant == 3 && rv == 2 && ((p.cin >> 5) & 1) == 0)
+  // the halo kernel (conv_halo.h) where it is the faster one: the 256-output-channel layers at 120 x 160
+  // (conv3_1..conv3_3: 0.57 / 1.00 / 0.95 ms against 0.60 / 1.04 / 0.97 on the ring; deeper layers lose 5-10 %).
+  // Hook: 1 = ring kernels only, 3 = halo kernel wherever it applies.
+  const bool halo_ok = rv == 2 && ((p.cin >> 5) & 1) == 0;
+  if (halo_ok && (g_mx_variant == 3 || (g_mx_variant == 0 && p.cout == 256)))
     return pool ? launch_conv_halo<true>(p, st) : launch_conv_halo<false>(p, st);
   if (g_mx_variant == 2) {
     if (rv == 2) return pool ? launch_conv_ring<2, true, RING_MX>(p, st) : launch_conv_ring<2, false, RING_MX>(p, st);

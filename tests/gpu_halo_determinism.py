@@ -19,7 +19,7 @@ for (N, H, W, cin, cout, pool) in [(32, 120, 160, 256, 256, 1), (32, 60, 80, 512
     b = torch.randn((cout,), generator=g, device=dev) * 0.1
     x = ops.mx_split(xf)
     wp = ops.pack_conv3x3(w, "f16mx")
-    L.oibl_debug_set_mx_variant(0)
+    L.oibl_debug_set_mx_variant(1)
     ring = ops.conv3x3_nhwc(x, wp, b, True, bool(pool), "f16mx")
     L.oibl_debug_set_mx_variant(VARIANT)
     ref = ops.conv3x3_nhwc(x, wp, b, True, bool(pool), "f16mx")

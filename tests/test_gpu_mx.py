@@ -62,10 +62,11 @@ def _mx_out(y, which=0):
     return ops.nhwc_to_nchw_f32(ops.mx_join(y, which)).cpu()
 
 
-@pytest.fixture(params=[0, 3, 2], ids=["ring", "halo", "ring-late"])
+@pytest.fixture(params=[0, 1, 3, 2], ids=["auto", "ring", "halo", "ring-late"])
 def mx_variant(request):
-    """0 = default dispatch (ring kernels), 3 = halo kernel for the 256-channel-tile layers, 2 = ring kernels
-    with the LDS-DMA issue inside the COMPUTE segments."""
+    """0 = default dispatch (halo kernel for the 256-output-channel layers, ring kernels elsewhere), 1 = ring
+    kernels only, 3 = halo kernel wherever it applies, 2 = ring kernels with the LDS-DMA issue inside the
+    COMPUTE segments."""
     from openibl_amd import lib
     lib.debug_hooks().oibl_debug_set_mx_variant(request.param)
     yield request.param
@@ -302,7 +303,7 @@ def test_conv_mx_repeatable_under_load(dev):
     x, wp = ops.mx_split(xf), ops.pack_conv3x3(w, "f16mx")
     big = torch.randn((4096, 4096), device=dev)
     side = torch.cuda.Stream()
-    for variant in (0, 3):
+    for variant in (1, 3):
         lib.debug_hooks().oibl_debug_set_mx_variant(variant)
         try:
             ref = ops.conv3x3_nhwc(x, wp, b, True, True, "f16mx")
