@@ -190,7 +190,8 @@ int oibl_vgg16_stem_x3(const float* x_nchw, int N, int H, int W, const float* w1
  * packed into f16mx lines inside LDS, conv1_2 runs in the f16mx arithmetic (2 fp16 + 1 scaled-fp6 MFMA per 32
  * channels) and the pooled map leaves as f16mx lines.  The e2m3 image of a lo part is rounded through fp16
  * here (the other f16mx producers convert it from fp32): its codes can differ by one step from
- * oibl_mx_split_rows of the same values.  Used automatically by oibl_vgg16_conv5_forward in OIBL_F16MX. */
+ * oibl_mx_split_rows of the same values.  H >= 2, W >= 3.  Used automatically by oibl_vgg16_conv5_forward
+ * in OIBL_F16MX. */
 int oibl_vgg16_stem_mx(const float* x_nchw, int N, int H, int W, const float* w1_oihw,
                        const float* b1, const void* packed_w2, const float* b2, void* out,
                        void* stream);

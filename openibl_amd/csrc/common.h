@@ -252,8 +252,9 @@ __device__ static inline void mx_pack_half(const float (&v)[16], unsigned (&h16)
   for (int e = 0; e < 16; e += 2) asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(v[e]), "v"(v[e + 1]));
   {  // the other half's maximum.  v_permlane32_swap exchanges the upper half of its first register with the
      // lower half of its second: with the maximum in both, every lane finds its partner's in one of them.
-     // (Inline asm: through __builtin_amdgcn_permlane32_swap(x, x) hipcc 7.2 drops the second result — the
-     //  lower lanes then see only their own value.  s_nop: the VALU-write -> permlane hazard is the
+     // (Inline asm keeps the instruction count exact; with __builtin_amdgcn_permlane32_swap mind that
+     //  __builtin_bit_cast(float, r[1]) of the returned vector reads element 0 — bit_cast of a vector-element
+     //  lvalue — which cost this function a GPU run.  s_nop: the VALU-write -> permlane hazard is the
      //  compiler's to handle for the builtin, ours here.)
     unsigned a = __builtin_bit_cast(unsigned, amax), b = a;
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));

@@ -1751,7 +1751,14 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
     for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int k = 16 * s + 8 * half + e;
+        // K slot (s, half, e) of the 32: bf16x3 — window element k = 16 s + 8 half + e (c, ky, kx order);
+        // f16mx — the window travels as ROWS (below): slot 8 s + e of a lane half is element kx = idx % 3 of
+        // its row idx / 3, the lower half owning rows (c, ky) = 0..4, the upper half rows 5..8
+        int k = 16 * s + 8 * half + e;
+        if (MX) {
+          const int idx = 8 * s + e;
+          k = idx < (half ? 12 : 15) ? (idx / 3 + (half ? 5 : 0)) * 3 + idx % 3 : 27;
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int ch = MX ? 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3) : l31;   // channel of row l31
@@ -1811,12 +1818,59 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
       return ty >= 1 && ty * 8 + 10 <= p.H && tx >= 1 && tx * 32 + 34 <= p.W;
     };
     float xv[1][16];
+    int xfix[1] = {0};   // f16mx, image edge: 1 = this pixel's rows were fetched from x (not x - 1), 2 = from x - 2
     auto issue_loads = [&](int tile) __attribute__((always_inline)) {
       int n, ty, tx;
       decode(tile, n, ty, tx);
       const int y0 = ty * 8 - 1, x0 = tx * 32 - 1;
       const int origin = ((n * 3) * p.H + y0) * p.W + x0;
-      if (is_interior(ty, tx)) {
+      if constexpr (MX) {
+        // The 3 x 3 x 3 window as nine ROWS (c, ky) of three consecutive pixels x - 1 .. x + 1: five 12-byte
+        // loads per lane (the lower lane half rows 0-4, the upper half rows 5-8 and row 8 once more under zero
+        // weights) instead of sixteen 4-byte ones — the sixteen were ~3k cycles of the texture path per tile.
+        // Image edges: a row above / below the image is fetched from the out-of-range offset (zeros);
+        // at x = 0 the fetch starts at x, at x = W - 1 at x - 2 (no byte outside the tensor is ever touched)
+        // and convert() moves the elements into place.
+        const bool interior = is_interior(ty, tx);
+        if (has_block) {
+          constexpr int bi = 0;
+          int hsel = half;
+          asm volatile("" : "+v"(hsel));
+          bool in = true, ya = true, yc = true;
+          int shift = -1;
+          xfix[bi] = 0;
+          if (!interior) {
+            int hy, hx;
+            hyx_of(bi, hy, hx);
+            const int y = y0 + hy, x = x0 + hx;
+            in = y >= 0 && y < p.H && x >= 0 && x < p.W;
+            ya = y > 0;
+            yc = y + 1 < p.H;
+            xfix[bi] = !in ? 0 : x == 0 ? 1 : x + 1 >= p.W ? 2 : 0;
+            shift = xfix[bi] == 1 ? 0 : xfix[bi] == 2 ? -2 : -1;
+          }
+          const int base = origin + g_rel[bi] + shift;
+#pragma unroll
+          for (int i = 0; i < 5; ++i) {
+            const int rA = i, rB = i + 5 < 9 ? i + 5 : 8;
+            const int oA = (rA / 3) * plane + (rA % 3 - 1) * p.W, oB = (rB / 3) * plane + (rB % 3 - 1) * p.W;
+            const int kyA = rA % 3, kyB = rB % 3;
+            unsigned off = (unsigned)(base + (hsel ? oB : oA)) * 4u;
+            if (!interior) {
+              const int ky = hsel ? kyB : kyA;
+              const bool ok = in && (ky == 0 ? ya : ky == 2 ? yc : true);
+              off = ok ? off : ST_OOB;
+            }
+            // (elements through scalars: __builtin_bit_cast applied to a vector-element lvalue reads element 0)
+            const auto d = __builtin_amdgcn_raw_buffer_load_b96(rs_x, (int)off, 0, 0);
+            const unsigned d0 = d[0], d1 = d[1], d2 = d[2];
+            xv[bi][3 * i] = __builtin_bit_cast(float, d0);
+            xv[bi][3 * i + 1] = __builtin_bit_cast(float, d1);
+            xv[bi][3 * i + 2] = __builtin_bit_cast(float, d2);
+          }
+          xv[bi][15] = 0.f;
+        }
+      } else if (is_interior(ty, tx)) {
 #pragma unroll
         for (int bi = 0; bi < 1; ++bi) {
           if (!has_block) continue;  // wave-uniform
@@ -1856,6 +1910,18 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
 #pragma unroll
       for (int bi = 0; bi < 1; ++bi) {
         if (!has_block) continue;
+        if constexpr (MX) {
+          if (__builtin_amdgcn_ballot_w64(xfix[bi] != 0) != 0) {   // an image edge inside this block (rare)
+            const bool left = xfix[bi] == 1, right = xfix[bi] == 2;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+              const float a = xv[bi][3 * i], b = xv[bi][3 * i + 1], c = xv[bi][3 * i + 2];
+              xv[bi][3 * i] = left ? 0.f : right ? b : a;
+              xv[bi][3 * i + 1] = left ? a : right ? c : b;
+              xv[bi][3 * i + 2] = left ? b : right ? 0.f : c;
+            }
+          }
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           u32x4_t hi4, lo4;
@@ -1872,6 +1938,30 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
       }
     };
     // conv1_1 of channel half h on the converted window, bias + ReLU + split, halo tile -> LDS
+    // f16mx: the packed half line of the lane's pixel, between produce() and flush()
+    unsigned ph16[8] = {}, ph6[3] = {}, pl6[3] = {}, pbh = 0, pbl = 0;
+    auto flush = [&](char* buf) __attribute__((always_inline)) {
+      typedef __attribute__((ext_vector_type(4))) unsigned u4;
+      typedef __attribute__((ext_vector_type(3))) unsigned u3;
+      constexpr int bi = 0;
+      if (!has_block || row_of(bi) >= ST_HALO_PX) return;
+      // this lane's 16 consecutive elements of the pixel's line: fp16 parts = 16-B slots 2 half, 2 half + 1;
+      // e2m3 images = dwords 3 half .. 3 half + 2 of the 6-dword strings, which the line keeps as
+      // slot 4 / 5 (hi / lo: dwords 0-3) and slot 6 / 7 (dwords 4, 5, zero, scale byte)
+      char* row = buf + row_of(bi) * 128;
+      const int sw = g_swz[bi];
+      *reinterpret_cast<u4*>(row + (((2 * half) ^ sw) << 4)) = (u4){ph16[0], ph16[1], ph16[2], ph16[3]};
+      *reinterpret_cast<u4*>(row + (((2 * half + 1) ^ sw) << 4)) = (u4){ph16[4], ph16[5], ph16[6], ph16[7]};
+      if (half == 0) {
+        *reinterpret_cast<u3*>(row + ((4 ^ sw) << 4)) = (u3){ph6[0], ph6[1], ph6[2]};
+        *reinterpret_cast<u3*>(row + ((5 ^ sw) << 4)) = (u3){pl6[0], pl6[1], pl6[2]};
+      } else {
+        *reinterpret_cast<unsigned*>(row + ((4 ^ sw) << 4) + 12) = ph6[0];
+        *reinterpret_cast<unsigned*>(row + ((5 ^ sw) << 4) + 12) = pl6[0];
+        *reinterpret_cast<u4*>(row + ((6 ^ sw) << 4)) = (u4){ph6[1], ph6[2], 0u, pbh};
+        *reinterpret_cast<u4*>(row + ((7 ^ sw) << 4)) = (u4){pl6[1], pl6[2], 0u, pbl};
+      }
+    };
     auto produce = [&](int tile, auto h_c, char* buf) __attribute__((always_inline)) {
       constexpr int h = decltype(h_c)::value;
       int n, ty, tx;
@@ -1910,33 +2000,13 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
           pix_ok = y >= 0 && y < p.H && x >= 0 && x < p.W;
         }
         if constexpr (MX) {
-          // this lane's 16 consecutive elements of the pixel's line: fp16 parts = 16-B slots 2 half, 2 half + 1;
-          // e2m3 images = dwords 3 half .. 3 half + 2 of the 6-dword strings, which the line keeps as
-          // slot 4 / 5 (hi / lo: dwords 0-3) and slot 6 / 7 (dwords 4, 5, zero, scale byte)
-          typedef __attribute__((ext_vector_type(4))) unsigned u4;
-          typedef __attribute__((ext_vector_type(3))) unsigned u3;
           // ReLU, the fp16 bound and conv1_2's zero padding (a halo pixel outside the image) in ONE v_med3
           float c[16];
           const float lim = pix_ok ? 65504.f : 0.f;
 #pragma unroll
           for (int j = 0; j < 16; ++j) c[j] = __builtin_amdgcn_fmed3f(acc[j], 0.f, lim);
-          unsigned h16[8], h6[3], l6[3], bh, bl;
-          mx_pack_half<false>(c, h16, h6, l6, bh, bl);
-          if (row_of(bi) < ST_HALO_PX) {
-            char* row = buf + row_of(bi) * 128;
-            const int sw = g_swz[bi];
-            *reinterpret_cast<u4*>(row + (((2 * half) ^ sw) << 4)) = (u4){h16[0], h16[1], h16[2], h16[3]};
-            *reinterpret_cast<u4*>(row + (((2 * half + 1) ^ sw) << 4)) = (u4){h16[4], h16[5], h16[6], h16[7]};
-            if (half == 0) {
-              *reinterpret_cast<u3*>(row + ((4 ^ sw) << 4)) = (u3){h6[0], h6[1], h6[2]};
-              *reinterpret_cast<u3*>(row + ((5 ^ sw) << 4)) = (u3){l6[0], l6[1], l6[2]};
-            } else {
-              *reinterpret_cast<unsigned*>(row + ((4 ^ sw) << 4) + 12) = h6[0];
-              *reinterpret_cast<unsigned*>(row + ((5 ^ sw) << 4) + 12) = l6[0];
-              *reinterpret_cast<u4*>(row + ((6 ^ sw) << 4)) = (u4){h6[1], h6[2], 0u, bh};
-              *reinterpret_cast<u4*>(row + ((7 ^ sw) << 4)) = (u4){l6[1], l6[2], 0u, bl};
-            }
-          }
+          mx_pack_half<false>(c, ph16, ph6, pl6, pbh, pbl);
+          flush(buf);
         } else if (row_of(bi) < ST_HALO_PX) {
           char* row = buf + row_of(bi) * 128 + 8 * half;
 #pragma unroll
@@ -1960,8 +2030,8 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
     using H0 = std::integral_constant<int, 0>;
     using H1 = std::integral_constant<int, 1>;
     const bool prof = p.prof != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && wave == 4;
-    unsigned long long pt[2] = {0, 0};
-    auto hand_over = [&](unsigned long long t0) __attribute__((always_inline)) {
+    unsigned long long pt[4] = {0, 0, 0, 0};   // work, wait; of which in the stage beside the consumers' pass 0
+    auto hand_over = [&](unsigned long long t0, int stage = 1) __attribute__((always_inline)) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       const unsigned long long t1 = prof ? __builtin_amdgcn_s_memtime() : 0;
       __builtin_amdgcn_s_barrier();
@@ -1969,6 +2039,10 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
         const unsigned long long t2 = __builtin_amdgcn_s_memtime();
         pt[0] += t1 - t0;
         pt[1] += t2 - t1;
+        if (stage == 0) {
+          pt[2] += t1 - t0;
+          pt[3] += t2 - t1;
+        }
       }
     };
     if (niter > 0) {
@@ -1989,8 +2063,10 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
         convert();
         if (it + 2 < niter) issue_loads(first + (it + 2) * stride);
       }
-      hand_over(t0);
-      // while they run pass 1: the first channel half of the next tile
+      hand_over(t0, 0);
+      // while they run pass 1: the first channel half of the next tile.  (Computing and packing it beside pass 0
+      // and only writing it here was measured: 1.66 instead of 1.54 ms — that stage already carries the
+      // consumers' epilogue and is bound by what the four waves of a SIMD can issue.)
       t0 = prof ? __builtin_amdgcn_s_memtime() : 0;
       if (it + 1 < niter) produce(first + (it + 1) * stride, H0{}, hb);
       hand_over(t0);
@@ -1998,6 +2074,8 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
     if (prof && lane == 0) {
       p.prof[4] = pt[0];
       p.prof[5] = pt[1];
+      p.prof[6] = pt[2];
+      p.prof[7] = pt[3];
     }
     return;
   }
@@ -2049,7 +2127,7 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     __builtin_amdgcn_s_barrier();
     const bool cprof = p.prof != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0;
-    unsigned long long ct[3] = {0, 0, 0};
+    unsigned long long ct[3] = {0, 0, 0}, ct0w = 0;
     f32x16_t acc[2];
     // operand registers, single-buffered: a fragment is reloaded for the next tap right behind the last
     // MFMA that reads it, and the MFMA order (w0.b0, w0.b1, w1.b0, w1.b1, wm.b0, wm.b1 — accumulators
@@ -2167,8 +2245,10 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
       const unsigned long long c1 = cprof ? __builtin_amdgcn_s_memtime() : 0;
       __builtin_amdgcn_s_barrier();
       if (cprof) {
+        const unsigned long long c2 = __builtin_amdgcn_s_memtime();
         ct[0] += c1 - c0;
-        ct[1] += __builtin_amdgcn_s_memtime() - c1;
+        ct[1] += c2 - c1;
+        if (h == 0) ct0w += c2 - c1;
       }
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) w_off[kk] += h == 0 ? 9 * 32 * 128 : -(9 * 32 * 128);
@@ -2203,17 +2283,24 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
       {
         // pooling: the window's x pair first (lane ^ 1), then the two blocks merge — even lanes keep block 0,
         // odd lanes block 1 — and the y pair (lane ^ 2) follows on the merged values: ONE line per lane pair
-        float v[16];
+        // (v_max_f32_dpp by hand: through fmaxf + mov_dpp every step is a v_mov_dpp, a v_max and two
+        //  canonicalising v_max x, x — 176 instructions instead of 48.  A DPP read needs two wait states behind
+        //  the VALU write of its source, which the compiler does not see inside asm: the first round reads
+        //  accumulators written long ago, the second carries its own s_nop.)
+        float v[16], m0[16], m1[16];
         const bool odd = l31 & 1;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-          float t0 = acc[0][j], t1 = acc[1][j];
-          t0 = fmaxf(t0, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, t0), 0xB1, 0xF, 0xF, true)));
-          t1 = fmaxf(t1, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, t1), 0xB1, 0xF, 0xF, true)));
-          float t = odd ? t1 : t0;
-          t = fmaxf(t, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, t), 0x4E, 0xF, 0xF, true)));
-          v[j] = __builtin_amdgcn_fmed3f(t + bv[j], 0.f, 65504.f);   // bias, ReLU, the fp16 bound
+          asm volatile("v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(m0[j]) : "v"(acc[0][j]));
+          asm volatile("v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(m1[j]) : "v"(acc[1][j]));
         }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = odd ? m1[j] : m0[j];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)   // (s_nop: the select above may be scheduled right in front of its reader)
+          asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(m0[j]) : "v"(v[j]));
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = __builtin_amdgcn_fmed3f(m0[j] + bv[j], 0.f, 65504.f);   // bias, ReLU, the fp16 bound
         unsigned h16[8], h6[3], l6[3], bh, bl;
         mx_pack_half<false>(v, h16, h6, l6, bh, bl);
         // lanes 0, 1 of a quad store: pooled pixel 8 (l31 & 1) + (l31 >> 2) of the tile row
@@ -2237,6 +2324,7 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
       p.prof[0] = ct[0];
       p.prof[1] = ct[1];
       p.prof[2] = ct[2];
+      p.prof[3] = ct0w;   // of the waits: behind pass 0
     }
     return;
   }
@@ -2643,7 +2731,7 @@ int oibl_vgg16_stem_x3(const float* x_nchw, int N, int H, int W, const float* w1
 int oibl_vgg16_stem_mx(const float* x_nchw, int N, int H, int W, const float* w1_oihw, const float* b1,
                        const void* packed_w2, const float* b2, void* out, void* stream) {
   OIBL_REQUIRE(x_nchw && w1_oihw && b1 && packed_w2 && b2 && out, "vgg16_stem_mx: null pointer");
-  OIBL_REQUIRE(N > 0 && H >= 2 && W >= 2, "vgg16_stem_mx: bad shape N=%d H=%d W=%d", N, H, W);
+  OIBL_REQUIRE(N > 0 && H >= 2 && W >= 3, "vgg16_stem_mx: bad shape N=%d H=%d W=%d (needs H >= 2, W >= 3)", N, H, W);
   OIBL_REQUIRE(stem_eligible(N, H, W), "vgg16_stem_mx: input of %d x 3 x %d x %d exceeds 3.5 GB", N, H, W);
   OIBL_REQUIRE((uintptr_t)packed_w2 % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)x_nchw % 4 == 0,
                "vgg16_stem_mx: packed weights / output must be 16-byte aligned");

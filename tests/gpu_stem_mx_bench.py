@@ -39,5 +39,7 @@ for name, fn, prec, mode in [("bf16x3", ops.vgg16_stem_x3, "bf16x3", 0)] + [("f1
     L.oibl_debug_set_prof_buffer(None)
     t = buf.cpu().tolist()
     print(f"{name} stem: {a.elapsed_time(b) / 10:.3f} ms | per tile: consumer passes {t[0] / tiles:7.0f} waits {t[1] / tiles:6.0f} "
-          f"epilogue {t[2] / tiles:6.0f} | producer work {t[4] / tiles:7.0f} waits {t[5] / tiles:6.0f}")
+          f"epilogue {t[2] / tiles:6.0f} | producer work {t[4] / tiles:7.0f} waits {t[5] / tiles:6.0f}"
+          + (f" || beside pass 0: consumers wait {t[3] / tiles:6.0f}, producers work {t[6] / tiles:6.0f} wait {t[7] / tiles:6.0f}"
+             if "f16mx" in name else ""))
 L.oibl_debug_set_stem3_prio(0)

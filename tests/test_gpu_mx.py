@@ -197,8 +197,8 @@ def test_mx_batch_rows_independent_and_graphed(model, dev):
     assert torch.equal(a, want) and torch.equal(b, want)
 
 
-@pytest.mark.parametrize("N,H,W", [(1, 8, 32), (2, 16, 64), (1, 21, 45), (3, 30, 70), (1, 2, 2),
-                                   (2, 9, 33), (1, 64, 96), (5, 40, 136)])
+@pytest.mark.parametrize("N,H,W", [(1, 8, 32), (2, 16, 64), (1, 21, 45), (3, 30, 70), (1, 2, 3), (2, 3, 4),
+                                   (2, 9, 33), (1, 64, 96), (5, 40, 136), (1, 17, 65)])
 def test_vgg_stem_mx_fused(dev, N, H, W):
     """f16mx: conv1_1 (split bf16) + conv1_2 (f16mx arithmetic on f16mx lines packed inside LDS) + pool in one
     launch, output = f16mx lines packed from registers.  Against the fp64 host convolutions (one f16mx
