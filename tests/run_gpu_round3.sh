@@ -37,7 +37,8 @@ if [ -z "$QUICK" ]; then
   timeout 300 python bench.py --sustain 12 --precision f16mx 2>> $OUT/bench_err.log > $OUT/sustain_f16mx.json
   timeout 300 python bench.py --sustain 12 --precision bf16 2>> $OUT/bench_err.log > $OUT/sustain_bf16.json
   timeout 120 python tests/gpu_mx_stamps.py 2>&1 | grep -v amdgpu.ids | tee $OUT/mx_stamps.log
-  timeout 120 python tests/gpu_stem_mx_bench.py 0 14 2>&1 | grep -v amdgpu.ids | tee $OUT/stem_mx.log
+  timeout 120 python tests/gpu_stem_mx_bench.py 0 2>&1 | grep -v amdgpu.ids | tee $OUT/stem_mx.log
+  timeout 120 python tests/gpu_pca_bench.py 2>&1 | grep -v amdgpu.ids | tee $OUT/pca_small.log
 fi
 cd /tmp && export TMPDIR=/tmp
 # --no-pipeline: one lane, so that the per-kernel durations are those of the roofline's span leg
