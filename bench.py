@@ -21,8 +21,8 @@ and reported under `fast_mode`, labelled as what it is; `--precision bf16x3` giv
 
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   roofline      the matrix-core convolution kernels (12 launches per step: the fused stem — conv1_1 +
-                conv1_2 + pool in one launch — and the 11 ring launches conv2_1..conv5_3, in bf16x3
-                and in bf16 alike): ALGORITHMIC FLOPs of those launches / their measured span, bracketed with
+                conv1_2 + pool in one launch — and the 11 launches conv2_1..conv5_3, in every matrix-core
+                mode alike): ALGORITHMIC FLOPs of those launches / their measured span, bracketed with
                 HIP events recorded on the launching stream, against the dense bf16 MFMA peak
                 (2.5 PFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md).  The headline steps run on two
                 lanes (two streams in flight, openibl_amd/extract.py) whose launches overlap; the span
@@ -188,7 +188,8 @@ def time_extraction(c, model, x, precision, steps, warmup, eager=False, pipeline
                   "bf16x3": "oibl::vgg_stem_x3_kernel (conv1_1+conv1_2+pool) + oibl::conv3x3_ring_kernel<..., RING_X3> "
                             "(conv2_1..conv5_3), 12 launches/step",
                   "f16mx": "oibl::vgg_stem_x3_kernel<MX> (conv1_1 in bf16x3 + conv1_2 in f16mx + pool) + "
-                           "oibl::conv3x3_ring_kernel<..., RING_MX> (conv2_1..conv5_3), 12 launches/step"}[precision]
+                           "oibl::conv3x3_ring_kernel<..., RING_MX> (conv2_x, conv4_x, conv5_x) + "
+                           "oibl::conv3x3_halo_kernel (conv3_x), 12 launches/step"}[precision]
     elif fwd is not None:
         # fp32: the replayed backbone graph holds conv1_1 too: 13 launches inside the span
         launches, fl = 13, (igemm_flops_per_image() + conv11_flops_per_image()) * batch
