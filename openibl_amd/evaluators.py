@@ -76,7 +76,8 @@ def extract_cnn_feature(model, inputs, vlad=True, gpu=None, scales=None):
 FAST_EXTRACTION = True   # False: batch-by-batch eager launches (the cross-check of the replayed path)
 
 
-def _extract_local(model, data_loader, vlad, pca, gpu, print_freq, rank, scales=None, store_dtype=None):
+def _extract_local(model, data_loader, vlad, pca, gpu, print_freq, rank, scales=None, store_dtype=None,
+                   use_graphs=True):
     """Run the loader of this rank; returns the [n_local][d] descriptor matrix ON DEVICE, in
     `store_dtype` (None = float32; float16 / bfloat16 = 16-bit descriptor storage).
 
@@ -90,7 +91,8 @@ def _extract_local(model, data_loader, vlad, pca, gpu, print_freq, rank, scales=
     from . import extract
     if FAST_EXTRACTION and scales is None and extract.fast_path_supported(model):
         return extract.extract_descriptors(model, data_loader, vlad=vlad, pca=pca, gpu=gpu,
-                                           print_freq=print_freq, rank=rank, store_dtype=store_dtype)
+                                           print_freq=print_freq, rank=rank, store_dtype=store_dtype,
+                                           use_graphs=use_graphs)
     batch_t, data_t = _Meter(), _Meter()
     chunks = []
     end = time.time()
@@ -139,13 +141,15 @@ def _gather_all(local: torch.Tensor, sync_gather: bool, rank: int, world: int) -
 
 
 def extract_features(model, data_loader, dataset, print_freq=10, vlad=True, pca=None, gpu=None,
-                     sync_gather=False, scales=None, store_dtype=None):
+                     sync_gather=False, scales=None, store_dtype=None, use_graphs=True):
     """OrderedDict fname -> CPU descriptor for every item of `dataset` (evaluators.py:36-103).
+    `use_graphs=False`: the two-lane route without hipGraph capture (loaders whose batch shapes rarely
+    repeat; `openibl_amd.extract.MAX_CACHED_SHAPES` bounds the captured shapes kept otherwise).
 
     Each rank extracts the slice its DistributedSliceSampler yields; slices are gathered
     rank-major and truncated to len(dataset) (the wrap-around padding of the last slices)."""
     rank, world = _rank_world()
-    local = _extract_local(model, data_loader, vlad, pca, gpu, print_freq, rank, scales, store_dtype)
+    local = _extract_local(model, data_loader, vlad, pca, gpu, print_freq, rank, scales, store_dtype, use_graphs)
     allf = _gather_all(local, sync_gather, rank, world)[: len(dataset)]
     features = OrderedDict()
     for item, row in zip(dataset, allf):

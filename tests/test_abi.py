@@ -187,11 +187,14 @@ def test_hot_kernels_stay_inside_their_register_budgets():
     seen = set()
     for name, u in usage.items():
         scratch, vgprs = u.get("ScratchSize", 0), u.get("VGPRs", 0) + u.get("AGPRs", 0)
-        if "conv3x3_ring_kernel" in name or "pairwise_ring_kernel" in name or "vgg_stem_kernel" in name:
+        if any(k in name for k in ("conv3x3_ring_kernel", "pairwise_ring_kernel", "vgg_stem_kernel",
+                                   "conv3x3_halo_kernel", "pca_small_kernel")):
             assert scratch == 0 and vgprs <= 256, (name, u)
             seen.add(re.sub(r"I.*", "", name))
         elif "vgg_stem_x3_kernel" in name:
-            assert u["VGPRs"] <= 128 and u.get("AGPRs", 0) == 0 and scratch <= 16, (name, u)
+            # <true> = the f16mx stem: no scratch at all; <false> = bf16x3: two values parked outside its loops
+            assert u["VGPRs"] <= 128 and u.get("AGPRs", 0) == 0, (name, u)
+            assert scratch == 0 if "ILb1E" in name else scratch <= 16, (name, u)
             seen.add("x3stem")
         elif "conv3x3_igemm_kernel" in name:
             glds = re.search(r"ELb([01])ELb([01])ELb([01])EEE", name).group(2)

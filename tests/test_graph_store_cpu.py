@@ -1,0 +1,37 @@
+"""The key under which extract_descriptors keeps captured forwards on a model (openibl_amd/extract.py,
+_graph_store): same state -> same store; a parameter written in place, a precision switch, another PCA object
+or head option -> a fresh one.  (CPU: only the bookkeeping, no capture.)"""
+import torch
+
+import hubconf
+from openibl_amd.extract import _graph_store, unwrap_model
+
+
+def test_store_follows_the_state_it_was_captured_in():
+    model = hubconf.vgg16_netvlad(pretrained=False).eval()
+    core = unwrap_model(model)
+    dev = torch.device("cuda", 0)            # only part of the key here
+    a = _graph_store(core, None, True, None, dev)
+    a["marker"] = 1
+    assert _graph_store(core, None, True, None, dev) is a
+    assert _graph_store(core, None, True, torch.float16, dev) is not a      # head option
+    b = _graph_store(core, None, True, None, dev)
+    assert b is not a and "marker" not in b                                  # the old store is gone for good
+    with torch.no_grad():
+        core.net_vlad.centroids.add_(0.0)                                    # in place: version counter
+    c = _graph_store(core, None, True, None, dev)
+    assert c is not b
+    model.set_precision("bf16x3")
+    d = _graph_store(core, None, True, None, dev)
+    assert d is not c
+    core.base_model.F16MX_MIN_TILES = 0
+    assert _graph_store(core, None, True, None, dev) is not d
+
+    class FakePCA:
+        precision = "fp32"
+        weight = torch.zeros(4, 8)
+        bias = torch.zeros(4)
+    p1, p2 = FakePCA(), FakePCA()
+    e = _graph_store(core, p1, True, None, dev)
+    assert _graph_store(core, p1, True, None, dev) is e
+    assert _graph_store(core, p2, True, None, dev) is not e
