@@ -36,6 +36,21 @@ def split(x):
     return hi.double().reshape(shp), hi6.reshape(shp), lo6.reshape(shp)
 
 
+def split_half_pack(x):
+    """The same images as mx_pack_half makes them (the fused f16mx stem): hi and hi6 as in split(); the lo image
+    goes through fp16 first — q6(fp16(lo * 2^11)) on hi's block scale, i.e. lo is rounded twice."""
+    shp = x.shape
+    xb = x.float().reshape(-1, shp[-1] // 32, 32)
+    hi = xb.clamp(-65504.0, 65504.0).half().float()
+    lo = xb - hi
+    bh = scale_byte(hi.abs().amax(-1, keepdim=True))
+    sh = torch.pow(2.0, (bh - 127).double())
+    hi6 = e2m3_rne(hi.double() / sh) * sh
+    lo16 = (lo * 2048.0).half().double()                    # exact scaling, one rounding to fp16
+    lo6 = e2m3_rne(lo16 / sh) * sh / 2048.0
+    return hi.double().reshape(shp), hi6.reshape(shp), lo6.reshape(shp)
+
+
 def conv3x3(x_nchw, w_oihw, bias, relu, pool):
     """The f16mx product of a 3x3 layer in fp64: hi.hi + q6(hi).q6(lo) + q6(lo).q6(hi) (+ bias, ReLU, pool)."""
     import torch.nn.functional as F
