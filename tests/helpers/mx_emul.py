@@ -65,6 +65,30 @@ def conv3x3(x_nchw, w_oihw, bias, relu, pool):
     return y
 
 
+def stem(x_nchw, w1, b1, w2, b2):
+    """The fused f16mx stem in fp64, arithmetic for arithmetic: conv1_1 as the split-bf16 product
+    (hi.hi + hi.lo + lo.hi), bias, ReLU, the half-line pack of its fp32 result; conv1_2 as the f16mx product of
+    those lines with weights packed by mx_pack_line; 2x2 max-pool, bias, ReLU; the half-line pack of the output.
+    Returns the value the output lines carry (hi + q6(lo)), NCHW."""
+    import torch.nn.functional as F
+
+    def x3(v):
+        hi = v.float().bfloat16().float()
+        lo = (v.float() - hi).bfloat16().float()
+        return hi.double(), lo.double()
+    xh, xl = x3(x_nchw)
+    wh, wl = x3(w1)
+    c1 = F.conv2d(xh, wh, None, padding=1) + F.conv2d(xl, wh, None, padding=1) + F.conv2d(xh, wl, None, padding=1)
+    a1 = F.relu(c1 + b1.double().view(1, -1, 1, 1)).clamp(max=65504.0).float()
+    ah, ah6, al6 = [t.permute(0, 3, 1, 2) for t in split_half_pack(a1.permute(0, 2, 3, 1).contiguous())]
+    w2h, w2h6, w2l6 = [t.permute(0, 3, 1, 2) for t in split(w2.permute(0, 2, 3, 1).contiguous())]
+    y = F.conv2d(ah, w2h, None, padding=1) + F.conv2d(ah6, w2l6, None, padding=1) + F.conv2d(al6, w2h6, None, padding=1)
+    y = F.max_pool2d(y, 2, 2) + b2.double().view(1, -1, 1, 1)
+    y = F.relu(y).clamp(max=65504.0).float()
+    oh, _, ol6 = [t.permute(0, 3, 1, 2) for t in split_half_pack(y.permute(0, 2, 3, 1).contiguous())]
+    return oh + ol6
+
+
 def matmul_nt(x, y):
     """x [m][d] . y [n][d]^T with the f16mx product, fp64 accumulation."""
     xh, xh6, xl6 = split(x)

@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
 TOL_DESC = 1e-4      # north_star: descriptors within 1e-4 relative of the reference CPU path
 TOL_LAYER = 4e-5     # one contraction (~2^-15 per product, random signs) + the output representation hi + q6(lo)
 TOL_EMUL = 3e-6      # device vs the fp64 emulation of the same arithmetic: fp32 accumulation only
+TOL_STEM_EMUL = 1e-5  # the same for the fused stem (two contractions, two packs)
 
 
 def test_split_matches_host_emulation(dev):
@@ -227,6 +228,23 @@ def test_vgg_stem_mx_fused(dev, N, H, W):
     err = (_mx_out(y).double() - want).abs().reshape(N, 2, 32, -1).amax(2)
     ref = want.abs().reshape(N, 2, 32, -1).amax(2)
     assert (err <= 3e-4 * ref + 1e-6).all(), float((err / (ref + 1e-9)).max())
+
+
+@pytest.mark.parametrize("N,H,W", [(1, 8, 32), (2, 17, 65), (1, 64, 96)])
+def test_vgg_stem_mx_matches_the_emulation_of_its_arithmetic(dev, N, H, W):
+    """The stem against the fp64 emulation of ITS OWN arithmetic (tests/helpers/mx_emul.stem: split-bf16 conv1_1,
+    half-line packs, f16mx conv1_2): what is left is fp32 accumulation and the output codes it tips."""
+    x, w1, b1 = _case(N, H, W, 3, 64, seed=5 * H + W)
+    x = x * 60.0
+    _, w2, b2 = _case(1, 4, 4, 64, 64, seed=H + 9 * W)
+    y = ops.vgg16_stem_mx(x.to(dev), w1.to(dev), b1.to(dev), ops.pack_conv3x3(w2.to(dev), "f16mx"), b2.to(dev))
+    want = mx_emul.stem(x, w1, b1, w2, b2)
+    assert_rel_l2("fused f16mx stem vs its emulation", _mx_out(y), want, TOL_STEM_EMUL)
+    # (informative) fp16 parts: equal except where fp32 sums — or an input code they tipped — straddle an fp16
+    # rounding boundary
+    hi_got = _mx_out(y, 1).double()
+    hi_want = want.float().half().double()      # fp16 part of the emulated carried value (lo6 < half an ulp)
+    print(f"fp16 parts equal: {(hi_got == hi_want).double().mean().item():.4%}")
 
 
 # ---- matching -------------------------------------------------------------------------------------
