@@ -155,6 +155,8 @@ def time_extraction(c, model, x, precision, steps, warmup, eager=False, pipeline
         t0 = time.perf_counter()
         for k in range(steps):
             out = step(None if fwd1 is not None else ev[k])
+        if fwd is not None:
+            fwd.wait()                  # f16mx: the range flags of the last two batches are checked INSIDE the region
         c.barrier()
         t1 = time.perf_counter()
         model.base_model.profile_events = None
@@ -172,6 +174,7 @@ def time_extraction(c, model, x, precision, steps, warmup, eager=False, pipeline
             t0 = time.perf_counter()
             for k in range(steps):
                 out = step(ev[k], fwd1)
+            fwd1.wait()
             c.barrier()
             one_lane = x.shape[0] * steps / (time.perf_counter() - t0)
             assert torch.equal(out, ref), "one-lane timed forward differs from model(x)"

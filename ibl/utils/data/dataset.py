@@ -45,8 +45,10 @@ class Dataset(object):
         """Fill the record lists from the json files the reference's dataset parsers write under
         `root` (meta[_scale].json: identities + utm; splits[_scale].json: place ids per split) —
         the loader the reference's Pittsburgh / Tokyo classes call from their constructors
-        (ibl/utils/data/dataset.py:57-115).  Queries without a positive within 25 m are dropped from
-        val / test, training queries without a positive within `intra_thres`."""
+        (ibl/utils/data/dataset.py:57-115).  Training queries without a positive within `intra_thres` are
+        dropped; for val / test the reference's literal 25 m radius applies and — as there — every query is
+        ASSERTED to have a positive inside it (a split with such a query raises AssertionError, it is not
+        filtered)."""
         import os.path as osp
         from ..serialization import read_json
         suffix = '' if scale is None else '_' + str(scale)

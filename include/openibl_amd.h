@@ -37,6 +37,15 @@
  *                   OIBL_BF16X3.  Element = 4 bytes; a row of C elements (C % 32 == 0) is C/32 lines
  *                   of 128 bytes: [32 x fp16 | q6(hi) 16 B | q6(lo) 16 B | q6(hi) 8 B, scale, pad |
  *                   q6(lo) 8 B, scale, pad], see oibl_mx_split_rows.
+ *                   RANGE: hi = fp16(v) exists only for |v| <= 65504.  A producer of f16mx lines that meets
+ *                   a larger value saturates it (the line is then NOT a 1e-4 image of the value) and raises
+ *                   the caller's RANGE FLAG — a uint32 in device memory that the caller zeroes before the
+ *                   pass and reads after it: non-zero = the pass must be repeated in OIBL_BF16X3 (same
+ *                   tolerance class, no range limit).  oibl_vgg16_conv5_forward* keep the flag in the first
+ *                   word of their workspace; oibl_conv3x3_nhwc_flagged / oibl_mx_split_rows_flagged take it
+ *                   as an argument; the matching entry points mark an out-of-range descriptor row with a
+ *                   +inf norm (all its distances are +inf).  The host mirror (openibl_amd/models.py) reads
+ *                   the flag once per batch and re-runs flagged batches in OIBL_BF16X3.
  *     and with it the element type of activation / packed-weight buffers ("T" below:
  *     uint16 bf16 bits, float, or the 4-byte split element).
  */
@@ -98,6 +107,10 @@ int oibl_x3_join_rows(const void* src, float* dst, size_t rows, int C, void* str
  * returns what the kernels see of every element: which = 0: hi + q6(lo) (the stored value to ~2^-15
  * of the line's largest element), 1: hi (fp16, exact), 2: q6(hi), 3: q6(lo). */
 int oibl_mx_split_rows(const float* src, void* dst, size_t rows, int C, void* stream);
+/* The same with a range flag (may be NULL): *range_flag is set to 1 when a group holds a value beyond
+ * +-65504 (see OIBL_F16MX above); never cleared by the call. */
+int oibl_mx_split_rows_flagged(const float* src, void* dst, size_t rows, int C, uint32_t* range_flag,
+                               void* stream);
 int oibl_mx_join_rows(const void* src, float* dst, size_t rows, int C, int which, void* stream);
 
 /* ---- bilinear resize --------------------------------------------------------------- *
@@ -129,6 +142,12 @@ int oibl_pack_conv3x3_weights(const float* w_oihw, int cout, int cin, int precis
 int oibl_conv3x3_nhwc(const void* in, int N, int H, int W, int cin, const void* packed_w,
                       const float* bias, int cout, int relu, int pool, int precision,
                       void* out, void* stream);
+/* The same with a range flag for OIBL_F16MX outputs (may be NULL; ignored by the other precisions):
+ * *range_flag is set to 1 when an output of the layer is beyond +-65504 and was saturated (see OIBL_F16MX
+ * above); never cleared by the call. */
+int oibl_conv3x3_nhwc_flagged(const void* in, int N, int H, int W, int cin, const void* packed_w,
+                              const float* bias, int cout, int relu, int pool, int precision,
+                              void* out, uint32_t* range_flag, void* stream);
 
 /* First layer: reads the reference's input tensor directly — x [N][3][H][W] fp32 NCHW
  * (already mean/std normalised, ibl/utils/data/__init__.py:40-41) — conv1_1 + bias + ReLU,
@@ -203,7 +222,13 @@ int oibl_vgg16_stem_mx(const float* x_nchw, int N, int H, int W, const float* w1
  * OIBL_BF16X3: activations between the layers are (hi, lo) split elements, but `feat` is written as
  * plain fp32 (the head consumes it with OIBL_F32).
  * OIBL_F16MX: every entry packed with OIBL_F16MX (conv1_1 + conv1_2 + pool = oibl_vgg16_stem_mx; the
- * mode has no unfused front: inputs of 3.5 GB and more are refused); `feat` is plain fp32.
+ * mode has no unfused front and 32-bit-offset kernels only: a batch whose fp32 input or whose largest
+ * activation — conv2_2's input, N (H/2) (W/2) 128 x 4 bytes: 95 images of 480x640 — reaches 3.5 GB is
+ * refused with OIBL_E_INVALID); `feat` is plain fp32.  The FIRST
+ * 32-BIT WORD OF THE WORKSPACE is the pass's range flag: zeroed (stream-ordered) when the call starts,
+ * 1 afterwards if any activation between the layers was beyond +-65504 — `feat` is then not a 1e-4 result
+ * and the batch has to be repeated in OIBL_BF16X3 (see OIBL_F16MX at the top).  The other precisions leave
+ * the word untouched.
  * The workspace holds the two ping-pong activation buffers and, for small batches, the fp32
  * partial tiles of the layers that run split-K (a layer whose 128-row tiling gives <= 192 tiles is
  * contracted by 2-8 workgroups per tile and reduced in a fixed order: deterministic, equal to

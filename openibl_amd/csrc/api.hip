@@ -261,7 +261,7 @@ int oibl_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_host) {
   return OIBL_OK;
 }
 
-int oibl_abi_version(void) { return 2; }
+int oibl_abi_version(void) { return 3; }
 const char* oibl_last_error(void) { return g_err; }
 const char* oibl_target_arch(void) { return "gfx950"; }
 size_t oibl_elem_size(int precision) {

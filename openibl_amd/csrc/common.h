@@ -176,8 +176,18 @@ __host__ __device__ static inline int mx_scale_byte(float amax) {
   return b < 12 ? 12 : (b > 254 ? 254 : b);
 }
 
+// Range guard of the f16mx arithmetic.  hi = fp16(v) exists only for |v| <= 65504: beyond that the packers
+// saturate hi and the excess goes to lo, whose e2m3 image saturates too — the line no longer carries v (one
+// 256 -> 256 layer: rel-L2 2.4e-1 with activations up to 2e5 against 1.5e-5 up to 3e4).  Every packer
+// therefore RAISES A STICKY FLAG — one 32-bit word the caller zeroes before the pass and reads after it —
+// when a group's largest |v| is beyond fp16; the host mirror re-runs such a batch in bf16x3
+// (openibl_amd/models.py).  The branch is wave-uniform and off the common path; all writers store 1.
+__device__ static inline void mx_raise_range_flag(unsigned* flag) {
+  if (flag != nullptr) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // 32 fp32 values (one pixel's / row's 32-element group) -> the 128-byte f16mx line
-__device__ static inline void mx_pack_line(const float (&v)[32], uint4 (&out)[8]) {
+__device__ static inline void mx_pack_line(const float (&v)[32], uint4 (&out)[8], unsigned* range_flag = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)   // (the host pass only needs the declaration)
   typedef __attribute__((ext_vector_type(2))) float f2;
   typedef __attribute__((ext_vector_type(2))) _Float16 h2;
@@ -192,14 +202,16 @@ __device__ static inline void mx_pack_line(const float (&v)[32], uint4 (&out)[8]
   float amax = 0.f;
 #pragma unroll
   for (int e = 0; e < 32; e += 2) asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(v[e]), "v"(v[e + 1]));
-  // beyond fp16 (never seen on this model): hi saturates at +-65504, the excess goes to lo.  Wave-uniform
-  // branch, so that the 32 clamps are not if-converted into the common path.
+  // beyond fp16: hi saturates at +-65504, the excess goes to lo, and the range flag is raised (the line is
+  // then NOT a 1e-4 image of v: see mx_raise_range_flag).  Wave-uniform branch, so that the 32 clamps are
+  // not if-converted into the common path.
   float c[32];
 #pragma unroll
   for (int e = 0; e < 32; ++e) c[e] = v[e];
   if (__builtin_amdgcn_ballot_w64(amax > 65504.f) != 0) {
 #pragma unroll
     for (int e = 0; e < 32; ++e) c[e] = __builtin_amdgcn_fmed3f(c[e], -65504.f, 65504.f);
+    if (amax > 65504.f) mx_raise_range_flag(range_flag);
   }
 #pragma unroll
   for (int e = 0; e < 32; e += 2) {
@@ -237,10 +249,12 @@ __device__ static inline void mx_pack_line(const float (&v)[32], uint4 (&out)[8]
 // source instead of two half-used ones — these callers have no registers to give away).  lo is thereby
 // rounded twice (fp16, then e2m3; mx_pack_line converts it from fp32): a code can move by one step where
 // the fp16 rounding crosses an e2m3 midpoint — 2^-12 of a term that is itself 2^-11 of the product.
-// CLAMP = false: the caller guarantees |v| <= 65504 (the stems fold the bound into their ReLU).
+// CLAMP = false: the caller guarantees |v| <= 65504 (the stems fold the bound into their ReLU); a group
+// maximum AT the bound then counts as out of range (a value clamped there, or — harmlessly — exactly 65504).
 template <bool CLAMP = true>
 __device__ static inline void mx_pack_half(const float (&v)[16], unsigned (&h16)[8], unsigned (&h6)[3],
-                                           unsigned (&l6)[3], unsigned& bh, unsigned& bl) {
+                                           unsigned (&l6)[3], unsigned& bh, unsigned& bl,
+                                           unsigned* range_flag = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef __attribute__((ext_vector_type(2))) float f2;
   typedef __attribute__((ext_vector_type(2))) _Float16 h2;
@@ -264,9 +278,14 @@ __device__ static inline void mx_pack_half(const float (&v)[16], unsigned (&h16)
 #pragma unroll
   for (int e = 0; e < 16; ++e) c[e] = v[e];
   if constexpr (CLAMP) {
-    if (__builtin_amdgcn_ballot_w64(amax > 65504.f) != 0) {   // never seen on this model; wave-uniform
+    if (__builtin_amdgcn_ballot_w64(amax > 65504.f) != 0) {   // wave-uniform, off the common path
 #pragma unroll
       for (int e = 0; e < 16; ++e) c[e] = __builtin_amdgcn_fmed3f(c[e], -65504.f, 65504.f);
+      if (amax > 65504.f) mx_raise_range_flag(range_flag);
+    }
+  } else {
+    if (__builtin_amdgcn_ballot_w64(amax >= 65504.f) != 0) {
+      if (amax >= 65504.f) mx_raise_range_flag(range_flag);
     }
   }
   u16v_ w_;   // dwords 0..7: hi pairs, 8..15: fp16(lo * 2^11) pairs

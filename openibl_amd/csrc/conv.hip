@@ -71,7 +71,8 @@ __global__ void pack_conv3x3_mx_kernel(const float* __restrict__ w, char* __rest
 // rows: SRC = 0 fp32 rows [rows][C] -> f16mx lines; SRC = 1 bf16x3 lines -> f16mx lines (may be in
 // place: a thread reads its whole line before it writes it).  One thread per line.
 template <int SRC>
-__global__ void mx_pack_rows_kernel(const char* __restrict__ src, char* __restrict__ dst, size_t lines) {
+__global__ void mx_pack_rows_kernel(const char* __restrict__ src, char* __restrict__ dst, size_t lines,
+                                    unsigned* range_flag) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < lines;
        i += (size_t)gridDim.x * blockDim.x) {
     float v[32];
@@ -103,7 +104,7 @@ __global__ void mx_pack_rows_kernel(const char* __restrict__ src, char* __restri
       }
     }
     uint4 line[8];
-    mx_pack_line(v, line);
+    mx_pack_line(v, line, range_flag);
     uint4* dp = reinterpret_cast<uint4*>(dst + i * 128);
 #pragma unroll
     for (int k = 0; k < 8; ++k) dp[k] = line[k];
@@ -356,6 +357,7 @@ struct ConvParams {
   // a fixed order, then bias / ReLU / pool / store.
   int ksplit;
   float* partial;
+  unsigned* range_flag;  // f16mx: the pass's range flag (common.h, mx_raise_range_flag); may be null
 };
 
 // one output element into the staged tile row (row-major [BN] of T; bf16x3: (hi, lo) groups or fp32)
@@ -716,6 +718,7 @@ static int launch_conv_ring_impl(const ConvParams& p, hipStream_t st) {
   q.tiles_m = (int)tiles_m;
   q.raster = g_ring_raster;
   q.korder = p.korder;
+  q.range_flag = p.range_flag;
   constexpr int lds = ring_lds_bytes<WM, POOL, P, OUTMX>();
   auto kern = conv3x3_ring_kernel<WM, POOL, ODD, P, OUTMX>;
   OIBL_SET_MAX_LDS(kern, lds);
@@ -882,6 +885,7 @@ static int launch_conv_halo(const ConvParams& p, hipStream_t st) {
   ring_magic_u31((unsigned)(q.PW + 2), &q.hp_mul, &q.hp_sh);
   q.relu = p.relu;
   q.out_f32 = p.out_f32;
+  q.range_flag = p.range_flag;
   const dim3 grid((unsigned)(tiles_m * q.tiles_n));
   if (g_halo_var == 3) {
     auto kern = conv3x3_halo_kernel<POOL, RING_MX_EARLY, 3>;
@@ -925,8 +929,8 @@ static int launch_conv_mx(const ConvParams& p, int pool, hipStream_t st) {
   }
   if (rv == 2) return pool ? launch_conv_ring<2, true, RING_MX_EARLY>(p, st) : launch_conv_ring<2, false, RING_MX_EARLY>(p, st);
   if (rv == 4) return pool ? launch_conv_ring<4, true, RING_MX_EARLY>(p, st) : launch_conv_ring<4, false, RING_MX_EARLY>(p, st);
-  set_error("conv3x3 (f16mx): unsupported layer cin=%d cout=%d (needs Cin %% 64 == 0, Cout %% 128 == 0)", p.cin,
-            p.cout);
+  set_error("conv3x3 (f16mx): unsupported layer cin=%d cout=%d at N=%d H=%d W=%d (needs Cin %% 64 == 0, "
+            "Cout %% 128 == 0 and an input below 3.5 GB)", p.cin, p.cout, p.N, p.H, p.W);
   return OIBL_E_UNSUPPORTED;
 }
 
@@ -1253,6 +1257,7 @@ struct StemParams {
   int tiles_x, tiles_y, ntiles;
   unsigned long long* prof;  // optional (test hook): shader-clock totals of block 0, waves 0 and 4
   int prod_prio;             // bf16x3 stem: issue priority of the producer role outside its MFMAs
+  unsigned* range_flag;      // f16mx stem: raised when a conv1_1 / conv1_2 output hits the fp16 bound; may be null
 };
 
 // U8 = true: the input is the loader's raw uint8 NHWC image; ToTensor + Normalize
@@ -2005,7 +2010,7 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
           const float lim = pix_ok ? 65504.f : 0.f;
 #pragma unroll
           for (int j = 0; j < 16; ++j) c[j] = __builtin_amdgcn_fmed3f(acc[j], 0.f, lim);
-          mx_pack_half<false>(c, ph16, ph6, pl6, pbh, pbl);
+          mx_pack_half<false>(c, ph16, ph6, pl6, pbh, pbl, p.range_flag);
           flush(buf);
         } else if (row_of(bi) < ST_HALO_PX) {
           char* row = buf + row_of(bi) * 128 + 8 * half;
@@ -2302,7 +2307,7 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = __builtin_amdgcn_fmed3f(m0[j] + bv[j], 0.f, 65504.f);   // bias, ReLU, the fp16 bound
         unsigned h16[8], h6[3], l6[3], bh, bl;
-        mx_pack_half<false>(v, h16, h6, l6, bh, bl);
+        mx_pack_half<false>(v, h16, h6, l6, bh, bl, p.range_flag);
         // lanes 0, 1 of a quad store: pooled pixel 8 (l31 & 1) + (l31 >> 2) of the tile row
         const unsigned off = (l31 & 2) ? 0x80000000u
                                        : (unsigned)(tx * 16 + 8 * (l31 & 1) + (l31 >> 2)) * 256u + blockIdx.y * 128u;
@@ -2499,8 +2504,9 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
 
 static int launch_vgg_stem_x3(const float* x, int N, int H, int W, const float* w1, const float* b1,
                               const void* packed_w2, const float* b2, void* out, hipStream_t st,
-                              bool mx = false) {
+                              bool mx = false, unsigned* range_flag = nullptr) {
   StemParams p = {};
+  p.range_flag = range_flag;
   p.x = x;
   p.w1 = w1;
   p.b1 = b1;
@@ -2554,6 +2560,11 @@ __global__ void u8_nhwc_to_nchw_f32_kernel(const uint8_t* __restrict__ x, float*
 
 static bool stem_eligible(int N, int H, int W) {
   return H >= 2 && W >= 2 && (size_t)N * 3 * H * W * 4 < (size_t)0xE0000000u;
+}
+// every activation an f16mx convolution reads stays inside a 32-bit buffer offset (ring_variant): the
+// largest is conv2_2's input [N][H/2][W/2][128] x 4 bytes
+static bool vgg16_f16mx_fits(int N, int H, int W) {
+  return stem_eligible(N, H, W) && (size_t)N * (H / 2) * (W / 2) * 128 * 4 < (size_t)0xE0000000u;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2637,7 +2648,8 @@ static size_t conv_splitk_bytes(long m_total, int cin, int cout, int precision) 
 
 static int conv3x3_impl(const void* in, int N, int H, int W, int cin, const void* packed_w,
                         const float* bias, int cout, int relu, int pool, int precision, void* out,
-                        hipStream_t st, int out_f32 = 0, void* splitk_ws = nullptr) {
+                        hipStream_t st, int out_f32 = 0, void* splitk_ws = nullptr,
+                        unsigned* range_flag = nullptr) {
   OIBL_REQUIRE(in && packed_w && bias && out, "conv3x3: null pointer");
   OIBL_REQUIRE(precision_ok(precision), "conv3x3: bad precision %d", precision);
   const int bk = precision == OIBL_BF16 ? 64 : 32;
@@ -2679,6 +2691,7 @@ static int conv3x3_impl(const void* in, int N, int H, int W, int cin, const void
   }
   p.ksplit = 0;
   p.partial = (float*)splitk_ws;
+  p.range_flag = range_flag;
   if (splitk_ws && g_conv_splitk && precision != OIBL_F16MX)
     p.ksplit = conv_splitk_factor(p.m_total, cout, 9 * (cin / bk));
   if (precision == OIBL_F16MX) return launch_conv_mx(p, pool, st);
@@ -2848,6 +2861,14 @@ int oibl_conv3x3_nhwc(const void* in, int N, int H, int W, int cin, const void* 
                       (hipStream_t)stream);
 }
 
+int oibl_conv3x3_nhwc_flagged(const void* in, int N, int H, int W, int cin, const void* packed_w,
+                              const float* bias, int cout, int relu, int pool, int precision, void* out,
+                              uint32_t* range_flag, void* stream) {
+  OIBL_REQUIRE(range_flag == nullptr || (uintptr_t)range_flag % 4 == 0, "conv3x3: range flag must be 4-byte aligned");
+  return conv3x3_impl(in, N, H, W, cin, packed_w, bias, cout, relu, pool, precision, out,
+                      (hipStream_t)stream, 0, nullptr, range_flag);
+}
+
 int oibl_conv1_1_nchw(const float* x_nchw, int N, int H, int W, const float* w_oihw,
                       const float* bias, int precision, void* out, void* stream) {
   OIBL_REQUIRE(x_nchw && w_oihw && bias && out, "conv1_1: null pointer");
@@ -2962,12 +2983,15 @@ static size_t vgg_splitk_bytes(int N, int H, int W, int precision) {
   return mx;
 }
 
+// the workspace starts with the f16mx range flag (one 32-bit word, see the header) in a 256-byte slot
+constexpr size_t VGG_WS_HEAD = 256;
+
 size_t oibl_vgg16_workspace_bytes(int N, int H, int W, int precision) {
   if (N <= 0 || H < 16 || W < 16) return 0;
   size_t ea, eb;
   vgg_buffer_elems(N, H, W, &ea, &eb);
   const size_t es = oibl_elem_size(precision);
-  return align_up(ea * es, 256) + align_up(eb * es, 256) + vgg_splitk_bytes(N, H, W, precision);
+  return VGG_WS_HEAD + align_up(ea * es, 256) + align_up(eb * es, 256) + vgg_splitk_bytes(N, H, W, precision);
 }
 
 int oibl_vgg16_conv5_forward(const float* x_nchw, int N, int H, int W,
@@ -2996,10 +3020,13 @@ static int vgg_forward_impl(const void* x, int u8, const float* mean3, const flo
   size_t ea, eb;
   vgg_buffer_elems(N, H, W, &ea, &eb);
   const size_t es = oibl_elem_size(precision);
-  char* bufA = (char*)ws;
+  char* bufA = (char*)ws + VGG_WS_HEAD;
   char* bufB = bufA + align_up(ea * es, 256);
   char* splitk = vgg_splitk_bytes(N, H, W, precision) ? bufB + align_up(eb * es, 256) : nullptr;
   hipStream_t st = (hipStream_t)stream;
+  // f16mx: the pass starts with a clear range flag; every packer of the pass may raise it (common.h)
+  unsigned* const range_flag = precision == OIBL_F16MX ? (unsigned*)ws : nullptr;
+  if (range_flag) OIBL_HIP_CHECK(hipMemsetAsync(range_flag, 0, sizeof(unsigned), st));
 
   int rc;
   int h = H, w = W, l0 = 1;
@@ -3021,11 +3048,15 @@ static int vgg_forward_impl(const void* x, int u8, const float* mean3, const flo
                       !g_conv_ablate && g_conv_tile == 0;
   // f16mx has no unfused front (Cout = 64 fits no f16mx tile): conv1_2's weights are packed for the stem
   OIBL_REQUIRE(!mx || fused3, "vgg16: the f16mx backbone needs the fused stem (input below 3.5 GB, no stem / tile hooks)");
+  // ... and only 32-bit-offset kernels behind it: the largest activation they read is conv2_2's input
+  OIBL_REQUIRE(!mx || vgg16_f16mx_fits(N, H, W),
+               "vgg16 (f16mx): a batch of %d x %d x %d exceeds the 3.5 GB per-activation limit of the f16mx kernels "
+               "(conv2_2 reads N (H/2) (W/2) 128 4-byte elements): split the batch or use OIBL_BF16X3", N, H, W);
   if (fused3) {
     // bf16x3 / f16mx: conv1_1 + conv1_2 + pool in one launch (the uint8 entry has normalised into x_f32)
     if (ev_igemm_begin) OIBL_HIP_CHECK(hipEventRecord((hipEvent_t)ev_igemm_begin, st));
     rc = launch_vgg_stem_x3(x_f32, N, H, W, (const float*)packed_w_host[0], bias_host[0], packed_w_host[1],
-                            bias_host[1], bufB, st, mx);
+                            bias_host[1], bufB, st, mx, range_flag);
     if (rc) return rc;
     h /= 2;
     w /= 2;
@@ -3052,7 +3083,8 @@ static int vgg_forward_impl(const void* x, int u8, const float* mean3, const flo
     void* dst = (l == OIBL_VGG16_NUM_CONV - 1) ? feat : (l % 2 == 0 ? (void*)bufA : (void*)bufB);
     // bf16x3 / f16mx: the last layer hands the head a plain fp32 map
     rc = conv3x3_impl(cur, N, h, w, kVgg[l].cin, packed_w_host[l], bias_host[l], kVgg[l].cout,
-                      kVgg[l].relu, kVgg[l].pool, precision, dst, st, l == OIBL_VGG16_NUM_CONV - 1, splitk);
+                      kVgg[l].relu, kVgg[l].pool, precision, dst, st, l == OIBL_VGG16_NUM_CONV - 1, splitk,
+                      range_flag);
     if (rc) return rc;
     if (kVgg[l].pool) {
       h /= 2;
@@ -3099,16 +3131,22 @@ int oibl_x3_split_rows(const float* src, void* dst, size_t rows, int C, void* st
   return OIBL_OK;
 }
 
-int oibl_mx_split_rows(const float* src, void* dst, size_t rows, int C, void* stream) {
+int oibl_mx_split_rows_flagged(const float* src, void* dst, size_t rows, int C, uint32_t* range_flag,
+                               void* stream) {
   OIBL_REQUIRE(src && dst, "mx_split_rows: null pointer");
   OIBL_REQUIRE(C > 0 && C % 32 == 0, "mx_split_rows: C %% 32 != 0");
+  OIBL_REQUIRE(range_flag == nullptr || (uintptr_t)range_flag % 4 == 0, "mx_split_rows: range flag must be 4-byte aligned");
   if (rows == 0) return OIBL_OK;
   const size_t lines = rows * (size_t)(C / 32);
   unsigned b = (unsigned)((lines + 255) / 256);
   hipLaunchKernelGGL(mx_pack_rows_kernel<0>, dim3(b > 16384 ? 16384 : b), dim3(256), 0, (hipStream_t)stream,
-                     (const char*)src, (char*)dst, lines);
+                     (const char*)src, (char*)dst, lines, (unsigned*)range_flag);
   OIBL_LAUNCH_CHECK();
   return OIBL_OK;
+}
+
+int oibl_mx_split_rows(const float* src, void* dst, size_t rows, int C, void* stream) {
+  return oibl_mx_split_rows_flagged(src, dst, rows, C, nullptr, stream);
 }
 
 int oibl_mx_join_rows(const void* src, float* dst, size_t rows, int C, int which, void* stream) {

@@ -66,6 +66,7 @@ struct HaloParams {
   unsigned pw_mul, pw_sh;    // divide by PW (pooled: PW / 2): tile row -> pixel / quad
   unsigned hp_mul, hp_sh;    // divide by PW + 2: halo position -> (hy, hx)
   int relu, out_f32;
+  unsigned* range_flag;      // raised when an output is beyond fp16 (common.h, mx_raise_range_flag); may be null
 };
 
 // one phase's matrix work on two 32x32 accumulator tiles (ring_core.h, compute)
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(HaloParams p) {
           v[4 * k + 3] = t.w;
         }
         uint4 line[8];
-        mx_pack_line(v, line);
+        mx_pack_line(v, line, p.range_flag);
 #pragma unroll
         for (int k = 0; k < 8; ++k) *reinterpret_cast<uint4*>(rowp + (((grp * 8 + k) ^ sw) << 4)) = line[k];
       }

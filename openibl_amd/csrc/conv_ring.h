@@ -46,6 +46,7 @@ struct RingParams {
   int tiles_m;
   int raster;   // xcd_tile() mode
   int korder;   // 0 = (tap, channel chunk), 1 = (channel chunk, tap): see ConvRingALoader::begin_tile
+  unsigned* range_flag;  // f16mx output: raised when an output is beyond fp16 (common.h, mx_raise_range_flag); may be null
 };
 
 // mul, sh with floor(m / d) == (m * mul) >> sh for every m < 2^31 (d >= 1):  sh = 31 + ceil(log2 d),
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
             v[4 * k + 3] = t.w;
           }
           uint4 line[8];
-          mx_pack_line(v, line);
+          mx_pack_line(v, line, p.range_flag);
 #pragma unroll
           for (int k = 0; k < 8; ++k) *reinterpret_cast<uint4*>(rowp + (((grp * 8 + k) ^ sw) << 4)) = line[k];
         }

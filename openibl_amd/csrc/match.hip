@@ -96,7 +96,9 @@ __global__ void row_sqnorm_cast_kernel(const void* __restrict__ x, float* __rest
 }
 
 // f16mx operand rows (common.h): one wave per row, a lane packs whole 32-element groups (their 128-byte
-// lines); the norm is that of the widened row, as in the other modes.
+// lines); the norm is that of the widened row, as in the other modes.  A row with an element beyond fp16
+// (|v| > 65504: its line is not a 1e-4 image of it, common.h) gets the norm +inf — every distance to it is
+// +inf, never a finite wrong number.  (Descriptors are unit vectors: ibl/evaluators.py:33.)
 template <int ST>
 __global__ void row_sqnorm_mx_kernel(const void* __restrict__ x, float* __restrict__ out,
                                      void* __restrict__ xo, int rows, int d) {
@@ -107,6 +109,7 @@ __global__ void row_sqnorm_mx_kernel(const void* __restrict__ x, float* __restri
   const char* xr = static_cast<const char*>(x) + (size_t)row * d * es;
   uint4* orow = reinterpret_cast<uint4*>(static_cast<char*>(xo) + (size_t)row * d * 4);
   float s = 0.f;
+  bool over = false;
   for (int g = lane; g < (d >> 5); g += 64) {
     float v[32];
 #pragma unroll
@@ -119,12 +122,15 @@ __global__ void row_sqnorm_mx_kernel(const void* __restrict__ x, float* __restri
     }
 #pragma unroll
     for (int e = 0; e < 32; ++e) s = fmaf(v[e], v[e], s);
+#pragma unroll
+    for (int e = 0; e < 32; ++e) over |= fabsf(v[e]) > 65504.f;   // (a NaN row keeps its NaN norm)
     uint4 line[8];
     mx_pack_line(v, line);
 #pragma unroll
     for (int k = 0; k < 8; ++k) orow[g * 8 + k] = line[k];
   }
   s = wave_sum(s);
+  if (__builtin_amdgcn_ballot_w64(over) != 0) s = INFINITY;
   if (lane == 0) out[row] = s;
 }
 
@@ -297,29 +303,32 @@ __global__ __launch_bounds__(512) void pairwise_ring_kernel(PairRingParams p) {
   // lane geometry: column col0 + 32 j, rows row0 + 32 i + (r & 3) + 8 (r >> 2)
   const int col0 = wn * 64 + (lane & 31), row0 = wm * 128 + 4 * (lane >> 5);
   if constexpr (!FILTER) {
-    // stores go through a buffer descriptor based at the tile's first element: one 32-bit lane
-    // offset, everything else is scalar (the host guarantees 256 * ldd * 4 < 2^31)
-    const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(
-        p.dist + (size_t)kh * p.part_stride + (size_t)m0 * p.ldd + n0, 0, 0x7fffffff, 0x00020000);
+    // stores go through buffer descriptors based at the first element of each 32-row accumulator tile of
+    // the wave: one 32-bit lane offset, everything else is scalar (offsets inside a tile stay below
+    // 31 * ldd * 4 bytes: the host guarantees ldd <= 2^24)
+    const float* const dbase = p.dist + (size_t)kh * p.part_stride + ((size_t)m0 + wm * 128) * p.ldd + n0;
     const unsigned ldd4 = (unsigned)p.ldd * 4u;
-    const unsigned voff = (unsigned)row0 * ldd4 + (unsigned)col0 * 4u;
+    const unsigned voff = (unsigned)(4 * (lane >> 5)) * ldd4 + (unsigned)col0 * 4u;
     const int rows_left = p.m - m0 - row0;  // row r of this lane is valid iff its offset < rows_left
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const bool nok = n0 + col0 + 32 * j < p.n;
-      const float yn = yn_s[col0 + 32 * j];
+    for (int i = 0; i < 4; ++i) {
+      const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(dbase + (size_t)(32 * i) * p.ldd), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 2; ++j) {
+        const bool nok = n0 + col0 + 32 * j < p.n;
+        const float yn = yn_s[col0 + 32 * j];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int ro = 32 * i + (r & 3) + 8 * (r >> 2);
+          const int rt = (r & 3) + 8 * (r >> 2), ro = 32 * i + rt;
           const float dv = fmaf(-2.0f, acc[i][j][r], xn_s[row0 + ro] + yn);
           if (nok && ro < rows_left)
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dv), rs_d, (int)voff,
-                                                  (int)((unsigned)ro * ldd4 + 128u * j), 0);
+                                                  (int)((unsigned)rt * ldd4 + 128u * j), 0);
           // keep the scalar row offsets from being computed (and spilled) for all 128 stores at once
           if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
         }
+      }
     }
   } else {
     // Survivors are rare (about 1 % of the distances, ~1.3 per lane and tile) but a wave sees one
@@ -962,7 +971,7 @@ static int pairwise_launch(const void* xo, const void* yo, const float* xn, cons
   if (precision == OIBL_F16MX) {
     // the ring kernel is the only f16mx implementation: panels of rows / columns keep every launch inside
     // the 32-bit buffer offsets of its operand loaders
-    OIBL_REQUIRE(ldd <= ((size_t)1 << 20), "pairwise (f16mx): row stride %zu above 2^20", ldd);
+    OIBL_REQUIRE(ldd <= ((size_t)1 << 24), "pairwise (f16mx): row stride %zu above 2^24", ldd);
     long panel = (long)(((size_t)0xE0000000u / ((size_t)d * 4) - 1) / 256 * 256);
     if (panel > (1 << 20)) panel = 1 << 20;
     for (long r0 = 0; r0 < rows; r0 += panel)
@@ -987,7 +996,7 @@ static int pairwise_launch(const void* xo, const void* yo, const float* xn, cons
       }
     return OIBL_OK;
   }
-  if (mfma16(precision) && pair_ring_wanted(rows, n, d, (int)es) && ldd <= ((size_t)1 << 20)) {
+  if (mfma16(precision) && pair_ring_wanted(rows, n, d, (int)es) && ldd <= ((size_t)1 << 24)) {
     PairRingParams q = {};
     q.x = (const char*)xo + (size_t)row0 * d * es;
     q.y = yo;

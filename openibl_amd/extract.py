@@ -28,6 +28,7 @@ bit-identical to `extract_cnn_feature` batch by batch (tested).
 from __future__ import annotations
 
 import time
+import weakref
 from collections import OrderedDict
 from typing import Callable, Optional
 
@@ -35,7 +36,7 @@ import torch
 
 from . import ops
 
-__all__ = ["GraphedForward", "extract_descriptors", "unwrap_model", "MAX_CACHED_SHAPES"]
+__all__ = ["GraphedForward", "extract_descriptors", "unwrap_model", "release_graphs", "MAX_CACHED_SHAPES"]
 
 MAX_CACHED_SHAPES = 3     # captured (shape, dtype) entries kept per extraction (each owns its
                           # activation workspaces: ~2.5 GB for 32 x 480x640 in bf16)
@@ -82,10 +83,21 @@ class GraphedForward:
     has copied it (`wait()`); host tensors are read before the call returns unless pinned.
     `events`: optional (start, stop) torch.cuda.Event pair recorded on the launching lane right
     around the backbone graph (bench.py's matrix-core span: meaningful with ONE lane — with two the
-    spans of consecutive batches overlap)."""
+    spans of consecutive batches overlap).
+
+    f16mx range guard.  A backbone that runs in f16mx raises a device flag when an activation is beyond
+    fp16 (models.VGG.features_nhwc); a replayed graph cannot branch on it, so the flag travels to a pinned
+    host word behind every backbone replay and is CHECKED BEFORE THE SLOT IS USED AGAIN (or in `wait()`):
+    the host then waits for that batch's `done` event — two batches back with two lanes, so the lanes never
+    run dry — and a flagged batch is recomputed eagerly in bf16x3 from the slot's still-resident input,
+    into the slot's output and into its `dest`.  With the guard `wait()` therefore blocks the host, and a
+    one-lane forward checks before it returns.  `range_guard`: the object with `last_range_flag()` /
+    `features_fallback(x)` (default: the object `backbone_fn` is bound to, if it has them).
+    `keep`: optional callable returning tensors (in nested dicts / lists) the captured kernels point into —
+    packed weights — evaluated after the capture; they stay referenced for the life of this object."""
 
     def __init__(self, backbone_fn: Callable, head_fn: Callable, example: torch.Tensor,
-                 pipeline: bool = False):
+                 pipeline: bool = False, range_guard=None, keep: Optional[Callable] = None):
         if not example.is_cuda or example.dim() != 4 or example.dtype not in (torch.float32, torch.uint8):
             raise ValueError("graphed forward: example must be a CUDA tensor, float32 [N][3][H][W] "
                              "or uint8 [N][H][W][3]")
@@ -103,6 +115,17 @@ class GraphedForward:
         self.done = [torch.cuda.Event() for _ in range(self.depth)]
         self.g_backbone, self.g_head, self.out = [], [], []
         self._keep = []
+        if range_guard is None:
+            owner = getattr(backbone_fn, "__self__", None)
+            if hasattr(owner, "last_range_flag") and hasattr(owner, "features_fallback"):
+                range_guard = owner
+        self.guard = range_guard
+        self.head_fn = head_fn
+        self.flag_dev = [None] * self.depth       # the lane's range flag (device), None: not an f16mx capture
+        self.flag_host = [None] * self.depth      # its pinned host copy, refreshed behind every backbone replay
+        self.unsettled = [False] * self.depth     # a batch of this slot has not had its flag checked yet
+        self.pending_dest = [None] * self.depth
+        self.range_fallbacks = 0
         with torch.no_grad():
             head_fn(backbone_fn(self.static_in[0]))   # packs weights, sizes every workspace, warms up
             torch.cuda.synchronize(dev)               # (also: the shared lanes are idle before a capture)
@@ -117,6 +140,11 @@ class GraphedForward:
                 # touch the HIP runtime while this thread captures
                 with torch.cuda.graph(gb, capture_error_mode="thread_local", **kw):
                     feat = backbone_fn(self.static_in[j])
+                flag = self.guard.last_range_flag() if self.guard is not None else None
+                if flag is not None:
+                    self.flag_dev[j] = flag
+                    self.flag_host[j] = torch.zeros(1, dtype=torch.int32).pin_memory()
+                    self._keep.append(flag)
                 gh = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gh, capture_error_mode="thread_local", **kw):
                     out = head_fn(feat)
@@ -125,7 +153,29 @@ class GraphedForward:
                 self.out.append(out)
                 self._keep += [feat, out]
             self._keep += ops.workspaces_snapshot()   # scratch the graphs recorded pointers into
+            if keep is not None:
+                self._keep += _tensors_in(keep())     # packed weights the graphs recorded pointers into
             torch.cuda.synchronize(dev)
+
+    def _settle(self, j: int) -> None:
+        """Check the range flag of the batch slot j ran last; recompute the batch in bf16x3 if it is set."""
+        if not self.unsettled[j]:
+            return
+        self.unsettled[j] = False
+        dest, self.pending_dest[j] = self.pending_dest[j], None
+        if self.flag_dev[j] is None:
+            return
+        self.done[j].synchronize()
+        if int(self.flag_host[j][0]) == 0:
+            return
+        self.range_fallbacks += 1
+        lane = self.lanes[j] if self.pipeline else torch.cuda.current_stream(self.device)
+        with torch.no_grad(), torch.cuda.stream(lane):
+            out = self.head_fn(self.guard.features_fallback(self.static_in[j]))
+            self.out[j].copy_(out)
+            if dest is not None:
+                dest.copy_(out)
+            self.done[j].record(lane)
 
     @property
     def shape(self):
@@ -135,6 +185,7 @@ class GraphedForward:
                  dest: Optional[torch.Tensor] = None) -> torch.Tensor:
         j = self.calls % self.depth
         self.calls += 1
+        self._settle(j)
         main = torch.cuda.current_stream(self.device)
         if x is not None and (x.shape != self.static_in[j].shape or x.dtype != self.static_in[j].dtype):
             raise ValueError(f"graphed forward was captured for {tuple(self.static_in[j].shape)} "
@@ -148,9 +199,15 @@ class GraphedForward:
             self.g_backbone[j].replay()
             if events is not None:
                 events[1].record()
+            if self.flag_dev[j] is not None:
+                self.flag_host[j].copy_(self.flag_dev[j], non_blocking=True)
             self.g_head[j].replay()
             if dest is not None:
                 dest.copy_(self.out[j], non_blocking=True)
+            if self.flag_dev[j] is not None:      # one lane: the result is final when the call returns
+                self.done[j].record(main)
+                self.unsettled[j], self.pending_dest[j] = True, dest
+                self._settle(j)
             return self.out[j]
         lane = self.lanes[j]
         if x is not None:
@@ -178,18 +235,38 @@ class GraphedForward:
             self.bb_done[j].record(lane)
             if events is not None:
                 events[1].record(lane)
+            if self.flag_dev[j] is not None:
+                self.flag_host[j].copy_(self.flag_dev[j], non_blocking=True)
             self.g_head[j].replay()
             if dest is not None:
                 dest.copy_(self.out[j], non_blocking=True)
             self.done[j].record(lane)
+        self.unsettled[j], self.pending_dest[j] = True, dest
         return self.out[j]
 
     def wait(self) -> None:
-        """Make the current stream wait for every batch (and hand-off copy) launched so far."""
+        """Make the current stream wait for every batch (and hand-off copy) launched so far.  With the f16mx
+        range guard this first checks the flags of the batches in flight (the host waits for them)."""
+        for j in range(self.depth):
+            self._settle(j)
         if self.pipeline:
             main = torch.cuda.current_stream(self.device)
             for ev in self.done:
                 main.wait_event(ev)
+
+
+def _tensors_in(obj, out=None):
+    """Every tensor reachable through nested dicts / lists / tuples."""
+    out = [] if out is None else out
+    if torch.is_tensor(obj):
+        out.append(obj)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _tensors_in(v, out)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _tensors_in(v, out)
+    return out
 
 
 # ---------------------------------------------------------------------------------------------
@@ -247,28 +324,53 @@ class _PinnedStage:
         self.done[j] = ev
 
 
+# model -> (state key, OrderedDict of captured forwards).  Outside the modules (a module holding CUDAGraph /
+# Stream / Event objects could no longer be deep-copied or pickled), weakly keyed: the graphs go with the model.
+_GRAPH_STORES: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+def release_graphs(model=None) -> None:
+    """Drop the captured forwards kept for `model` between extract_descriptors calls (all models: None).
+    Each captured batch shape owns static inputs, two graph memory pools and its activation workspaces —
+    2.5-5 GB for 32 x 480 x 640 — until it is evicted (MAX_CACHED_SHAPES), the model's state changes or
+    this is called."""
+    if model is None:
+        _GRAPH_STORES.clear()
+    else:
+        _GRAPH_STORES.pop(unwrap_model(model), None)
+
+
 def _graph_store(core, pca, vlad, store_dtype, dev) -> "OrderedDict":
-    """The captured forwards of `core`, kept ON the module between extract_descriptors calls (a capture is a
-    device sync, an eager warm-up and four graph captures: ~30 ms, 5 % of a 48-batch extraction).  They are
-    valid for exactly the state they were captured in — every parameter / buffer (storage and version
-    counter), the precision of every module, the small-batch threshold, the PCA object and its parameters,
-    the head's options, the device; anything else empties the store.  (A graph holds pointers into the packed
-    weights of that state; the modules' own caches re-pack on the same fingerprint.)"""
+    """The captured forwards of `core`, kept between extract_descriptors calls (a capture is a device sync,
+    an eager warm-up and four graph captures: ~30 ms, 5 % of a 48-batch extraction).  They are valid for
+    exactly the state they were captured in — every parameter / buffer (storage and version counter), the
+    precision AND THE CACHE GENERATION of every module (`set_precision()`, `invalidate()` and
+    `load_state_dict` bump it: they free the packed weights a graph points into, and `p.data.copy_()` +
+    `invalidate()` changes weights without a version bump), the small-batch threshold, the PCA object and
+    its parameters, the head's options, the device; anything else empties the store.  Every GraphedForward
+    additionally keeps the packed tensors it captured referenced (`keep=`)."""
     def tensors_of(obj):
         return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in obj if torch.is_tensor(t))
     state = (
         tensors_of(list(core.parameters()) + list(core.buffers())),
-        tuple(getattr(m, "precision", None) for m in core.modules()),
+        tuple((getattr(m, "precision", None), getattr(m, "_cache_gen", 0)) for m in core.modules()),
         getattr(getattr(core, "base_model", None), "F16MX_MIN_TILES", None),
         None if pca is None else (id(pca), getattr(pca, "precision", None),
                                   tensors_of([getattr(pca, "weight", None), getattr(pca, "bias", None)])),
         bool(vlad), str(store_dtype), str(dev),
     )
-    store = core.__dict__.get("_oibl_graph_store")
+    store = _GRAPH_STORES.get(core)
     if store is None or store[0] != state:
         store = (state, OrderedDict())
-        core.__dict__["_oibl_graph_store"] = store
+        _GRAPH_STORES[core] = store
     return store[1]
+
+
+def _module_caches(core, pca=None):
+    """The packed / cast parameter copies of a model's modules (what captured kernels point into)."""
+    def collect():
+        return [getattr(m, "_cache", None) for m in core.modules()] + [getattr(pca, "_cache", None)]
+    return collect
 
 
 def extract_descriptors(model, data_loader, vlad=True, pca=None, gpu=None, print_freq=10, rank=0,
@@ -318,7 +420,7 @@ def extract_descriptors(model, data_loader, vlad=True, pca=None, gpu=None, print
                     last_fwd.wait()
                 main.synchronize()            # capture starts from an idle device
                 ex = imgs.to(dev, non_blocking=False)
-                fwd = GraphedForward(backbone, head, ex, pipeline=True)
+                fwd = GraphedForward(backbone, head, ex, pipeline=True, keep=_module_caches(core, pca))
                 graphs[key] = fwd
                 while len(graphs) > MAX_CACHED_SHAPES:
                     # a loader cycling through more shapes than are kept would re-capture (a device

@@ -26,6 +26,8 @@ SIGNATURES = {
     "oibl_pack_conv3x3_weights": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "oibl_conv3x3_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                   c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "oibl_conv3x3_nhwc_flagged": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                          c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "oibl_conv1_1_nchw": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
                                   c_void_p, c_void_p]),
     "oibl_global_maxpool_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -73,6 +75,7 @@ SIGNATURES = {
     "oibl_x3_split_rows": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "oibl_x3_join_rows": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "oibl_mx_split_rows": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "oibl_mx_split_rows_flagged": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_void_p]),
     "oibl_mx_join_rows": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "oibl_match_operand_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "oibl_match_prepare": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
@@ -118,7 +121,7 @@ _HOOKS = {"oibl_debug_set_regstage": (c_int, [c_int]),
           "oibl_debug_set_netvlad_slabs": (c_int, [c_int]),
           "oibl_debug_set_prof_buffer": (c_int, [c_void_p])}
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class OpenIBLAmdError(RuntimeError):

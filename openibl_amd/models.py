@@ -46,8 +46,14 @@ class _PrecisionMixin:
         for m in self.modules():
             if isinstance(m, _PrecisionMixin):
                 m._precision = precision.lower()
-                m._cache = {}
+                m._drop_cache()
         return self
+
+    def _drop_cache(self):
+        """Forget the packed / cast parameter copies and advance the cache generation: captured forwards
+        kept for the model (extract._graph_store) point into those copies and are keyed on the generation."""
+        self._cache = {}
+        self._cache_gen = getattr(self, "_cache_gen", 0) + 1
 
     @property
     def precision(self) -> str:
@@ -62,7 +68,7 @@ class _PrecisionMixin:
         its copies at capture time and has to be re-created."""
         for m in self.modules():
             if isinstance(m, _PrecisionMixin):
-                m._cache = {}
+                m._drop_cache()
         return self
 
     def _hook_state_dict_loads(self):
@@ -102,6 +108,8 @@ class VGG(_PrecisionMixin, nn.Module):
         self.base = nn.Sequential(*layers[:-2])   # drop the last ReLU and max-pool (vgg.py:41-42)
         self.gap = nn.AdaptiveMaxPool2d(1)
         self._cache: Dict = {}
+        self.range_fallbacks = 0           # batches recomputed in bf16x3 because f16mx met a value beyond fp16
+        self.precision_runs: Dict = {}     # effective precision -> backbone passes run in it
         self._hook_state_dict_loads()
         self._init_params()
         if not pretrained:
@@ -146,7 +154,11 @@ class VGG(_PrecisionMixin, nn.Module):
         n = int(x.shape[0])
         h, w = (int(x.shape[1]), int(x.shape[2])) if x.dtype == torch.uint8 else (int(x.shape[2]), int(x.shape[3]))
         tiles = -(-(n * (h // 8) * (w // 8)) // 256) * 2
-        if n * 3 * h * w * 4 >= 0xE0000000:      # beyond the fused stem's 32-bit offsets: f16mx has no other front
+        # f16mx kernels address their input through 32-bit buffer offsets and have no other implementation:
+        # the largest activation they read — conv2_2's input, [N][H/2][W/2][128] 4-byte elements (39 MB per
+        # 480x640 image: 95 images) — must stay below 3.5 GB, like the stem's fp32 input (vgg16_f16mx_fits in
+        # csrc/conv.hip is the same test; the C entry point refuses what this lets through)
+        if n * 3 * h * w * 4 >= 0xE0000000 or n * (h // 2) * (w // 2) * 128 * 4 >= 0xE0000000:
             return "bf16x3"
         return p if tiles >= self.F16MX_MIN_TILES else "bf16x3"
 
@@ -171,13 +183,44 @@ class VGG(_PrecisionMixin, nn.Module):
     def features_nhwc(self, x: torch.Tensor) -> torch.Tensor:
         """[N][3][H][W] fp32 (normalised) or [N][H][W][3] uint8 (raw image; the loader's
         ToTensor + Normalize run inside the first kernel) -> conv5_3 map [N][h][w][512] in the
-        precision's element type."""
+        precision's element type.
+
+        f16mx range guard: the fp16 main term of f16mx exists only for |activation| <= 65504.  The kernels
+        raise a device flag when a layer's output is beyond that (include/openibl_amd.h, OIBL_F16MX); it is
+        read here — one 4-byte copy per batch — and a flagged batch is recomputed in bf16x3, the other mode
+        inside the 1e-4 tolerance, which has no range limit (`range_fallbacks` counts them).  Under a
+        hipGraph capture nothing can be read: the capturer takes `last_range_flag()` and checks it after
+        every replay (extract.GraphedForward does)."""
         if x.dtype != torch.uint8 and x.dtype != torch.float32:
             x = x.float()
         x = x.contiguous()
         prec = self.effective_precision(x)
         ws, bs = self._packed(x.device, prec)
-        return ops.vgg16_conv5(x, ws, bs, prec, events=getattr(self, "profile_events", None))
+        ev = getattr(self, "profile_events", None)
+        self.precision_runs[prec] = self.precision_runs.get(prec, 0) + 1
+        if ops.precision_code(prec) != ops.F16MX:
+            self._range_flag = None
+            return ops.vgg16_conv5(x, ws, bs, prec, events=ev)
+        feat, flag = ops.vgg16_conv5(x, ws, bs, prec, events=ev, return_flag=True)
+        self._range_flag = flag
+        if torch.cuda.is_current_stream_capturing():
+            return feat
+        if int(flag.item()) != 0:
+            self.range_fallbacks += 1
+            feat = self.features_fallback(x)
+        return feat
+
+    def last_range_flag(self) -> Optional[torch.Tensor]:
+        """The f16mx range flag of the last `features_nhwc` call (int32 [1] view of the first word of that
+        stream's backbone workspace, rewritten by every later pass on the stream), None if that call did not
+        run in f16mx."""
+        return getattr(self, "_range_flag", None)
+
+    def features_fallback(self, x: torch.Tensor) -> torch.Tensor:
+        """The conv5_3 map of a batch whose f16mx pass raised the range flag: the same network in bf16x3."""
+        ws, bs = self._packed(x.device, "bf16x3")
+        self.precision_runs["bf16x3(range)"] = self.precision_runs.get("bf16x3(range)", 0) + 1
+        return ops.vgg16_conv5(x.contiguous(), ws, bs, "bf16x3")
 
     @torch.no_grad()
     def forward(self, x):
@@ -303,9 +346,9 @@ def GraphedDescriptor(model: "EmbedNetPCA", example: torch.Tensor, pipeline: boo
     a second stream while the backbone of batch i+1 already occupies the matrix cores; a batch passed
     to the call travels on a third (copy) stream.  The tensor returned by call i is then complete
     once `fwd.wait()` (or a device synchronisation) has returned, and is overwritten by call i+2."""
-    from .extract import GraphedForward
+    from .extract import GraphedForward, _module_caches
     return GraphedForward(model.base_model.features_nhwc, model.head_from_features, example,
-                          pipeline=pipeline)
+                          pipeline=pipeline, keep=_module_caches(model))
 
 
 class EmbedRegionNet(_PrecisionMixin, nn.Module):

@@ -135,16 +135,23 @@ def x3_split(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def mx_split(x: torch.Tensor) -> torch.Tensor:
+def new_range_flag(dev: torch.device) -> torch.Tensor:
+    """A cleared f16mx range flag (int32 [1] on the device): producers of f16mx lines set it to 1 when they
+    meet a value beyond fp16 (|v| > 65504), see include/openibl_amd.h, OIBL_F16MX."""
+    return torch.zeros(1, dtype=torch.int32, device=dev)
+
+
+def mx_split(x: torch.Tensor, range_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
     """float32 [..., C] (C % 32 == 0) -> the f16mx operand layout (int32 container, same shape): per 32
-    elements one 128-byte line [32 fp16 | e2m3 images of hi and lo + their scale bytes]."""
-    dev = _need_cuda(x)
+    elements one 128-byte line [32 fp16 | e2m3 images of hi and lo + their scale bytes].  range_flag: optional
+    int32 [1] device tensor, set to 1 when a value is beyond fp16."""
+    dev = _need_cuda(x, range_flag)
     if x.dtype != torch.float32 or x.shape[-1] % 32 != 0:
         raise ValueError("mx_split expects a float32 tensor whose last dimension is a multiple of 32")
     C_ = int(x.shape[-1])
     out = torch.empty(x.shape, dtype=torch.int32, device=dev)
-    _lib.check(_lib.load().oibl_mx_split_rows(_ptr(x), _ptr(out), x.numel() // C_, C_, _stream(dev)),
-               "mx_split_rows")
+    _lib.check(_lib.load().oibl_mx_split_rows_flagged(_ptr(x), _ptr(out), x.numel() // C_, C_, _ptr(range_flag),
+                                                      _stream(dev)), "mx_split_rows")
     return out
 
 
@@ -234,10 +241,11 @@ def pack_conv3x3(w: torch.Tensor, precision) -> torch.Tensor:
 
 
 def conv3x3_nhwc(x: torch.Tensor, packed_w: torch.Tensor, bias: torch.Tensor, relu: bool,
-                 pool: bool, precision) -> torch.Tensor:
-    """x [N][H][W][Cin] T -> [N][Ho][Wo][Cout] T (conv3x3 pad 1 + bias (+ReLU) (+2x2 max-pool))."""
+                 pool: bool, precision, range_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [N][H][W][Cin] T -> [N][Ho][Wo][Cout] T (conv3x3 pad 1 + bias (+ReLU) (+2x2 max-pool)).
+    range_flag (f16mx): optional int32 [1] device tensor, set to 1 when an output is beyond fp16."""
     p = precision_code(precision)
-    dev = _need_cuda(x, packed_w, bias)
+    dev = _need_cuda(x, packed_w, bias, range_flag)
     if x.dtype != _DTYPES[p] or packed_w.dtype != _DTYPES[p] or bias.dtype != torch.float32:
         raise ValueError("conv3x3_nhwc: dtype mismatch with precision")
     N, H, W, cin = map(int, x.shape)
@@ -246,9 +254,9 @@ def conv3x3_nhwc(x: torch.Tensor, packed_w: torch.Tensor, bias: torch.Tensor, re
         raise ValueError("conv3x3_nhwc: packed weight Cin mismatch")
     Ho, Wo = (H // 2, W // 2) if pool else (H, W)
     out = torch.empty((N, Ho, Wo, cout), dtype=_DTYPES[p], device=dev)
-    _lib.check(_lib.load().oibl_conv3x3_nhwc(_ptr(x), N, H, W, cin, _ptr(packed_w), _ptr(bias),
-                                             cout, int(relu), int(pool), p, _ptr(out),
-                                             _stream(dev)), "conv3x3_nhwc")
+    _lib.check(_lib.load().oibl_conv3x3_nhwc_flagged(_ptr(x), N, H, W, cin, _ptr(packed_w), _ptr(bias),
+                                                     cout, int(relu), int(pool), p, _ptr(out),
+                                                     _ptr(range_flag), _stream(dev)), "conv3x3_nhwc")
     return out
 
 
@@ -332,7 +340,7 @@ REF_STD = (0.00392156862745098, 0.00392156862745098, 0.00392156862745098)
 
 
 def vgg16_conv5(x: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor],
-                precision, events=None, mean=REF_MEAN, std=REF_STD) -> torch.Tensor:
+                precision, events=None, mean=REF_MEAN, std=REF_STD, return_flag: bool = False):
     """conv5_3 feature map [N][h][w][512] T (NHWC), h = H//16, w = W//16, of
       x [N][3][H][W] float32, already normalised (what the reference's loader hands over), or
       x [N][H][W][3] uint8, the raw decoded image: ToTensor + Normalize(mean, std) are folded into
@@ -340,7 +348,10 @@ def vgg16_conv5(x: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequen
 
     weights[0] is the plain conv1_1 tensor, weights[1:] come from pack_conv3x3.
     `events`: optional pair of already-recorded torch.cuda.Event(enable_timing=True); they are
-    re-recorded right before / after the matrix-core convolutions (bench.py's roofline)."""
+    re-recorded right before / after the matrix-core convolutions (bench.py's roofline).
+    return_flag: also return the pass's f16mx range flag — an int32 [1] VIEW of the first word of this
+    stream's backbone workspace (None in the other precisions): non-zero once the pass has run = an
+    activation was beyond fp16 and `feat` must be recomputed in bf16x3 (models.VGG does)."""
     p = precision_code(precision)
     dev = _need_cuda(x, *weights, *biases)
     u8 = x.dtype == torch.uint8
@@ -378,6 +389,8 @@ def vgg16_conv5(x: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequen
         _lib.check(lib.oibl_vgg16_conv5_forward_ev(_ptr(x), N, H, W, wp, bp, p, _ptr(feat), _ptr(ws),
                                                    ws.numel(), _stream(dev), ev0, ev1),
                    "vgg16_conv5_forward")
+    if return_flag:
+        return feat, (ws[:4].view(torch.int32) if p == F16MX else None)
     return feat
 
 

@@ -34,16 +34,45 @@ def _normal(rng: np.random.Generator, shape, std: float) -> torch.Tensor:
     return torch.from_numpy(rng.standard_normal(shape, dtype=np.float32) * np.float32(std))
 
 
-def backbone_state(seed: int = 0, prefix: str = "base_model.base.") -> "OrderedDict[str, torch.Tensor]":
+def backbone_state(seed: int = 0, prefix: str = "base_model.base.", trained_like: bool = False,
+                   gain: float = 30.0) -> "OrderedDict[str, torch.Tensor]":
     """conv weights ~ N(0, sqrt(2 / fan_out)) like VGG.reset_params (vgg.py:72-77); biases are
     small non-zero values (the reference zero-fills them, which would leave the bias path of the
-    kernels untested)."""
+    kernels untested).
+
+    trained_like=True: the same draw reshaped towards what a trained MatConvNet VGG16 looks like to the
+    arithmetic on 0-255-scale pixels (ibl/utils/data/__init__.py:40-41) — the released checkpoint cannot be
+    fetched here.  Per OUTPUT channel a log-normal gain (sigma 0.5: the channel norms of a trained layer
+    spread over an order of magnitude), 3 % dead channels (zero filter, negative bias: always off behind the
+    ReLU), per INPUT channel a milder log-normal gain (sigma 0.25), every layer re-normalised to its original
+    Frobenius norm so that the signal neither dies nor explodes with depth, and conv1_1 scaled by `gain`
+    (biases of all layers with it: the network is positively homogeneous) so that the activations behind
+    conv1_2 peak in the thousands instead of at ~100.  A separate random stream: the default draw (the
+    goldens' weights) is unchanged."""
     rng = np.random.default_rng([seed, 1])
     sd = OrderedDict()
     for idx, (cin, cout) in zip(CONV_IDX, CONV_CH):
         std = math.sqrt(2.0 / (cout * 9))
         sd[f"{prefix}{idx}.weight"] = _normal(rng, (cout, cin, 3, 3), std)
         sd[f"{prefix}{idx}.bias"] = _normal(rng, (cout,), 0.05)
+    if not trained_like:
+        return sd
+    rng2 = np.random.default_rng([seed, 11])
+    for li, (idx, (cin, cout)) in enumerate(zip(CONV_IDX, CONV_CH)):
+        w, b = sd[f"{prefix}{idx}.weight"], sd[f"{prefix}{idx}.bias"]
+        frob = float(w.norm())
+        go = torch.from_numpy(np.exp(rng2.normal(0.0, 0.5, size=cout)).astype(np.float32))
+        gi = torch.from_numpy(np.exp(rng2.normal(0.0, 0.25, size=cin)).astype(np.float32))
+        dead = torch.from_numpy(rng2.uniform(size=cout) < (0.03 if li < 12 else 0.0))
+        w = w * go[:, None, None, None] * gi[None, :, None, None]
+        w[dead] = 0.0
+        w = w * (frob / float(w.norm()))
+        b = b * go
+        b[dead] = -0.1
+        if li == 0:
+            w = w * gain
+        sd[f"{prefix}{idx}.weight"] = w.contiguous()
+        sd[f"{prefix}{idx}.bias"] = (b * gain).contiguous()
     return sd
 
 
@@ -71,9 +100,9 @@ def pca_state(seed: int = 0, prefix: str = "pca_layer.", dim: int = PCA_DIM
     return sd
 
 
-def embednetpca_state(seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+def embednetpca_state(seed: int = 0, trained_like: bool = False) -> "OrderedDict[str, torch.Tensor]":
     """Full state dict of the reference's EmbedNetPCA (30 tensors, 149 002 048 parameters)."""
-    sd = backbone_state(seed)
+    sd = backbone_state(seed, trained_like=trained_like)
     sd.update(netvlad_state(seed))
     sd.update(pca_state(seed))
     return sd

@@ -266,7 +266,7 @@ def test_configs1_batch32_480x640_against_oracle(dev, state_dict, precision, tol
     worst = max(rel_l2(got[i].cpu(), want[i]) for i in range(32))
     worst_abs = float(((got.cpu().double() - want.double()).abs().amax(1) / want.double().abs().amax(1)).max())
     print(f"{precision}: worst single-image rel-L2 {worst:.3e}, worst max|diff| / max|want| {worst_abs:.3e}")
-    assert worst < 2 * tol and worst_abs < 2 * tol
+    assert worst < tol and worst_abs < tol          # north_star's bound holds for EVERY image, not on average
     if precision == "f16mx":
         assert model.base_model.effective_precision(xd) == "f16mx"     # the benchmark batch runs the MX kernels
     fwd = model.graphed(xd, pipeline=True)
@@ -342,7 +342,7 @@ def test_captured_forwards_survive_between_extractions_and_die_with_their_state(
     changes: a parameter written in place, the precision, the head's options."""
     import hubconf
     from openibl_amd import evaluators as ev
-    from openibl_amd.extract import unwrap_model
+    from openibl_amd.extract import unwrap_model, _GRAPH_STORES, release_graphs
     model = hubconf.vgg16_netvlad(pretrained=False)
     model.load_state_dict(state_dict)
     model = model.to(dev).eval().set_precision("bf16x3")
@@ -369,21 +369,39 @@ def test_captured_forwards_survive_between_extractions_and_die_with_their_state(
         assert torch.equal(torch.stack(list(feats.values())), eager)
 
     run(700)
-    store = core.__dict__["_oibl_graph_store"]
+    store = _GRAPH_STORES[core]
     assert len(store[1]) == 1
     fwd = next(iter(store[1].values()))
     calls = fwd.calls
     run(800)                                            # other images, same shape: all four batches replayed
-    assert core.__dict__["_oibl_graph_store"] is store and next(iter(store[1].values())) is fwd
+    assert _GRAPH_STORES[core] is store and next(iter(store[1].values())) is fwd
     assert fwd.calls == calls + 4
     run(900, store_dtype=torch.float16)                 # another head: another store
-    assert core.__dict__["_oibl_graph_store"] is not store
-    store = core.__dict__["_oibl_graph_store"]
+    assert _GRAPH_STORES[core] is not store
+    store = _GRAPH_STORES[core]
     with torch.no_grad():
         core.net_vlad.centroids.mul_(1.0)               # written in place: the version counter moves
     run(1000, store_dtype=torch.float16)
-    assert core.__dict__["_oibl_graph_store"] is not store
-    store = core.__dict__["_oibl_graph_store"]
+    assert _GRAPH_STORES[core] is not store
+    store = _GRAPH_STORES[core]
     model.set_precision("fp32")
     run(1100, store_dtype=torch.float16)
-    assert core.__dict__["_oibl_graph_store"] is not store
+    assert _GRAPH_STORES[core] is not store
+    # a precision ROUND TRIP with no extraction in between frees the packed weights the kept
+    # graphs point into although every key component but the cache generation is back to its old value
+    store = _GRAPH_STORES[core]
+    model.set_precision("bf16")
+    model.set_precision("fp32")
+    run(1200, store_dtype=torch.float16)
+    assert _GRAPH_STORES[core] is not store
+    # ... and p.data.copy_() + invalidate() (the documented idiom) changes weights without a version bump
+    store = _GRAPH_STORES[core]
+    core.net_vlad.centroids.data.copy_(core.net_vlad.centroids.data * 1.5)
+    model.invalidate()
+    run(1300, store_dtype=torch.float16)                # (compares against the eager forward of the NEW weights)
+    assert _GRAPH_STORES[core] is not store
+    # the model stays copyable / picklable with captured forwards around, and they can be released
+    import copy
+    copy.deepcopy(core.net_vlad)
+    release_graphs(model)
+    assert core not in _GRAPH_STORES

@@ -26,6 +26,24 @@ def test_store_follows_the_state_it_was_captured_in():
     assert d is not c
     core.base_model.F16MX_MIN_TILES = 0
     assert _graph_store(core, None, True, None, dev) is not d
+    # a precision round trip / invalidate(): same parameters, same precisions — but the packed weights the
+    # graphs point into were dropped in between (cache generation)
+    f = _graph_store(core, None, True, None, dev)
+    model.set_precision("bf16")
+    model.set_precision("bf16x3")
+    g = _graph_store(core, None, True, None, dev)
+    assert g is not f
+    model.invalidate()
+    assert _graph_store(core, None, True, None, dev) is not g
+    h = _graph_store(core, None, True, None, dev)
+    core.base_model.set_precision("bf16x3")              # on a CHILD: the parent's store must notice
+    assert _graph_store(core, None, True, None, dev) is not h
+    import copy, pickle
+    copy.deepcopy(model)                                   # the store lives outside the modules
+    pickle.dumps(model.state_dict())
+    from openibl_amd.extract import release_graphs, _GRAPH_STORES
+    release_graphs(model)
+    assert core not in _GRAPH_STORES
 
     class FakePCA:
         precision = "fp32"
