@@ -685,7 +685,10 @@ OIBL_HOOK(int, g_ring_ablate, 0);                     // test hook: see RingPara
 
 // ring-schedule kernel (conv_ring.h): bf16, Cin % 64 == 0; WM = 2: 256 x 256 tile (Cout % 256 == 0),
 // WM = 4: 512 x 128 tile (Cout % 128 == 0)
-template <int WM, bool POOL, bool ODD, int P = RING_BF16, bool OUTMX = (P >= RING_MX)>
+// BAR1: the one-barrier-per-phase schedule (ring_core.h).  g_ring_bar1 (test hook): 0 = two barriers per
+// phase (rounds 1-3), 1 = one.
+OIBL_HOOK(int, g_ring_bar1, 1);
+template <int WM, bool POOL, bool ODD, int P = RING_BF16, bool OUTMX = (P >= RING_MX), bool BAR1 = false>
 static int launch_conv_ring_impl(const ConvParams& p, hipStream_t st) {
   using G = RingGeo<WM>;
   constexpr bool X3 = P != RING_BF16;  // 4-byte elements
@@ -720,7 +723,7 @@ static int launch_conv_ring_impl(const ConvParams& p, hipStream_t st) {
   q.korder = p.korder;
   q.range_flag = p.range_flag;
   constexpr int lds = ring_lds_bytes<WM, POOL, P, OUTMX>();
-  auto kern = conv3x3_ring_kernel<WM, POOL, ODD, P, OUTMX>;
+  auto kern = conv3x3_ring_kernel<WM, POOL, ODD, P, OUTMX, BAR1>;
   OIBL_SET_MAX_LDS(kern, lds);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, q);
   OIBL_LAUNCH_CHECK();
@@ -732,7 +735,12 @@ static int launch_conv_ring(const ConvParams& p, hipStream_t st) {
   // an odd number of K-tiles happens only for Cin = 64 in bf16 (the 4-byte element types have twice
   // the K-tiles), which only the 512 x 128 variant serves
   if constexpr (WM == 4 && P == RING_BF16) {
-    if ((9 * (p.cin / 64)) & 1) return launch_conv_ring_impl<WM, POOL, true>(p, st);
+    if ((9 * (p.cin / 64)) & 1)
+      return g_ring_bar1 ? launch_conv_ring_impl<WM, POOL, true, P, false, true>(p, st)
+                         : launch_conv_ring_impl<WM, POOL, true>(p, st);
+  }
+  if constexpr (P == RING_BF16 || P == RING_X3 || P == RING_MX_EARLY) {
+    if (g_ring_bar1) return launch_conv_ring_impl<WM, POOL, false, P, (P >= RING_MX), true>(p, st);
   }
   return launch_conv_ring_impl<WM, POOL, false, P>(p, st);
 }
@@ -889,6 +897,10 @@ static int launch_conv_halo(const ConvParams& p, hipStream_t st) {
   const dim3 grid((unsigned)(tiles_m * q.tiles_n));
   if (g_halo_var == 3) {
     auto kern = conv3x3_halo_kernel<POOL, RING_MX_EARLY, 3>;
+    OIBL_SET_MAX_LDS(kern, HALO_LDS);
+    hipLaunchKernelGGL(kern, grid, dim3(512), HALO_LDS, st, q);
+  } else if (g_ring_bar1) {
+    auto kern = conv3x3_halo_kernel<POOL, RING_MX_EARLY, 0, true>;
     OIBL_SET_MAX_LDS(kern, HALO_LDS);
     hipLaunchKernelGGL(kern, grid, dim3(512), HALO_LDS, st, q);
   } else {
@@ -2798,6 +2810,13 @@ int oibl_debug_set_mx_variant(int v) {
 #ifdef OIBL_DEBUG_HOOKS
 int oibl_debug_set_conv_korder(int mode) {
   g_conv_korder = mode < 0 ? -1 : (mode ? 1 : 0);
+  return OIBL_OK;
+}
+#endif
+
+#ifdef OIBL_DEBUG_HOOKS
+int oibl_debug_set_ring_bar1(int on) {
+  g_ring_bar1 = on ? 1 : 0;
   return OIBL_OK;
 }
 #endif

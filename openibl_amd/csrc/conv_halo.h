@@ -72,10 +72,11 @@ struct HaloParams {
 // one phase's matrix work on two 32x32 accumulator tiles (ring_core.h, compute)
 template <int P, bool SWAP, typename Prep>
 __device__ static inline void halo_phase_mma(f32x16_t& acc0, f32x16_t& acc1, const bf16x8_t (&fa)[2][4],
-                                             const bf16x8_t (&fb)[4], Prep&& prep) {
+                                             const bf16x8_t (&fb)[4], Prep&& prep, bool prio2 = false) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_setprio(1);
+  if (prio2) __builtin_amdgcn_s_setprio(2);   // (BAR1, group 0: ring_core.h)
+  else __builtin_amdgcn_s_setprio(1);
   if constexpr (P >= RING_MX) {
     typedef __attribute__((ext_vector_type(4))) int i4;
     auto f16 = [&](f32x16_t& acc, int i2, int k) __attribute__((always_inline)) {
@@ -122,7 +123,8 @@ __device__ static inline void halo_phase_mma(f32x16_t& acc0, f32x16_t& acc1, con
 
 // VAR (experiments kept for tests/gpu_halo_determinism.py): 0 = production; 3 = the waits that count the
 // halo instructions as outstanding (vmcnt(6) / vmcnt(5)) with out-of-range dummies: rarely WRONG, see below.
-template <bool POOL, int P, int VAR = 0>
+// BAR1: one barrier per phase and wave (ring_core.h) — the same hazard distances hold here.
+template <bool POOL, int P, int VAR = 0, bool BAR1 = false>
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(HaloParams p) {
   using G = RingGeo<2>;
   constexpr bool MX = P >= RING_MX;
@@ -281,6 +283,16 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(HaloParams p) {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
+  auto bar_g = [&](int g) __attribute__((always_inline)) {   // (ring_core.h)
+    if constexpr (BAR1) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (group == g) __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      bar();
+    }
+  };
+  const bool prio2 = BAR1 && group == 0;
 
   // accumulators start at the bias (conv_ring.h)
   f32x16_t acc[4][2];
@@ -330,7 +342,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(HaloParams p) {
   bar();
   read_b(0, 0, fbx);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if (group == 1) bar();  // group 1 runs one barrier behind group 0
+  if constexpr (!BAR1) {
+    if (group == 1) bar();  // group 1 runs one barrier behind group 0
+  }
 
   // one K-tile = tap `TAP` of channel chunk cc (halo buffer hb); PAR = parity of the K-tile (weight buffer,
   // register set of B0); kt = its index
@@ -351,27 +365,27 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(HaloParams p) {
     // 8 of 270 launches; 0 of 270 with the waits below).  So the halo instructions are not counted — the
     // waits allow only the 2 x NB younger WEIGHT instructions in flight — and every dummy is an in-range load.
     wait_vmcnt<(VAR == 3 ? 1 + 2 * NB + 1 : 2 * NB)>();
-    bar();
-    halo_phase_mma<P, SWAP>(acc[0][0], acc[1][0], fa, b0, [&] { lb.begin_tile(); });  // (cursor -> K-tile t+2;
-    bar();                                      //  unconditional: advanced under a branch it ends up in a VGPR)
+    bar_g(0);
+    halo_phase_mma<P, SWAP>(acc[0][0], acc[1][0], fa, b0, [&] { lb.begin_tile(); }, prio2);  // (cursor -> K-tile
+    bar_g(1);                          // t+2; unconditional: advanced under a branch it ends up in a VGPR)
     // P1: A0 x B1
     read_b(PAR, 1, b1);
     stage_b(PAR, 0, more);  // B0(t+2)
-    bar();
-    halo_phase_mma<P, SWAP>(acc[0][1], acc[1][1], fa, b1, [] {});
-    bar();
+    bar_g(0);
+    halo_phase_mma<P, SWAP>(acc[0][1], acc[1][1], fa, b1, [] {}, prio2);
+    bar_g(1);
     // P2: A1 x B1
     read_a(hb, I1{}, tap_c);
     wait_vmcnt<(VAR == 3 ? 2 * NB + 1 : 2 * NB)>();
-    bar();
-    halo_phase_mma<P, SWAP>(acc[2][1], acc[3][1], fa, b1, [] {});
-    bar();
+    bar_g(0);
+    halo_phase_mma<P, SWAP>(acc[2][1], acc[3][1], fa, b1, [] {}, prio2);
+    bar_g(1);
     // P3: A1 x B0   (B0 of the next K-tile goes into the register set B1 just vacated)
     read_b(PAR ^ 1, 0, b1);
     stage_b(PAR, 1, more);  // B1(t+2)
-    bar();
-    halo_phase_mma<P, SWAP>(acc[2][0], acc[3][0], fa, b0, [] {});
-    bar();
+    bar_g(0);
+    halo_phase_mma<P, SWAP>(acc[2][0], acc[3][0], fa, b0, [] {}, prio2);
+    bar_g(1);
     (void)TAP;
   };
   // two chunks = 18 K-tiles per trip (nine taps each: the K-tile parity flips from chunk to chunk)
@@ -397,7 +411,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(HaloParams p) {
     ktile(I1{}, HALO_IC(8), 1, cc + 1, kt + 17);
   }
 #undef HALO_IC
-  if (group == 0) bar();
+  if constexpr (!BAR1) {
+    if (group == 0) bar();
+  }
   wait_vmcnt<0>();  // (sink writes of the last dummies)
   __syncthreads();
 

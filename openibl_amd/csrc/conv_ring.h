@@ -217,7 +217,7 @@ __device__ static inline void ring_split4(float a0, float a1, float a2, float a3
 // OUTMX: the output is written as f16mx lines (always with f16mx operands; the parameter exists because the
 // epilogue only depends on it: bf16x3 operands with f16mx output compile too — round 3 ran conv2_1 that way
 // until the stem itself became f16mx).
-template <int WM, bool POOL, bool ODD, int P = RING_BF16, bool OUTMX = (P >= RING_MX)>
+template <int WM, bool POOL, bool ODD, int P = RING_BF16, bool OUTMX = (P >= RING_MX), bool BAR1 = false>
 __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
   using G = RingGeo<WM>;
   constexpr int NA = G::NA, NB = G::NB;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
   }
 
   const unsigned long long t_loop = prof ? __builtin_amdgcn_s_memtime() : 0;
-  ring_mainloop<WM, ODD, !POOL, P>(acc, smem, wave, lane, la, lb, nsteps,
+  ring_mainloop<WM, ODD, !POOL, P, BAR1>(acc, smem, wave, lane, la, lb, nsteps,
                                    (P == RING_MX_PROF && blockIdx.x == 0 && p.prof) ? p.prof + 8 : nullptr);
   // (the main loop ends on a workgroup barrier: the staging LDS is free for the epilogue)
   const unsigned long long t_epi = prof ? __builtin_amdgcn_s_memtime() : 0;

@@ -228,7 +228,7 @@ struct PairRingParams {
   float thr_slack;
 };
 
-template <bool FILTER, int P = RING_BF16>
+template <bool FILTER, int P = RING_BF16, bool BAR1 = false>
 __global__ __launch_bounds__(512) void pairwise_ring_kernel(PairRingParams p) {
   using G = RingGeo<2>;
   constexpr bool X3 = P != RING_BF16;  // 4-byte operand elements, 32 K per K-tile (bf16x3 and f16mx)
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(512) void pairwise_ring_kernel(PairRingParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  ring_mainloop<2, false, false, P>(acc, smem, wave, lane, la, lb, d_part >> (X3 ? 5 : 6));
+  ring_mainloop<2, false, false, P, BAR1>(acc, smem, wave, lane, la, lb, d_part >> (X3 ? 5 : 6));
 
   // norms (and thresholds) of the tile's rows / columns -> LDS; out-of-range rows/columns are
   // clamped here and masked at the store
@@ -833,10 +833,15 @@ extern "C" {
 OIBL_HOOK(int, g_match_ring, 1);  // test hook: 0 = never, 1 = auto, 2 = whenever legal
 OIBL_HOOK(int, g_match_group, 4);  // test hook: query tiles per ordering group of the ring kernel
 OIBL_HOOK(int, g_match_splitk, 1);  // test hook: 0 = never split the threshold sample's contraction
+OIBL_HOOK(int, g_match_bar1, 1);    // test hook: 0 = two barriers per phase in the ring kernel (rounds 1-3), 1 = one
 
 #ifdef OIBL_DEBUG_HOOKS
 int oibl_debug_set_match_splitk(int on) {
   g_match_splitk = on ? 1 : 0;
+  return OIBL_OK;
+}
+int oibl_debug_set_match_bar1(int on) {
+  g_match_bar1 = on ? 1 : 0;
   return OIBL_OK;
 }
 #endif
@@ -907,9 +912,15 @@ static int launch_pairwise_ring(PairRingParams& p, hipStream_t st, int ksplit = 
   const long grid = (long)p.tiles_m * p.tiles_n;
   OIBL_REQUIRE(grid > 0 && grid <= 0x7fffffffL, "pairwise: grid out of range");
   constexpr int lds = RingGeo<2>::MAIN_LDS;
-  auto kern = pairwise_ring_kernel<FILTER, P>;
-  OIBL_SET_MAX_LDS(kern, lds);
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)ksplit), dim3(512), lds, st, p);
+  if (g_match_bar1) {   // one barrier per phase (ring_core.h, BAR1)
+    auto kern = pairwise_ring_kernel<FILTER, P, true>;
+    OIBL_SET_MAX_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)ksplit), dim3(512), lds, st, p);
+  } else {
+    auto kern = pairwise_ring_kernel<FILTER, P>;
+    OIBL_SET_MAX_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)ksplit), dim3(512), lds, st, p);
+  }
   OIBL_LAUNCH_CHECK();
   return OIBL_OK;
 }

@@ -20,6 +20,18 @@
 //     APART: while one wave of a SIMD is in its COMPUTE segment the other is in its LOAD segment,
 //     so the matrix pipe of the SIMD always has a wave with operands in registers (s_setprio 1
 //     around the MFMAs lets it win issue arbitration against the loading partner).
+//   * BAR1 (round 4): ONE barrier per phase and wave instead of two.  Every wave runs the same sequence
+//     L(0) C(0) L(1) C(1) ...; group 0 crosses its barrier between L(p) and C(p), group 1 between C(p) and
+//     L(p+1).  Barrier interval n then holds  group 0: C(n-1) L(n)   |   group 1: L(n) C(n)  — the two
+//     COMPUTE segments of a SIMD run back to back on its matrix pipe (group 0 at the higher priority: its
+//     LOAD is still to come), each LOAD segment in the shadow of the partner's COMPUTE, and the barrier
+//     latency + arrival skew is paid once per 2 x COMPUTE instead of once per COMPUTE (with 6 MFMAs =
+//     192 pipe cycles per f16mx phase the two-barrier interval measured 245-277 cycles).  Hazards, with
+//     intervals counted like phases: the fragment reads of phase r are retired by the lgkmcnt(0) in front
+//     of C(r): in interval r (group 1) or at the head of interval r+1 (group 0) — a unit re-staged in
+//     L(q), q >= r+2, is issued in interval >= r+2 by either group: WAR as before.  A wait in L(w) is
+//     followed by barrier w in both groups (directly in group 0, behind C(w) in group 1); the reads of
+//     L(w+1) come after barrier w in both: RAW as before (read >= 1 phase after the retiring wait).
 //
 // Hazard rules (cdna_hip_programming.md, "256^2 8-phase template"), with phases numbered globally:
 //   RAW  a unit is read in phase >= w + 1 where w is the phase whose LOAD segment holds the
@@ -162,7 +174,7 @@ struct RingRowLoader {
 // both cross terms: per 32x32 tile and K-tile 2 f16 MFMAs + 1 MX MFMA, 6 per phase, on the same LDS
 // traffic and with the same fragment addresses for both operands.
 // On return every wave has passed a workgroup barrier: the staging LDS is free.
-template <int WM, bool ODD, bool SWAP, int P = RING_BF16, typename LA, typename LB>
+template <int WM, bool ODD, bool SWAP, int P = RING_BF16, bool BAR1 = false, typename LA, typename LB>
 __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, int wave, int lane,
                                             LA& la, LB& lb, int nsteps, unsigned long long* stamps = nullptr) {
   using G = RingGeo<WM>;
@@ -246,7 +258,12 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
     constexpr int h = decltype(h_c)::value, j = decltype(j_c)::value;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
+    if constexpr (BAR1) {   // both groups compute inside one barrier interval: the one that still has to LOAD first
+      if (group == 0) __builtin_amdgcn_s_setprio(2);
+      else __builtin_amdgcn_s_setprio(1);
+    } else {
+      __builtin_amdgcn_s_setprio(1);
+    }
     auto mma = [&](int i2, int ka, int kb) __attribute__((always_inline)) {
       acc[2 * h + i2][j] =
           SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kb], fa[i2][ka], acc[2 * h + i2][j], 0, 0, 0)
@@ -308,6 +325,16 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
     if constexpr (P != RING_MX_NOBAR) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
+  // the barrier in front of (g = 0) / behind (g = 1) a COMPUTE segment: with BAR1 only group g crosses it
+  auto bar_g = [&](int g) __attribute__((always_inline)) {
+    if constexpr (BAR1) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (group == g) __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      bar();
+    }
+  };
 
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -332,7 +359,9 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
   bar();
   read_b(0, 0, fbx);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if (group == 1) bar();  // group 1 runs one barrier behind group 0
+  if constexpr (!BAR1) {
+    if (group == 1) bar();  // group 1 runs one barrier behind group 0
+  }
 
   // One K-tile = 4 phases.  PAR = tile parity (LDS buffer; which register set holds B0).
   // TAIL: 0 = steady state, 1 = tile nsteps-2, 2 = tile nsteps-1 (nothing left to stage).
@@ -361,16 +390,16 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
         if constexpr (SB >= 0) RING_STAMP(SB + 2);       // LDS-DMA issued
         if constexpr (CNT >= 0) wait_vmcnt<CNT>();
         if constexpr (SB >= 0) RING_STAMP(SB + 3);       // counted wait passed
-        bar();
+        bar_g(0);
         if constexpr (SB >= 0) RING_STAMP(SB + 4);       // barrier passed: COMPUTE starts
         compute(h_c, j_c, fb, prep);
         if constexpr (SB >= 0) RING_STAMP(SB + 5);       // MFMAs issued
       } else {
         if constexpr (CNT >= 0) wait_vmcnt<(CNT - NI)>();
-        bar();
+        bar_g(0);
         compute(h_c, j_c, fb, issue);
       }
-      bar();
+      bar_g(1);
       if constexpr (SB >= 0) RING_STAMP(SB + 6);         // closing barrier passed
     };
 #define RING_IC(x) std::integral_constant<int, (x)> {}
@@ -434,7 +463,9 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
     ktile(I0{}, I1{});
     ktile(I1{}, I2{});
   }
-  if (group == 0) bar();
+  if constexpr (!BAR1) {
+    if (group == 0) bar();
+  }
   __syncthreads();
   if constexpr (PROF) {
     if (stamps != nullptr && lane == 0 && (wave & 3) == 0) {
