@@ -306,14 +306,24 @@ def time_matching(c, precision, Q, G, msteps=10):
     gg = torch.Generator(device=dev).manual_seed(11 + c.rank)
     g = torch.nn.functional.normalize(torch.randn((n_valid, 4096), generator=gg, device=dev), dim=1)
     # the gallery shard is resident: its norms / operand rows are prepared once, like an index that
-    # serves many query batches; the queries are prepared inside every step
+    # serves many query batches.  The QUERIES enter every step the way they leave extraction: rank r holds
+    # the Q / W rows it extracted, prepares THOSE (norms + operand rows) and the prepared parts are
+    # all-gathered (north_star's all-gather; sharded.gather_prepared_queries) — inside the timed step.  The
+    # local top-k then runs in query blocks whose exchange + merge overlap the next block's matrix work.
     gp = ops.PreparedRows(g, precision)
+    qs, qper, _ = sharded.slice_bounds(Q, c.rank, c.world)
+    q_local = torch.stack([q[(qs + i) % Q] for i in range(qper)]) if c.world > 1 else q
+    blocks = 2 if c.world > 1 else 1
+
+    def step():
+        qp = sharded.gather_prepared_queries(q_local, Q, precision)
+        return sharded.sharded_topk(qp, gp, 10, start, precision, blocks=blocks)
     for _ in range(3):
-        sharded.sharded_topk(q, gp, 10, start, precision)
+        step()
     c.barrier()
     t0 = time.perf_counter()
     for _ in range(msteps):
-        vals, idx = sharded.sharded_topk(q, gp, 10, start, precision)
+        vals, idx = step()
     c.barrier()
     t1 = time.perf_counter()
     mt = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
@@ -325,7 +335,9 @@ def time_matching(c, precision, Q, G, msteps=10):
             "ms_per_step": float(mt.item()) / msteps * 1e3, "scaling": "strong",
             "tflops": round(pairs * 8192 / 1e12, 2),
             "config": {"workload": f"{Q} queries x {G} gallery x 4096-d squared-L2 + top-10, gallery sharded "
-                                   f"{c.world}-way and resident as prepared operands, top-k all_gather merge",
+                                   f"{c.world}-way and resident as prepared operands; per step: every rank prepares "
+                                   f"its Q/{c.world} queries, all_gather of the prepared queries, local top-k in "
+                                   f"{blocks} query block(s), top-k all_gather + merge",
                        "precision": precision}}
 
 

@@ -148,6 +148,15 @@ int oibl_conv3x3_nhwc(const void* in, int N, int H, int W, int cin, const void* 
 int oibl_conv3x3_nhwc_flagged(const void* in, int N, int H, int W, int cin, const void* packed_w,
                               const float* bias, int cout, int relu, int pool, int precision,
                               void* out, uint32_t* range_flag, void* stream);
+/* The same with scratch: a layer whose tiling would leave most of the chip idle — conv4 / conv5 of a few
+ * images — is then contracted split-K (several workgroups per output tile, fp32 partial tiles in `ws`, a
+ * fixed-order reduction that also applies bias / ReLU / pool: deterministic, equal to the one-pass result up
+ * to fp32 association), in every precision.  oibl_conv3x3_workspace_bytes may return 0 (ws may then be NULL).
+ * This is what oibl_vgg16_conv5_forward runs per layer. */
+size_t oibl_conv3x3_workspace_bytes(int N, int H, int W, int cin, int cout, int pool, int precision);
+int oibl_conv3x3_nhwc_ws(const void* in, int N, int H, int W, int cin, const void* packed_w,
+                         const float* bias, int cout, int relu, int pool, int precision, void* out,
+                         void* ws, size_t ws_bytes, uint32_t* range_flag, void* stream);
 
 /* First layer: reads the reference's input tensor directly — x [N][3][H][W] fp32 NCHW
  * (already mean/std normalised, ibl/utils/data/__init__.py:40-41) — conv1_1 + bias + ReLU,
@@ -229,10 +238,11 @@ int oibl_vgg16_stem_mx(const float* x_nchw, int N, int H, int W, const float* w1
  * 1 afterwards if any activation between the layers was beyond +-65504 — `feat` is then not a 1e-4 result
  * and the batch has to be repeated in OIBL_BF16X3 (see OIBL_F16MX at the top).  The other precisions leave
  * the word untouched.
- * The workspace holds the two ping-pong activation buffers and, for small batches, the fp32
- * partial tiles of the layers that run split-K (a layer whose 128-row tiling gives <= 192 tiles is
- * contracted by 2-8 workgroups per tile and reduced in a fixed order: deterministic, equal to
- * rounding with the one-pass kernels). */
+ * The workspace holds the range flag, the two ping-pong activation buffers and the fp32 partial tiles of
+ * the layers that run split-K: a layer whose tiling leaves most of the chip idle (small batches), and in
+ * OIBL_F16MX also the tiles of a nearly empty LAST ROUND of a big layer (conv5_x at batch 32: 300 tiles on
+ * 256 CUs), are contracted by several workgroups per tile and reduced in a fixed order — deterministic,
+ * equal to the one-pass kernels up to fp32 association. */
 size_t oibl_vgg16_workspace_bytes(int N, int H, int W, int precision);
 int oibl_vgg16_conv5_forward(const float* x_nchw, int N, int H, int W,
                              const void* const* packed_w_host,

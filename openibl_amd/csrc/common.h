@@ -249,12 +249,14 @@ __device__ static inline void mx_pack_line(const float (&v)[32], uint4 (&out)[8]
 // source instead of two half-used ones — these callers have no registers to give away).  lo is thereby
 // rounded twice (fp16, then e2m3; mx_pack_line converts it from fp32): a code can move by one step where
 // the fp16 rounding crosses an e2m3 midpoint — 2^-12 of a term that is itself 2^-11 of the product.
-// CLAMP = false: the caller guarantees |v| <= 65504 (the stems fold the bound into their ReLU); a group
-// maximum AT the bound then counts as out of range (a value clamped there, or — harmlessly — exactly 65504).
+// CLAMP = false: the caller guarantees |v| <= 65504 (the stems fold the bound into their ReLU).
+// Range guard: `seen` accumulates the largest group maximum the caller has packed (one v_max per call — no
+// branch, no memory operation: these callers count their own lgkmcnt / vmcnt waits, and a kernel-argument or
+// flag access inside their loops would disturb the counts); the caller raises the flag ONCE, behind its loops,
+// when seen > 65504 (CLAMP) / seen >= 65504 (!CLAMP: a value clamped to the bound, or — harmlessly — exactly it).
 template <bool CLAMP = true>
 __device__ static inline void mx_pack_half(const float (&v)[16], unsigned (&h16)[8], unsigned (&h6)[3],
-                                           unsigned (&l6)[3], unsigned& bh, unsigned& bl,
-                                           unsigned* range_flag = nullptr) {
+                                           unsigned (&l6)[3], unsigned& bh, unsigned& bl, float& seen) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef __attribute__((ext_vector_type(2))) float f2;
   typedef __attribute__((ext_vector_type(2))) _Float16 h2;
@@ -277,15 +279,11 @@ __device__ static inline void mx_pack_half(const float (&v)[16], unsigned (&h16)
   float c[16];
 #pragma unroll
   for (int e = 0; e < 16; ++e) c[e] = v[e];
+  seen = fmaxf(seen, amax);
   if constexpr (CLAMP) {
     if (__builtin_amdgcn_ballot_w64(amax > 65504.f) != 0) {   // wave-uniform, off the common path
 #pragma unroll
       for (int e = 0; e < 16; ++e) c[e] = __builtin_amdgcn_fmed3f(c[e], -65504.f, 65504.f);
-      if (amax > 65504.f) mx_raise_range_flag(range_flag);
-    }
-  } else {
-    if (__builtin_amdgcn_ballot_w64(amax >= 65504.f) != 0) {
-      if (amax >= 65504.f) mx_raise_range_flag(range_flag);
     }
   }
   u16v_ w_;   // dwords 0..7: hi pairs, 8..15: fp16(lo * 2^11) pairs

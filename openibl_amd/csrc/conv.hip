@@ -686,10 +686,22 @@ OIBL_HOOK(int, g_ring_ablate, 0);                     // test hook: see RingPara
 // ring-schedule kernel (conv_ring.h): bf16, Cin % 64 == 0; WM = 2: 256 x 256 tile (Cout % 256 == 0),
 // WM = 4: 512 x 128 tile (Cout % 128 == 0)
 // BAR1: the one-barrier-per-phase schedule (ring_core.h).  g_ring_bar1 (test hook): 0 = two barriers per
-// phase (rounds 1-3), 1 = one.
-OIBL_HOOK(int, g_ring_bar1, 1);
+// phase (the default), 1 = one.  Measured (profiles/r04_a_bar1_ab.txt): bit-identical, race-free, and 3-8 %
+// SLOWER on every layer but conv2_1 (+5 %) in all three arithmetics — kept behind the hook as the tested
+// negative result it is.
+OIBL_HOOK(int, g_ring_bar1, 0);
+// a launch over a row sub-range and / or a K split of the layer (conv_ring.h, RingParams; f16mx split-K)
+struct RingSub {
+  int tiles_m;       // M tiles of this launch, starting at GEMM row m_base
+  long m_base;
+  int parts;         // 0: one pass; else gridDim.y = parts split-K workgroups per tile
+  int nsteps_part, outer_step;
+  void* out;         // parts: the partial tensor [parts][out_rows][cout] fp32
+  long out_rows;
+  size_t part_stride;
+};
 template <int WM, bool POOL, bool ODD, int P = RING_BF16, bool OUTMX = (P >= RING_MX), bool BAR1 = false>
-static int launch_conv_ring_impl(const ConvParams& p, hipStream_t st) {
+static int launch_conv_ring_impl(const ConvParams& p, hipStream_t st, const RingSub* sub = nullptr) {
   using G = RingGeo<WM>;
   constexpr bool X3 = P != RING_BF16;  // 4-byte elements
   RingParams q;
@@ -716,7 +728,25 @@ static int launch_conv_ring_impl(const ConvParams& p, hipStream_t st) {
     ring_magic_u31(hq * wq ? hq * wq : 1u, &q.hw_mul, &q.hw_sh);
     ring_magic_u31(wq ? wq : 1u, &q.w_mul, &q.w_sh);
   }
-  const long tiles_m = (p.m_total + G::BM - 1) / G::BM;
+  long tiles_m = (p.m_total + G::BM - 1) / G::BM;
+  q.m_base = 0;
+  q.nsteps_part = q.k_outer_step = 0;
+  q.part_stride = 0;
+  unsigned parts = 1;
+  if (sub) {
+    tiles_m = sub->tiles_m;
+    q.m_base = (int)sub->m_base;
+    if (sub->parts) {   // split-K: raw fp32 accumulators into the partial tensor
+      parts = (unsigned)sub->parts;
+      q.nsteps_part = sub->nsteps_part;
+      q.k_outer_step = sub->outer_step;
+      q.part_stride = sub->part_stride;
+      q.out = sub->out;
+      q.out_rows = (int)sub->out_rows;
+      q.out_f32 = 1;
+      q.relu = 0;
+    }
+  }
   const long grid = tiles_m * q.tiles_n;
   q.tiles_m = (int)tiles_m;
   q.raster = g_ring_raster;
@@ -725,13 +755,13 @@ static int launch_conv_ring_impl(const ConvParams& p, hipStream_t st) {
   constexpr int lds = ring_lds_bytes<WM, POOL, P, OUTMX>();
   auto kern = conv3x3_ring_kernel<WM, POOL, ODD, P, OUTMX, BAR1>;
   OIBL_SET_MAX_LDS(kern, lds);
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, q);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid, parts), dim3(512), lds, st, q);
   OIBL_LAUNCH_CHECK();
   return OIBL_OK;
 }
 
 template <int WM, bool POOL, int P = RING_BF16>
-static int launch_conv_ring(const ConvParams& p, hipStream_t st) {
+static int launch_conv_ring(const ConvParams& p, hipStream_t st, const RingSub* sub = nullptr) {
   // an odd number of K-tiles happens only for Cin = 64 in bf16 (the 4-byte element types have twice
   // the K-tiles), which only the 512 x 128 variant serves
   if constexpr (WM == 4 && P == RING_BF16) {
@@ -740,9 +770,9 @@ static int launch_conv_ring(const ConvParams& p, hipStream_t st) {
                          : launch_conv_ring_impl<WM, POOL, true>(p, st);
   }
   if constexpr (P == RING_BF16 || P == RING_X3 || P == RING_MX_EARLY) {
-    if (g_ring_bar1) return launch_conv_ring_impl<WM, POOL, false, P, (P >= RING_MX), true>(p, st);
+    if (g_ring_bar1) return launch_conv_ring_impl<WM, POOL, false, P, (P >= RING_MX), true>(p, st, sub);
   }
-  return launch_conv_ring_impl<WM, POOL, false, P>(p, st);
+  return launch_conv_ring_impl<WM, POOL, false, P>(p, st, sub);
 }
 
 // 0 = not eligible, else the wave-row count of the instantiation to use (es = bytes per element)
@@ -912,13 +942,206 @@ static int launch_conv_halo(const ConvParams& p, hipStream_t st) {
   return OIBL_OK;
 }
 
+// ---- f16mx: row sub-ranges + split-K on the ring kernels ------------------------------------------
+// The ring tiles are 256 x 256 / 512 x 128 outputs and a workgroup owns a CU: a layer with T tiles runs
+// ceil(T / 256) rounds and the last one may be nearly empty — conv5_x at batch 32: 300 tiles = one full
+// round + 44 workgroups for a second; a single 480x640 image: 10 tiles on 256 CUs.  The plan: the FULL
+// rounds run as they are; the REMAINDER tiles are contracted by s workgroups each (s = 3 or 9 in K order
+// (tap, chunk): a part is 3 taps / one tap of all channel chunks; s = 2 in order (chunk, tap)), every part
+// from zero accumulators into an fp32 partial tensor, and conv_mx_splitk_reduce_kernel adds bias + parts in
+// a fixed order, applies ReLU (and the 2x2 max-pool), packs the f16mx lines.  Deterministic; the sums are
+// those of the one-pass kernel up to fp32 association.  A pooled layer is split only as a whole (its
+// remainder is not a contiguous range of the pooling kernel's quad-major rows).
+constexpr int MX_CUS = 256;
+struct MxSplitPlan {
+  int wm;           // wave rows of the ring instantiation (2: 256 x 256 tiles, 4: 512 x 128)
+  int tm_main;      // M tiles of the unsplit part (0: none)
+  int tm_rem;       // M tiles of the split part (0: the layer runs in one pass)
+  int s;            // parts per remainder tile
+  int nsteps_part;  // K-tiles per part
+  int outer_step;   // outer K indices per part
+  long m_base;      // first GEMM row of the split part
+  long rows_part;   // GEMM rows of the split part
+};
+OIBL_HOOK(int, g_mx_splitk, 1);   // test hook: 0 = never split
+static MxSplitPlan mx_split_plan(long m_plain, int cin, int cout, int pool, int korder, int wm) {
+  MxSplitPlan pl = {};
+  pl.wm = wm;
+  const int bm = wm * 128, tiles_n = cout / (wm == 2 ? 256 : 128);
+  const long tm = (m_plain + bm - 1) / bm;
+  const long T = tm * tiles_n;
+  const int cchunks = cin >> 5, nsteps = 9 * cchunks;
+  pl.tm_main = (int)tm;
+  if (!g_mx_splitk || wm == 0) return pl;
+  // full rounds of whole M-tile columns stay unsplit
+  long tm_main = (T / MX_CUS) * MX_CUS / tiles_n;
+  if (pool && tm_main != 0) return pl;
+  const long r = (tm - tm_main) * tiles_n;
+  if (r == 0) return pl;
+  // cost in K-tile times: a workgroup pays ~12 K-tiles of prologue + epilogue on top of its contraction
+  auto rounds = [](long wgs) { return (wgs + MX_CUS - 1) / MX_CUS; };
+  const long base = rounds(r) * (nsteps + 12);
+  long best = base;
+  int best_s = 1;
+  const int cands0[] = {3, 9}, cands1[] = {2, 4};
+  for (int ci = 0; ci < 2; ++ci) {
+    const int s = korder == 0 ? cands0[ci] : cands1[ci];
+    const int outer = korder == 0 ? 9 : cchunks;
+    if (outer % s != 0) continue;
+    const int part = nsteps / s;
+    if (part < 4 || (part & 1)) continue;            // the ring loop wants an even number >= 4 of K-tiles
+    const long c = rounds(r * s) * (part + 12) + 4;    // + the reduction pass
+    if (c < best) {
+      best = c;
+      best_s = s;
+    }
+  }
+  // worth it from 10 % of the layer on (two more launches)
+  const long whole = (tm_main * tiles_n / MX_CUS) * (nsteps + 12) + base;
+  if (best_s == 1 || (base - best) * 10 < whole) return pl;
+  pl.tm_main = (int)tm_main;
+  pl.tm_rem = (int)(tm - tm_main);
+  pl.s = best_s;
+  pl.nsteps_part = nsteps / best_s;
+  pl.outer_step = (korder == 0 ? 9 : cchunks) / best_s;
+  pl.m_base = tm_main * bm;
+  pl.rows_part = m_plain - pl.m_base;
+  return pl;
+}
+static int mx_ring_wm(int cin, int cout) {
+  if (cin % 64 != 0) return 0;
+  if (cout % 256 == 0 && cin % 128 == 0) return 2;
+  return cout % 128 == 0 ? 4 : 0;
+}
+static size_t mx_split_bytes(long m_plain, int cin, int cout, int pool, int korder) {
+  const MxSplitPlan pl = mx_split_plan(m_plain, cin, cout, pool, korder, mx_ring_wm(cin, cout));
+  return pl.tm_rem ? align_up((size_t)pl.s * pl.rows_part * cout * sizeof(float), 256) : 0;
+}
+
+// partial [s][rows_part][cout] fp32 -> out rows (f16mx lines, or fp32 when out_f32): one thread per
+// (output row, 32-channel group).  POOL: an output row is a pooled pixel, its four sources are GEMM rows
+// (n, 2 yo + dy, 2 xo + dx) in plain pixel order; rows_part then covers the whole layer (m_base = 0).
+template <bool POOL>
+__global__ void conv_mx_splitk_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
+                                             char* __restrict__ out, long out_row0, long out_rows_here,
+                                             long rows_part, int cout, int s, int relu, int out_f32, int H,
+                                             int W, unsigned* range_flag) {
+  const int groups = cout >> 5;
+  const long items = out_rows_here * groups;
+  const size_t part = (size_t)rows_part * cout;
+  const int Ho = H >> 1, Wo = W >> 1;
+  for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long)gridDim.x * blockDim.x) {
+    const long r = it / groups;
+    const int g = (int)(it - r * groups);
+    float v[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) v[e] = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < (POOL ? 4 : 1); ++q) {
+      long src = r;
+      if constexpr (POOL) {
+        const long n = r / ((long)Ho * Wo), rem = r - n * (long)Ho * Wo;
+        const int yo = (int)(rem / Wo), xo = (int)(rem - (long)yo * Wo);
+        src = (n * H + 2 * yo + (q >> 1)) * W + 2 * xo + (q & 1);
+      }
+      float a[32];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float4 b = *reinterpret_cast<const float4*>(bias + g * 32 + 4 * k);
+        a[4 * k] = b.x;
+        a[4 * k + 1] = b.y;
+        a[4 * k + 2] = b.z;
+        a[4 * k + 3] = b.w;
+      }
+      for (int ks = 0; ks < s; ++ks) {
+        const float4* pp = reinterpret_cast<const float4*>(partial + ks * part + (size_t)src * cout + g * 32);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float4 t = pp[k];
+          a[4 * k] += t.x;
+          a[4 * k + 1] += t.y;
+          a[4 * k + 2] += t.z;
+          a[4 * k + 3] += t.w;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 32; ++e) v[e] = fmaxf(v[e], a[e]);
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 32; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    char* dst = out + ((size_t)(out_row0 + r) * cout + g * 32) * 4;
+    if (out_f32) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        reinterpret_cast<float4*>(dst)[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+    } else {
+      uint4 line[8];
+      mx_pack_line(v, line, range_flag);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) reinterpret_cast<uint4*>(dst)[k] = line[k];
+    }
+  }
+}
+
 // f16mx: ring kernels (Cin % 64 == 0, Cout % 128 == 0 — every layer of the backbone behind the stem).
 // g_mx_variant (test hook): 0 = that; 3 = the halo kernel (conv_halo.h) for the 256-channel-tile layers —
 // 0.58x the LDS-DMA bytes, +5 % on conv3_x, -5 % on conv4_x / conv5_x since the ring's K cursor left its
 // LOAD segments (profiles/r03_*): kept as the tested alternative; 2 = ring kernels with the LDS-DMA issue
 // inside COMPUTE (RING_MX); 4..8 = timing experiments (wrong results) / stamps.
 OIBL_HOOK(int, g_mx_variant, 0);
+static int launch_conv_mx_split(const ConvParams& p, int pool, const MxSplitPlan& pl, hipStream_t st) {
+  // 1. the full rounds, unsplit, straight into the output (never pooled: see mx_split_plan)
+  int rc;
+  if (pl.tm_main) {
+    RingSub main = {};
+    main.tiles_m = pl.tm_main;
+    rc = pl.wm == 2 ? launch_conv_ring<2, false, RING_MX_EARLY>(p, st, &main)
+                    : launch_conv_ring<4, false, RING_MX_EARLY>(p, st, &main);
+    if (rc) return rc;
+  }
+  // 2. the remainder tiles, s parts each, plain pixel order, raw fp32 accumulators
+  ConvParams q = p;
+  const long m_plain = (long)p.N * p.H * p.W;
+  q.m_total = m_plain;
+  q.out_rows = m_plain;
+  RingSub rem = {};
+  rem.tiles_m = pl.tm_rem;
+  rem.m_base = pl.m_base;
+  rem.parts = pl.s;
+  rem.nsteps_part = pl.nsteps_part;
+  rem.outer_step = pl.outer_step;
+  rem.out = p.partial;
+  rem.out_rows = pl.rows_part;
+  rem.part_stride = (size_t)pl.rows_part * p.cout * sizeof(float);
+  rc = pl.wm == 2 ? launch_conv_ring<2, false, RING_MX_EARLY>(q, st, &rem)
+                  : launch_conv_ring<4, false, RING_MX_EARLY>(q, st, &rem);
+  if (rc) return rc;
+  // 3. bias + parts in order, ReLU, pool, pack
+  const long out_row0 = pool ? 0 : pl.m_base;
+  const long out_rows_here = pool ? p.out_rows : pl.rows_part;
+  const long items = out_rows_here * (p.cout / 32);
+  unsigned blocks = (unsigned)((items + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  if (pool)
+    hipLaunchKernelGGL(conv_mx_splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, st, p.partial, p.bias,
+                       (char*)p.out, out_row0, out_rows_here, pl.rows_part, p.cout, pl.s, p.relu, p.out_f32, p.H, p.W,
+                       p.range_flag);
+  else
+    hipLaunchKernelGGL(conv_mx_splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, st, p.partial, p.bias,
+                       (char*)p.out, out_row0, out_rows_here, pl.rows_part, p.cout, pl.s, p.relu, p.out_f32, p.H, p.W,
+                       p.range_flag);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
+
 static int launch_conv_mx(const ConvParams& p, int pool, hipStream_t st) {
+  // row sub-ranges + split-K where the tiling leaves a nearly empty round (needs the partial scratch)
+  if (p.partial && g_mx_variant <= 1 && !(pool && p.out_f32) && ring_variant(p, 4)) {
+    const MxSplitPlan pl = mx_split_plan((long)p.N * p.H * p.W, p.cin, p.cout, pool, p.korder, mx_ring_wm(p.cin, p.cout));
+    if (pl.tm_rem) return launch_conv_mx_split(p, pool, pl, st);
+  }
   const int rv = (pool && p.out_f32) ? 0 : ring_variant(p, 4);
   // the halo kernel (conv_halo.h) where it is the faster one: the 256-output-channel layers at 120 x 160
   // (conv3_1..conv3_3: 0.57 / 1.00 / 0.95 ms against 0.60 / 1.04 / 0.97 on the ring; deeper layers lose 5-10 %).
@@ -1742,6 +1965,17 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
   if (MX && threadIdx.x >= 64 && threadIdx.x < 96)
     reinterpret_cast<float*>(smem + S3_BIAS_OFF)[threadIdx.x] = p.b2[co0 + threadIdx.x - 64];
   __syncthreads();
+  // f16mx range guard (common.h): the largest group maximum this lane has packed, in a register; the flag —
+  // a kernel argument and a global store — is touched once, behind the role's loops, whose lgkmcnt / vmcnt
+  // waits are counted by hand (a scalar argument load inside them was seen to break the counts)
+  float range_seen = 0.f;
+  auto raise_if_out_of_range = [&]() __attribute__((always_inline)) {
+    if constexpr (MX) {
+      if (__builtin_amdgcn_ballot_w64(range_seen >= 65504.f) != 0) {
+        if (range_seen >= 65504.f) mx_raise_range_flag(p.range_flag);
+      }
+    }
+  };
 
   if (wave >= 4) {
     // ================================ producers (waves 4-15) ====================================
@@ -2022,7 +2256,7 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
           const float lim = pix_ok ? 65504.f : 0.f;
 #pragma unroll
           for (int j = 0; j < 16; ++j) c[j] = __builtin_amdgcn_fmed3f(acc[j], 0.f, lim);
-          mx_pack_half<false>(c, ph16, ph6, pl6, pbh, pbl, p.range_flag);
+          mx_pack_half<false>(c, ph16, ph6, pl6, pbh, pbl, range_seen);
           flush(buf);
         } else if (row_of(bi) < ST_HALO_PX) {
           char* row = buf + row_of(bi) * 128 + 8 * half;
@@ -2094,6 +2328,7 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
       p.prof[6] = pt[2];
       p.prof[7] = pt[3];
     }
+    raise_if_out_of_range();
     return;
   }
 
@@ -2319,7 +2554,7 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = __builtin_amdgcn_fmed3f(m0[j] + bv[j], 0.f, 65504.f);   // bias, ReLU, the fp16 bound
         unsigned h16[8], h6[3], l6[3], bh, bl;
-        mx_pack_half<false>(v, h16, h6, l6, bh, bl, p.range_flag);
+        mx_pack_half<false>(v, h16, h6, l6, bh, bl, range_seen);
         // lanes 0, 1 of a quad store: pooled pixel 8 (l31 & 1) + (l31 >> 2) of the tile row
         const unsigned off = (l31 & 2) ? 0x80000000u
                                        : (unsigned)(tx * 16 + 8 * (l31 & 1) + (l31 >> 2)) * 256u + blockIdx.y * 128u;
@@ -2343,6 +2578,7 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
       p.prof[2] = ct[2];
       p.prof[3] = ct0w;   // of the waits: behind pass 0
     }
+    raise_if_out_of_range();
     return;
   }
   {
@@ -2652,10 +2888,20 @@ OIBL_HOOK(int, g_conv_splitk, 1);  // test hook: 0 = never split K
 // splitk_ws (optional): scratch for the split-K partials of layers with too few tiles
 // (conv_splitk_bytes); without it every layer runs one-pass
 static size_t conv_splitk_bytes(long m_total, int cin, int cout, int precision) {
-  if (precision == OIBL_F16MX) return 0;  // one-pass ring kernels only
+  if (precision == OIBL_F16MX) return 0;  // (its own plan: mx_split_bytes)
   const int steps = 9 * (cin / (precision == OIBL_BF16 ? 64 : 32));
   const int s = conv_splitk_factor(m_total, cout, steps);
   return s ? align_up((size_t)s * m_total * cout * sizeof(float), 256) : 0;
+}
+
+// scratch of one layer's split-K partials (0: the layer runs in one pass), any precision
+static size_t conv_layer_scratch_bytes(int N, int h, int w, int cin, int cout, int pool, int precision) {
+  if (precision == OIBL_F16MX) {   // (either K order: the order is a per-layer default a test hook can change)
+    const size_t a = mx_split_bytes((long)N * h * w, cin, cout, pool, 0), b = mx_split_bytes((long)N * h * w, cin, cout, pool, 1);
+    return a > b ? a : b;
+  }
+  const long m_total = pool ? (long)N * (h / 2) * (w / 2) * 4 : (long)N * h * w;
+  return conv_splitk_bytes(m_total, cin, cout, precision);
 }
 
 static int conv3x3_impl(const void* in, int N, int H, int W, int cin, const void* packed_w,
@@ -2815,6 +3061,13 @@ int oibl_debug_set_conv_korder(int mode) {
 #endif
 
 #ifdef OIBL_DEBUG_HOOKS
+int oibl_debug_set_mx_splitk(int on) {
+  g_mx_splitk = on ? 1 : 0;
+  return OIBL_OK;
+}
+#endif
+
+#ifdef OIBL_DEBUG_HOOKS
 int oibl_debug_set_ring_bar1(int on) {
   g_ring_bar1 = on ? 1 : 0;
   return OIBL_OK;
@@ -2886,6 +3139,25 @@ int oibl_conv3x3_nhwc_flagged(const void* in, int N, int H, int W, int cin, cons
   OIBL_REQUIRE(range_flag == nullptr || (uintptr_t)range_flag % 4 == 0, "conv3x3: range flag must be 4-byte aligned");
   return conv3x3_impl(in, N, H, W, cin, packed_w, bias, cout, relu, pool, precision, out,
                       (hipStream_t)stream, 0, nullptr, range_flag);
+}
+
+size_t oibl_conv3x3_workspace_bytes(int N, int H, int W, int cin, int cout, int pool, int precision) {
+  if (N <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0 || !precision_ok(precision)) return 0;
+  return conv_layer_scratch_bytes(N, H, W, cin, cout, pool, precision);
+}
+
+int oibl_conv3x3_nhwc_ws(const void* in, int N, int H, int W, int cin, const void* packed_w, const float* bias,
+                         int cout, int relu, int pool, int precision, void* out, void* ws, size_t ws_bytes,
+                         uint32_t* range_flag, void* stream) {
+  OIBL_REQUIRE(range_flag == nullptr || (uintptr_t)range_flag % 4 == 0, "conv3x3: range flag must be 4-byte aligned");
+  const size_t need = oibl_conv3x3_workspace_bytes(N, H, W, cin, cout, pool, precision);
+  if (need && (ws == nullptr || ws_bytes < need)) {
+    set_error("conv3x3: workspace %zu < required %zu bytes", ws_bytes, need);
+    return OIBL_E_WORKSPACE;
+  }
+  OIBL_REQUIRE(!need || (uintptr_t)ws % 256 == 0, "conv3x3: workspace must be 256-byte aligned");
+  return conv3x3_impl(in, N, H, W, cin, packed_w, bias, cout, relu, pool, precision, out,
+                      (hipStream_t)stream, 0, need ? ws : nullptr, range_flag);
 }
 
 int oibl_conv1_1_nchw(const float* x_nchw, int N, int H, int W, const float* w_oihw,
@@ -2991,8 +3263,7 @@ static size_t vgg_splitk_bytes(int N, int H, int W, int precision) {
   size_t mx = 0;
   int h = H, w = W;
   for (int l = 1; l < OIBL_VGG16_NUM_CONV; ++l) {
-    const long m_total = kVgg[l].pool ? (long)N * (h / 2) * (w / 2) * 4 : (long)N * h * w;
-    const size_t b = conv_splitk_bytes(m_total, kVgg[l].cin, kVgg[l].cout, precision);
+    const size_t b = conv_layer_scratch_bytes(N, h, w, kVgg[l].cin, kVgg[l].cout, kVgg[l].pool, precision);
     mx = b > mx ? b : mx;
     if (kVgg[l].pool) {
       h /= 2;

@@ -47,6 +47,14 @@ struct RingParams {
   int raster;   // xcd_tile() mode
   int korder;   // 0 = (tap, channel chunk), 1 = (channel chunk, tap): see ConvRingALoader::begin_tile
   unsigned* range_flag;  // f16mx output: raised when an output is beyond fp16 (common.h, mx_raise_range_flag); may be null
+  // Row / K sub-ranges (all zero: the whole problem in one pass).  A launch covers the GEMM rows from m_base
+  // on (tiles_m tiles of them); with nsteps_part != 0 it is a SPLIT-K launch: workgroup (tile, blockIdx.y)
+  // contracts nsteps_part K-tiles starting at OUTER K index blockIdx.y * k_outer_step (outer = tap in K order
+  // 0, channel chunk in order 1: a split starts where the inner index is 0), from ZERO accumulators, and its
+  // epilogue (host: out_f32 = 1, relu = 0) writes them as fp32 rows to out + blockIdx.y * part_stride bytes,
+  // row (m - m_base); conv_mx_splitk_reduce_kernel adds bias and partials in a fixed order.
+  int m_base, nsteps_part, k_outer_step;
+  size_t part_stride;
 };
 
 // mul, sh with floor(m / d) == (m * mul) >> sh for every m < 2^31 (d >= 1):  sh = 31 + ceil(log2 d),
@@ -80,14 +88,15 @@ struct ConvRingALoader {
   unsigned base[2 * NA], mask[2 * NA], cur[2 * NA];
   unsigned soff, abl_piece;
   int in, out, per, W, pix_bytes, ablate, korder;   // K cursor: inner / outer counter, inner period
-  __device__ inline void init(const RingParams& p, int m0, const int (&tile_row)[2 * NA], int piece) {
+  __device__ inline void init(const RingParams& p, int m0, const int (&tile_row)[2 * NA], int piece,
+                              int outer0 = 0) {
     korder = p.korder;
     rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (int)p.in_bytes, 0x00020000);
     pix_bytes = p.cin * (X3 ? 4 : 2);
     per = korder ? 9 : (p.cin >> (X3 ? 5 : 6));
     W = p.W;
     in = -1;
-    out = -1;
+    out = outer0 - 1;   // the first begin_tile() lands on (outer0, inner 0)
     soff = 0;
     ablate = p.ablate & 1;
     abl_piece = (unsigned)piece;
@@ -162,7 +171,8 @@ struct ConvRingBLoader {
   unsigned off[2 * NB];
   unsigned soff, step_in, step_wrap;   // K cursor as a running byte offset: + step_in, or + step_wrap when
   int in, per;                         // the inner counter (period `per`) wraps — no branches
-  __device__ inline void init(const RingParams& p, int n0, const int (&tile_row)[2 * NB], int piece) {
+  __device__ inline void init(const RingParams& p, int n0, const int (&tile_row)[2 * NB], int piece,
+                              int outer0 = 0) {
     rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)p.w_bytes, 0x00020000);
     const unsigned pix_bytes = (unsigned)p.cin * (X3 ? 4u : 2u);
     const unsigned cchunks = (unsigned)(p.cin >> (X3 ? 5 : 6));
@@ -178,7 +188,7 @@ struct ConvRingBLoader {
       step_wrap = 128u - 8u * tap_stride;
     }
     in = -1;
-    soff = 0u - step_in;
+    soff = (unsigned)outer0 * (p.korder == 0 ? tap_stride : 128u) - step_in;   // first begin_tile(): K-tile (outer0, 0)
 #pragma unroll
     for (int j = 0; j < 2 * NB; ++j) off[j] = (unsigned)(n0 + tile_row[j]) * pix_bytes + piece;
     if (p.ablate & 2) {    // timing experiment: every K-tile reads ONE line (wrong results)
@@ -232,8 +242,10 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
   const unsigned long long t_start = prof ? __builtin_amdgcn_s_memtime() : 0;
   int tm, tn;
   xcd_tile(blockIdx.x, (unsigned)p.tiles_m, (unsigned)p.tiles_n, p.raster, tm, tn);
-  const int m0 = tm * G::BM, n0 = tn * G::BN;
-  const int nsteps = 9 * (p.cin >> (X3 ? 5 : 6));
+  const int m0 = p.m_base + tm * G::BM, n0 = tn * G::BN;
+  const bool splitk = p.nsteps_part != 0;
+  const int nsteps = splitk ? p.nsteps_part : 9 * (p.cin >> (X3 ? 5 : 6));
+  const int outer0 = (int)blockIdx.y * p.k_outer_step;
 
   const int piece = ring_piece(wave, lane);
   int rows_a[2 * NA], rows_b[2 * NB];
@@ -246,8 +258,8 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
   }
   ConvRingALoader<NA, POOL, X3> la;
   ConvRingBLoader<NB, X3> lb;
-  la.init(p, m0, rows_a, piece);
-  lb.init(p, n0, rows_b, MX ? ring_piece_mxb(wave, lane) : piece);   // (operand format, not output format)
+  la.init(p, m0, rows_a, piece, outer0);
+  lb.init(p, n0, rows_b, MX ? ring_piece_mxb(wave, lane) : piece, outer0);   // (operand format, not output format)
 
   // The accumulators start at the bias (the fma chain of every output begins with it), laid out
   // like the results: natural layout = one channel per lane and column tile, transposed layout
@@ -258,6 +270,7 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
   for (int j = 0; j < 2; ++j) {
     if constexpr (POOL) {
       float b = p.bias[n0 + wn * 64 + j * 32 + (lane & 31)];
+      b = splitk ? 0.f : b;   // (split-K partials start from zero: the reduction adds the bias)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -268,8 +281,9 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
     } else {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 b =
+        float4 b =
             *reinterpret_cast<const float4*>(p.bias + n0 + wn * 64 + j * 32 + 8 * g + 4 * (lane >> 5));
+        if (splitk) b = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           acc[i][j][4 * g] = b.x;
@@ -312,8 +326,9 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
     constexpr int ITEMS = ROWS * (G::BN / 32);
     constexpr int ITERS = ROWS * CPR / 512, BATCH = 8;
     static_assert(ITEMS % 512 == 0 && ITERS % BATCH == 0, "f16mx epilogue shape");
-    const long row0 = POOL ? (m0 >> 2) : m0;
-    char* obase = reinterpret_cast<char*>(p.out) + (long)n0 * 4;
+    // (split-K: the partial tensor of this K range, rows counted from m_base)
+    const long row0 = (POOL ? (m0 >> 2) : m0) - (splitk ? p.m_base : 0);
+    char* obase = reinterpret_cast<char*>(p.out) + (long)n0 * 4 + (splitk ? (size_t)blockIdx.y * p.part_stride : 0);
     const long orow_bytes = (long)p.cout * 4;
     const float floor_v = p.relu ? 0.f : -INFINITY;
     unsigned long long t_copy = 0;

@@ -28,6 +28,9 @@ SIGNATURES = {
                                   c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "oibl_conv3x3_nhwc_flagged": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                           c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "oibl_conv3x3_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "oibl_conv3x3_nhwc_ws": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                     c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "oibl_conv1_1_nchw": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
                                   c_void_p, c_void_p]),
     "oibl_global_maxpool_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -120,6 +123,7 @@ _HOOKS = {"oibl_debug_set_regstage": (c_int, [c_int]),
           "oibl_debug_set_pca_small": (c_int, [c_int]),
           "oibl_debug_set_netvlad_slabs": (c_int, [c_int]),
           "oibl_debug_set_ring_bar1": (c_int, [c_int]),
+          "oibl_debug_set_mx_splitk": (c_int, [c_int]),
           "oibl_debug_set_match_bar1": (c_int, [c_int]),
           "oibl_debug_set_prof_buffer": (c_int, [c_void_p])}
 
@@ -146,7 +150,7 @@ _HOOK_DEFAULTS = {"oibl_debug_set_regstage": 0, "oibl_debug_set_conv11_valu": 0,
                   "oibl_debug_set_conv_korder": -1, "oibl_debug_set_mx_variant": 0, "oibl_debug_set_conv_splitk": 1,
                   "oibl_debug_set_stem3_prio": 0, "oibl_debug_set_match_group": 4, "oibl_debug_set_match_splitk": 1,
                   "oibl_debug_set_pca_small": 1, "oibl_debug_set_netvlad_slabs": 1,
-                  "oibl_debug_set_ring_bar1": 1, "oibl_debug_set_match_bar1": 1,
+                  "oibl_debug_set_ring_bar1": 0, "oibl_debug_set_match_bar1": 0, "oibl_debug_set_mx_splitk": 1,
                   "oibl_debug_set_prof_buffer": None}
 
 

@@ -139,15 +139,16 @@ class VGG(_PrecisionMixin, nn.Module):
     def _convs(self) -> List[nn.Conv2d]:
         return [m for m in self.base if isinstance(m, nn.Conv2d)]
 
-    # f16mx has ring kernels only (256-pixel tiles, no split-K): a batch whose conv4 layers give fewer
-    # than F16MX_MIN_TILES tiles leaves most of the chip idle, and the backbone then runs in bf16x3 — the
-    # other mode inside the 1e-4 tolerance, with small-problem kernels (a single 480x640 image: 1.04 ms
-    # against 1.37 ms; profiles/r03_c_latency.md).  conv4 of N images of H x W has N (H/8) (W/8) / 256 x 2 tiles.
-    F16MX_MIN_TILES = 256
+    # Rounds 1-3 ran f16mx batches whose conv4 layers gave fewer than F16MX_MIN_TILES ring tiles in bf16x3
+    # (every Tokyo 24/7 query, every ragged last batch).  Since round 4 the f16mx ring kernels split K for
+    # layers that would leave the chip idle (csrc/conv.hip, mx_split_plan): the threshold is 0 — what was asked
+    # for is what runs — and only kept as a knob (set it to 256 for the old behaviour).
+    F16MX_MIN_TILES = 0
 
     def effective_precision(self, x: torch.Tensor) -> str:
-        """The arithmetic the backbone runs this input in: the module's precision, except that small
-        f16mx batches run in bf16x3 (see F16MX_MIN_TILES)."""
+        """The arithmetic the backbone runs this input in: the module's precision, except for f16mx batches
+        beyond the 32-bit offsets of its kernels (95 images of 480x640 and more), which run in bf16x3 — and
+        F16MX_MIN_TILES, 0 by default.  `precision_runs` counts what actually ran."""
         p = self.precision
         if ops.precision_code(p) != ops.F16MX:
             return p

@@ -254,9 +254,15 @@ def conv3x3_nhwc(x: torch.Tensor, packed_w: torch.Tensor, bias: torch.Tensor, re
         raise ValueError("conv3x3_nhwc: packed weight Cin mismatch")
     Ho, Wo = (H // 2, W // 2) if pool else (H, W)
     out = torch.empty((N, Ho, Wo, cout), dtype=_DTYPES[p], device=dev)
-    _lib.check(_lib.load().oibl_conv3x3_nhwc_flagged(_ptr(x), N, H, W, cin, _ptr(packed_w), _ptr(bias),
-                                                     cout, int(relu), int(pool), p, _ptr(out),
-                                                     _ptr(range_flag), _stream(dev)), "conv3x3_nhwc")
+    lib = _lib.load()
+    # scratch for split-K partials: f16mx only here (its small-problem path); the bf16 / bf16x3 / fp32 layers
+    # keep running one-pass when called alone — the backbone entry point gives them their scratch — so that
+    # the tile-variant tests compare like with like
+    ws_bytes = lib.oibl_conv3x3_workspace_bytes(N, H, W, cin, cout, int(pool), p) if p == F16MX else 0
+    ws = workspace(ws_bytes, dev, "conv") if ws_bytes else None
+    _lib.check(lib.oibl_conv3x3_nhwc_ws(_ptr(x), N, H, W, cin, _ptr(packed_w), _ptr(bias), cout, int(relu),
+                                        int(pool), p, _ptr(out), _ptr(ws), ws_bytes, _ptr(range_flag),
+                                        _stream(dev)), "conv3x3_nhwc")
     return out
 
 

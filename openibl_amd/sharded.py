@@ -86,10 +86,17 @@ def gather_prepared_queries(q_local: torch.Tensor, n_total: int, precision, grou
     return type(p).from_parts(rows, norms, int(q_local.shape[1]), precision)
 
 
+def _query_block(q, lo: int, hi: int):
+    """Rows [lo, hi) of a query set given as a tensor or as ops.PreparedRows (views, no copies)."""
+    if hasattr(q, "operand_rows"):           # ops.PreparedRows (or a stand-in with its protocol)
+        return type(q).from_parts(q.operand_rows()[lo:hi], q.norms[lo:hi], q.shape[1], getattr(q, "precision", None))
+    return q[lo:hi]
+
+
 def sharded_topk(q_all: torch.Tensor, g_local: torch.Tensor, k: int, index_base: int,
                  precision="fp32", group=None,
                  local_topk_fn: Optional[Callable] = None,
-                 merge_fn: Optional[Callable] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                 merge_fn: Optional[Callable] = None, blocks: int = 1) -> Tuple[torch.Tensor, torch.Tensor]:
     """k nearest gallery rows (squared L2) of every query over ALL ranks' gallery slices.
 
     q_all   [Q][d]  the full query set, identical on every rank (or its ops.PreparedRows, e.g. from
@@ -99,7 +106,11 @@ def sharded_topk(q_all: torch.Tensor, g_local: torch.Tensor, k: int, index_base:
     index_base      global gallery index of g_local[0]
     Returns (values [Q][k] ascending, indices [Q][k] int32 global), identical on every rank.
     Ties are broken towards the lowest global index, so the result does not depend on the number
-    of shards."""
+    of shards.
+    blocks > 1 (and more than one rank): the queries are processed in that many row blocks and the
+    exchange + merge of block b runs on a second stream while the matrix cores already work on the local
+    top-k of block b + 1 — the collective's latency (and the merge) leave the critical path except for the
+    last block.  Same results (every query row is independent)."""
     local_topk_fn = local_topk_fn or hip_local_topk
     merge_fn = merge_fn or hip_merge_topk
     rank, world = _world(group)
@@ -131,8 +142,48 @@ def sharded_topk(q_all: torch.Tensor, g_local: torch.Tensor, k: int, index_base:
         mv, mi = merge_fn(vs, is_, k)
         return mv, mi, flags
 
-    v, i, flags = gather_and_merge(*local(False))
+    nq = int(q_all.shape[0])
+    if blocks > 1 and world > 1 and nq >= blocks:
+        bounds = [(b * nq // blocks, (b + 1) * nq // blocks) for b in range(blocks)]
+        probe = getattr(q_all, "norms", q_all)
+        on_gpu = probe.is_cuda
+        main = torch.cuda.current_stream(probe.device) if on_gpu else None
+        side = _side_stream(probe.device) if on_gpu else None
+        parts = []
+        for lo, hi in bounds:
+            qb = _query_block(q_all, lo, hi)
+            res = local_topk_fn(qb, g_local, k, index_base, precision)
+            if len(res) == 2:
+                res = (res[0], res[1], torch.zeros(1, dtype=torch.int32, device=res[0].device))
+            if on_gpu:
+                side.wait_stream(main)                  # this block's lists are complete
+                with torch.cuda.stream(side):
+                    out = gather_and_merge(*res)
+                for t in (*res, *out):
+                    t.record_stream(side)
+                parts.append(out)
+            else:
+                parts.append(gather_and_merge(*res))
+        if on_gpu:
+            main.wait_stream(side)
+        v = torch.cat([p_[0] for p_ in parts])
+        i = torch.cat([p_[1] for p_ in parts])
+        flags = torch.cat([p_[2].reshape(-1) for p_ in parts])
+    else:
+        v, i, flags = gather_and_merge(*local(False))
     # the only host synchronisation, after everything has been enqueued; identical on every rank
     if bool(flags.any().item()):
         v, i, _ = gather_and_merge(*local(True))
     return v, i
+
+
+_SIDE = {}
+
+
+def _side_stream(dev: torch.device):
+    """One exchange stream per device, created once (streams created at different times may share a
+    hardware queue: extract._lane_streams)."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]

@@ -334,18 +334,27 @@ def test_conv_mx_repeatable_under_load(dev):
             lib.debug_hooks().oibl_debug_set_mx_variant(0)
 
 
-def test_small_f16mx_batches_run_in_bf16x3(dev, state_dict):
-    """The f16mx kernels are ring kernels only; a batch too small to fill the chip with their tiles is served
-    by bf16x3 (the other mode inside the tolerance, with split-K / small tiles): same bits as an explicit
-    bf16x3 model, the switch is visible through effective_precision()."""
+def test_small_batch_threshold_is_a_knob_and_off_by_default(dev, state_dict):
+    """Rounds 1-3 served small f16mx batches in bf16x3 (F16MX_MIN_TILES = 256); the ring kernels now split K
+    for them (tests/test_gpu_splitk.py), so the threshold is 0.  Set, it still works as before — same bits as an
+    explicit bf16x3 model — and what actually ran is visible through effective_precision() / precision_runs."""
     import hubconf
     m = hubconf.vgg16_netvlad(pretrained=False)
     m.load_state_dict(state_dict)
     m = m.to(dev).eval().set_precision("f16mx")
     one = synth.images(1, 480, 640, seed=3).to(dev)
     many = torch.empty((8, 3, 480, 640), device=dev)
+    assert m.base_model.effective_precision(one) == "f16mx"
+    m.base_model.F16MX_MIN_TILES = 256
     assert m.base_model.effective_precision(one) == "bf16x3"
     assert m.base_model.effective_precision(many) == "f16mx"
     got = m(one).clone()
+    assert m.base_model.precision_runs == {"bf16x3": 1}
     m.set_precision("bf16x3")
     assert torch.equal(m(one), got)
+    # 95 images of 480x640 and more: beyond the 32-bit offsets of the f16mx kernels (conv2_2's input)
+    m.set_precision("f16mx")
+    m.base_model.F16MX_MIN_TILES = 0
+    assert m.base_model.effective_precision(torch.empty((94, 3, 480, 640), device="meta")) == "f16mx"
+    assert m.base_model.effective_precision(torch.empty((96, 3, 480, 640), device="meta")) == "bf16x3"
+    assert m.base_model.effective_precision(torch.empty((32, 3, 960, 1280), device="meta")) == "bf16x3"

@@ -24,7 +24,7 @@ def test_store_follows_the_state_it_was_captured_in():
     model.set_precision("bf16x3")
     d = _graph_store(core, None, True, None, dev)
     assert d is not c
-    core.base_model.F16MX_MIN_TILES = 0
+    core.base_model.F16MX_MIN_TILES = 256
     assert _graph_store(core, None, True, None, dev) is not d
     # a precision round trip / invalidate(): same parameters, same precisions — but the packed weights the
     # graphs point into were dropped in between (cache generation)

@@ -122,6 +122,20 @@ def _worker(rank, world, port, G, ret):
         v4, i4 = sharded.sharded_topk(qp, g[start:start + n_valid], 10, start,
                                       local_topk_fn=_prepared_local_topk, merge_fn=_oracle_merge)
         ok_topk = ok_topk and bool(np.array_equal(i4.numpy(), wi))
+        # the same in query blocks (the exchange of block b overlaps the local top-k of block b + 1 on the
+        # GPU; here: same lists, prepared queries sliced without copies, one rank's overflow repeats all)
+        for nb in (2, 3, 5):
+            v5, i5 = sharded.sharded_topk(qp, g[start:start + n_valid], 10, start, blocks=nb,
+                                          local_topk_fn=_prepared_local_topk, merge_fn=_oracle_merge)
+            v6, i6 = sharded.sharded_topk(q, g[start:start + n_valid], 10, start, blocks=nb,
+                                          local_topk_fn=_oracle_local_topk, merge_fn=_oracle_merge)
+            ok_topk = ok_topk and bool(np.array_equal(i5.numpy(), wi) and np.array_equal(i6.numpy(), wi)
+                                       and np.allclose(v5.numpy(), wv) and np.allclose(v6.numpy(), wv))
+        _overflowing_local_topk.calls = []
+        v7, i7 = sharded.sharded_topk(q, g[start:start + n_valid], 10, start, blocks=2,
+                                      local_topk_fn=_overflowing_local_topk, merge_fn=_oracle_merge)
+        ok_topk = ok_topk and _overflowing_local_topk.calls == [False, False, True] and \
+            bool(np.array_equal(i7.numpy(), wi))
         rec = evaluators.recalls_from_topk(idx.numpy(), gt)
         ok_rec = bool(np.array_equal(rec, om.evaluate_all(d, gt, pids)))
 
