@@ -967,12 +967,13 @@ OIBL_HOOK(int, g_mx_splitk, 1);   // test hook: 0 = never split
 static MxSplitPlan mx_split_plan(long m_plain, int cin, int cout, int pool, int korder, int wm) {
   MxSplitPlan pl = {};
   pl.wm = wm;
+  if (wm == 0 || m_plain <= 0) return pl;   // no ring tiling for this layer (Cout = 64: the stem's conv1_2)
   const int bm = wm * 128, tiles_n = cout / (wm == 2 ? 256 : 128);
   const long tm = (m_plain + bm - 1) / bm;
   const long T = tm * tiles_n;
   const int cchunks = cin >> 5, nsteps = 9 * cchunks;
   pl.tm_main = (int)tm;
-  if (!g_mx_splitk || wm == 0) return pl;
+  if (!g_mx_splitk) return pl;
   // full rounds of whole M-tile columns stay unsplit
   long tm_main = (T / MX_CUS) * MX_CUS / tiles_n;
   if (pool && tm_main != 0) return pl;

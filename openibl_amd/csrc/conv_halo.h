@@ -75,7 +75,7 @@ __device__ static inline void halo_phase_mma(f32x16_t& acc0, f32x16_t& acc1, con
                                              const bf16x8_t (&fb)[4], Prep&& prep, bool prio2 = false) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
-  if (prio2) __builtin_amdgcn_s_setprio(2);   // (BAR1, group 0: ring_core.h)
+  if (prio2) __builtin_amdgcn_s_setprio(2);   // (BAR1, group 0, a compile-time constant at every call: ring_core.h)
   else __builtin_amdgcn_s_setprio(1);
   if constexpr (P >= RING_MX) {
     typedef __attribute__((ext_vector_type(4))) int i4;
@@ -123,16 +123,14 @@ __device__ static inline void halo_phase_mma(f32x16_t& acc0, f32x16_t& acc1, con
 
 // VAR (experiments kept for tests/gpu_halo_determinism.py): 0 = production; 3 = the waits that count the
 // halo instructions as outstanding (vmcnt(6) / vmcnt(5)) with out-of-range dummies: rarely WRONG, see below.
-// BAR1: one barrier per phase and wave (ring_core.h) — the same hazard distances hold here.
-template <bool POOL, int P, int VAR = 0, bool BAR1 = false>
-__global__ __launch_bounds__(512) void conv3x3_halo_kernel(HaloParams p) {
+// BAR1: one barrier per phase and wave (ring_core.h) — the same hazard distances hold here; GROUP as in
+// conv3x3_ring_body (conv_ring.h).
+template <bool POOL, int P, int VAR, bool BAR1, int GROUP>
+__device__ __forceinline__ void conv3x3_halo_body(const HaloParams& p, char* smem, const int lane, const int wave) {
   using G = RingGeo<2>;
   constexpr bool MX = P >= RING_MX;
   constexpr bool SWAP = !POOL;
   constexpr int NB = G::NB;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave / G::WN, wn = wave % G::WN;
   const int group = wave >> 2;
   int tm, tn;
@@ -283,16 +281,16 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(HaloParams p) {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto bar_g = [&](int g) __attribute__((always_inline)) {   // (ring_core.h)
+  // BAR1: the stagger group is a compile-time constant of one of two copies of the K loop (ring_core.h, GROUP)
+  auto bar_g = [&](auto grp_c, int g) __attribute__((always_inline)) {
     if constexpr (BAR1) {
       __builtin_amdgcn_sched_barrier(0);
-      if (group == g) __builtin_amdgcn_s_barrier();
+      if (decltype(grp_c)::value == g) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
     } else {
       bar();
     }
   };
-  const bool prio2 = BAR1 && group == 0;
 
   // accumulators start at the bias (conv_ring.h)
   f32x16_t acc[4][2];
@@ -348,7 +346,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(HaloParams p) {
 
   // one K-tile = tap `TAP` of channel chunk cc (halo buffer hb); PAR = parity of the K-tile (weight buffer,
   // register set of B0); kt = its index
-  auto ktile = [&](auto par_c, auto tap_c, int hb, int cc, int kt) __attribute__((always_inline)) {
+  auto ktile = [&](auto grp_c, auto par_c, auto tap_c, int hb, int cc, int kt) __attribute__((always_inline)) {
+    constexpr bool prio2 = BAR1 && decltype(grp_c)::value == 0;
     constexpr int PAR = decltype(par_c)::value;
     constexpr int TAP = decltype(tap_c)::value;
     bf16x8_t(&b0)[4] = PAR ? fby : fbx;
@@ -365,51 +364,54 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(HaloParams p) {
     // 8 of 270 launches; 0 of 270 with the waits below).  So the halo instructions are not counted — the
     // waits allow only the 2 x NB younger WEIGHT instructions in flight — and every dummy is an in-range load.
     wait_vmcnt<(VAR == 3 ? 1 + 2 * NB + 1 : 2 * NB)>();
-    bar_g(0);
+    bar_g(grp_c, 0);
     halo_phase_mma<P, SWAP>(acc[0][0], acc[1][0], fa, b0, [&] { lb.begin_tile(); }, prio2);  // (cursor -> K-tile
-    bar_g(1);                          // t+2; unconditional: advanced under a branch it ends up in a VGPR)
+    bar_g(grp_c, 1);                          // t+2; unconditional: advanced under a branch it ends up in a VGPR)
     // P1: A0 x B1
     read_b(PAR, 1, b1);
     stage_b(PAR, 0, more);  // B0(t+2)
-    bar_g(0);
+    bar_g(grp_c, 0);
     halo_phase_mma<P, SWAP>(acc[0][1], acc[1][1], fa, b1, [] {}, prio2);
-    bar_g(1);
+    bar_g(grp_c, 1);
     // P2: A1 x B1
     read_a(hb, I1{}, tap_c);
     wait_vmcnt<(VAR == 3 ? 2 * NB + 1 : 2 * NB)>();
-    bar_g(0);
+    bar_g(grp_c, 0);
     halo_phase_mma<P, SWAP>(acc[2][1], acc[3][1], fa, b1, [] {}, prio2);
-    bar_g(1);
+    bar_g(grp_c, 1);
     // P3: A1 x B0   (B0 of the next K-tile goes into the register set B1 just vacated)
     read_b(PAR ^ 1, 0, b1);
     stage_b(PAR, 1, more);  // B1(t+2)
-    bar_g(0);
+    bar_g(grp_c, 0);
     halo_phase_mma<P, SWAP>(acc[2][0], acc[3][0], fa, b0, [] {}, prio2);
-    bar_g(1);
+    bar_g(grp_c, 1);
     (void)TAP;
   };
   // two chunks = 18 K-tiles per trip (nine taps each: the K-tile parity flips from chunk to chunk)
-  for (int cc = 0; cc < chunks; cc += 2) {
-    const int kt = 9 * cc;
-    ktile(I0{}, HALO_IC(0), 0, cc, kt);
-    ktile(I1{}, HALO_IC(1), 0, cc, kt + 1);
-    ktile(I0{}, HALO_IC(2), 0, cc, kt + 2);
-    ktile(I1{}, HALO_IC(3), 0, cc, kt + 3);
-    ktile(I0{}, HALO_IC(4), 0, cc, kt + 4);
-    ktile(I1{}, HALO_IC(5), 0, cc, kt + 5);
-    ktile(I0{}, HALO_IC(6), 0, cc, kt + 6);
-    ktile(I1{}, HALO_IC(7), 0, cc, kt + 7);
-    ktile(I0{}, HALO_IC(8), 0, cc, kt + 8);
-    ktile(I1{}, HALO_IC(0), 1, cc + 1, kt + 9);
-    ktile(I0{}, HALO_IC(1), 1, cc + 1, kt + 10);
-    ktile(I1{}, HALO_IC(2), 1, cc + 1, kt + 11);
-    ktile(I0{}, HALO_IC(3), 1, cc + 1, kt + 12);
-    ktile(I1{}, HALO_IC(4), 1, cc + 1, kt + 13);
-    ktile(I0{}, HALO_IC(5), 1, cc + 1, kt + 14);
-    ktile(I1{}, HALO_IC(6), 1, cc + 1, kt + 15);
-    ktile(I0{}, HALO_IC(7), 1, cc + 1, kt + 16);
-    ktile(I1{}, HALO_IC(8), 1, cc + 1, kt + 17);
-  }
+  auto run = [&](auto grp_c) __attribute__((always_inline)) {
+    for (int cc = 0; cc < chunks; cc += 2) {
+      const int kt = 9 * cc;
+      ktile(grp_c, I0{}, HALO_IC(0), 0, cc, kt);
+      ktile(grp_c, I1{}, HALO_IC(1), 0, cc, kt + 1);
+      ktile(grp_c, I0{}, HALO_IC(2), 0, cc, kt + 2);
+      ktile(grp_c, I1{}, HALO_IC(3), 0, cc, kt + 3);
+      ktile(grp_c, I0{}, HALO_IC(4), 0, cc, kt + 4);
+      ktile(grp_c, I1{}, HALO_IC(5), 0, cc, kt + 5);
+      ktile(grp_c, I0{}, HALO_IC(6), 0, cc, kt + 6);
+      ktile(grp_c, I1{}, HALO_IC(7), 0, cc, kt + 7);
+      ktile(grp_c, I0{}, HALO_IC(8), 0, cc, kt + 8);
+      ktile(grp_c, I1{}, HALO_IC(0), 1, cc + 1, kt + 9);
+      ktile(grp_c, I0{}, HALO_IC(1), 1, cc + 1, kt + 10);
+      ktile(grp_c, I1{}, HALO_IC(2), 1, cc + 1, kt + 11);
+      ktile(grp_c, I0{}, HALO_IC(3), 1, cc + 1, kt + 12);
+      ktile(grp_c, I1{}, HALO_IC(4), 1, cc + 1, kt + 13);
+      ktile(grp_c, I0{}, HALO_IC(5), 1, cc + 1, kt + 14);
+      ktile(grp_c, I1{}, HALO_IC(6), 1, cc + 1, kt + 15);
+      ktile(grp_c, I0{}, HALO_IC(7), 1, cc + 1, kt + 16);
+      ktile(grp_c, I1{}, HALO_IC(8), 1, cc + 1, kt + 17);
+    }
+  };
+  run(std::integral_constant<int, (GROUP == 1 ? 1 : 0)>{});
 #undef HALO_IC
   if constexpr (!BAR1) {
     if (group == 0) bar();
@@ -515,6 +517,19 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(HaloParams p) {
       }
     }
     if (pass + 1 < PASSES) __syncthreads();
+  }
+}
+
+template <bool POOL, int P, int VAR = 0, bool BAR1 = false>
+__global__ __launch_bounds__(512) void conv3x3_halo_kernel(HaloParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if constexpr (BAR1) {
+    if ((wave >> 2) == 0) conv3x3_halo_body<POOL, P, VAR, true, 0>(p, smem, lane, wave);
+    else conv3x3_halo_body<POOL, P, VAR, true, 1>(p, smem, lane, wave);
+  } else {
+    conv3x3_halo_body<POOL, P, VAR, false, -1>(p, smem, lane, wave);
   }
 }
 

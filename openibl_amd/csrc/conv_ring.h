@@ -227,16 +227,17 @@ __device__ static inline void ring_split4(float a0, float a1, float a2, float a3
 // OUTMX: the output is written as f16mx lines (always with f16mx operands; the parameter exists because the
 // epilogue only depends on it: bf16x3 operands with f16mx output compile too — round 3 ran conv2_1 that way
 // until the stem itself became f16mx).
-template <int WM, bool POOL, bool ODD, int P = RING_BF16, bool OUTMX = (P >= RING_MX), bool BAR1 = false>
-__global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
+// The kernel's body.  GROUP: -1, or (BAR1) the stagger group of the calling wave as a compile-time constant —
+// the kernel then holds one copy of the body per group (ring_core.h, GROUP: two copies of the LOOP that merged
+// again in front of a shared epilogue made the register allocator spill; a lambda around the body put the
+// kernel arguments on the stack).
+template <int WM, bool POOL, bool ODD, int P, bool OUTMX, bool BAR1, int GROUP>
+__device__ __forceinline__ void conv3x3_ring_body(const RingParams& p, char* smem, const int lane, const int wave) {
   using G = RingGeo<WM>;
   constexpr int NA = G::NA, NB = G::NB;
   constexpr bool X3 = P != RING_BF16;   // 4-byte elements, 32 channels per K-tile (bf16x3 and f16mx)
   constexpr bool MX = P >= RING_MX;     // f16mx operands
   static_assert(!OUTMX || X3, "f16mx output needs 4-byte elements");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave / G::WN, wn = wave % G::WN;
   const bool prof = p.prof != nullptr && blockIdx.x == 0 && wave == 0;
   const unsigned long long t_start = prof ? __builtin_amdgcn_s_memtime() : 0;
@@ -296,8 +297,8 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
   }
 
   const unsigned long long t_loop = prof ? __builtin_amdgcn_s_memtime() : 0;
-  ring_mainloop<WM, ODD, !POOL, P, BAR1>(acc, smem, wave, lane, la, lb, nsteps,
-                                   (P == RING_MX_PROF && blockIdx.x == 0 && p.prof) ? p.prof + 8 : nullptr);
+  ring_mainloop<WM, ODD, !POOL, P, BAR1, GROUP>(acc, smem, wave, lane, la, lb, nsteps,
+                                                (P == RING_MX_PROF && blockIdx.x == 0 && p.prof) ? p.prof + 8 : nullptr);
   // (the main loop ends on a workgroup barrier: the staging LDS is free for the epilogue)
   const unsigned long long t_epi = prof ? __builtin_amdgcn_s_memtime() : 0;
 
@@ -543,6 +544,19 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
       p.prof[2] = t_copy - t_epi;
       p.prof[3] = t_end - t_copy;
     }
+  }
+}
+
+template <int WM, bool POOL, bool ODD, int P = RING_BF16, bool OUTMX = (P >= RING_MX), bool BAR1 = false>
+__global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if constexpr (BAR1) {
+    if ((wave >> 2) == 0) conv3x3_ring_body<WM, POOL, ODD, P, OUTMX, true, 0>(p, smem, lane, wave);
+    else conv3x3_ring_body<WM, POOL, ODD, P, OUTMX, true, 1>(p, smem, lane, wave);
+  } else {
+    conv3x3_ring_body<WM, POOL, ODD, P, OUTMX, false, -1>(p, smem, lane, wave);
   }
 }
 

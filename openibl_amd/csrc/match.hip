@@ -272,7 +272,12 @@ __global__ __launch_bounds__(512) void pairwise_ring_kernel(PairRingParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  ring_mainloop<2, false, false, P, BAR1>(acc, smem, wave, lane, la, lb, d_part >> (X3 ? 5 : 6));
+  if constexpr (BAR1) {   // one copy of the loop per stagger group (ring_core.h)
+    if ((wave >> 2) == 0) ring_mainloop<2, false, false, P, true, 0>(acc, smem, wave, lane, la, lb, d_part >> (X3 ? 5 : 6));
+    else ring_mainloop<2, false, false, P, true, 1>(acc, smem, wave, lane, la, lb, d_part >> (X3 ? 5 : 6));
+  } else {
+    ring_mainloop<2, false, false, P>(acc, smem, wave, lane, la, lb, d_part >> (X3 ? 5 : 6));
+  }
 
   // norms (and thresholds) of the tile's rows / columns -> LDS; out-of-range rows/columns are
   // clamped here and masked at the store

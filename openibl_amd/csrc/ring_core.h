@@ -174,7 +174,11 @@ struct RingRowLoader {
 // both cross terms: per 32x32 tile and K-tile 2 f16 MFMAs + 1 MX MFMA, 6 per phase, on the same LDS
 // traffic and with the same fragment addresses for both operands.
 // On return every wave has passed a workgroup barrier: the staging LDS is free.
-template <int WM, bool ODD, bool SWAP, int P = RING_BF16, bool BAR1 = false, typename LA, typename LB>
+// GROUP (BAR1 only): the stagger group of the calling wave as a compile-time constant — the caller branches
+// ONCE on wave >> 2 into one of two copies of the loop, so that which barrier a wave crosses and at which
+// priority it computes cost no instructions inside the loop (with run-time tests — four branches and ~10 scalar
+// instructions per phase — the one-barrier schedule measured 3-8 % SLOWER than the two-barrier one).
+template <int WM, bool ODD, bool SWAP, int P = RING_BF16, bool BAR1 = false, int GROUP = -1, typename LA, typename LB>
 __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, int wave, int lane,
                                             LA& la, LB& lb, int nsteps, unsigned long long* stamps = nullptr) {
   using G = RingGeo<WM>;
@@ -183,6 +187,7 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
                 OFF_B1 = 2 * G::A_UNIT + G::B_UNIT;
   const int wm = wave / G::WN, wn = wave % G::WN;
   const int group = wave >> 2;
+  static_assert(!BAR1 || GROUP == 0 || GROUP == 1, "BAR1: the caller fixes the stagger group");
 
   char* const st_base = smem + wave * 1024;
   // SPLIT (512 x 128 tile: an A unit is 4 instructions, a B unit 1): the A unit is issued in two
@@ -258,9 +263,8 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
     constexpr int h = decltype(h_c)::value, j = decltype(j_c)::value;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (BAR1) {   // both groups compute inside one barrier interval: the one that still has to LOAD first
-      if (group == 0) __builtin_amdgcn_s_setprio(2);
-      else __builtin_amdgcn_s_setprio(1);
+    if constexpr (BAR1 && GROUP == 0) {   // both groups compute inside one barrier interval: the one that still
+      __builtin_amdgcn_s_setprio(2);      // has to LOAD goes first
     } else {
       __builtin_amdgcn_s_setprio(1);
     }
@@ -329,7 +333,7 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
   auto bar_g = [&](int g) __attribute__((always_inline)) {
     if constexpr (BAR1) {
       __builtin_amdgcn_sched_barrier(0);
-      if (group == g) __builtin_amdgcn_s_barrier();
+      if (GROUP == g) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
     } else {
       bar();

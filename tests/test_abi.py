@@ -172,6 +172,39 @@ def test_every_entry_point_is_documented_for_binders():
     assert not [n for n in names if n not in doc]
 
 
+def test_backbone_workspace_queries_host_side():
+    """oibl_vgg16_workspace_bytes / oibl_conv3x3_workspace_bytes are host arithmetic (tile counts, the f16mx
+    split plan): every precision, batch sizes on both sides of every split decision, odd image sizes — no
+    crash (round 4 shipped a division by zero here for one GPU call), monotone in the batch, and the f16mx
+    plan splits exactly where the tiling leaves a nearly empty round."""
+    from openibl_amd import lib
+    h = lib.load()
+    BF16, F32, X3, MX = 0, 1, 2, 3
+    for prec in (BF16, F32, X3, MX):
+        last = 0
+        for n in (1, 2, 3, 5, 8, 16, 32, 33):
+            b = h.oibl_vgg16_workspace_bytes(n, 480, 640, prec)
+            assert b > n * 240 * 320 * 64 * (2 if prec == BF16 else 4), (prec, n, b)
+            assert b >= last or prec == MX                       # (the f16mx plan's scratch is not monotone)
+            last = b
+            assert h.oibl_vgg16_u8_workspace_bytes(n, 480, 640, prec) == b + n * 3 * 480 * 640 * 4
+        for (H, W) in ((16, 16), (17, 31), (224, 224), (352, 500), (479, 637), (960, 1280)):
+            assert h.oibl_vgg16_workspace_bytes(1, H, W, prec) > 0
+        assert h.oibl_vgg16_workspace_bytes(1, 15, 640, prec) == 0 and h.oibl_vgg16_workspace_bytes(0, 480, 640, prec) == 0
+    ws = lambda n, hh, ww, ci, co, pool: h.oibl_conv3x3_workspace_bytes(n, hh, ww, ci, co, pool, MX)   # noqa: E731
+    assert ws(32, 30, 40, 512, 512, 0) == 9 * (150 - 128) * 256 * 512 * 4       # conv5_x at batch 32: 44 tiles x 9 parts
+    assert ws(32, 60, 80, 512, 512, 0) == 0 and ws(32, 120, 160, 256, 256, 0) == 0 and ws(32, 240, 320, 64, 128, 0) == 0
+    assert ws(1, 30, 40, 512, 512, 0) == 9 * 1200 * 512 * 4                      # one image: the whole layer, 9 parts
+    assert ws(1, 60, 80, 512, 512, 1) == 9 * 4800 * 512 * 4                      # pooled: split only as a whole
+    assert ws(1, 120, 160, 128, 256, 0) == 3 * 19200 * 256 * 4
+    assert ws(1, 240, 320, 64, 128, 0) == 0                                      # 150 short tiles: not worth it
+    assert ws(1, 24, 32, 64, 64, 1) == 0 and ws(1, 24, 32, 96, 128, 0) == 0      # no ring tiling: no plan, no crash
+    for prec in (BF16, F32, X3):
+        assert h.oibl_conv3x3_workspace_bytes(1, 30, 40, 512, 512, 0, prec) > 0 # their own split-K (128-row tiles)
+        assert h.oibl_conv3x3_workspace_bytes(32, 60, 80, 512, 512, 0, prec) == 0
+    assert h.oibl_conv3x3_workspace_bytes(1, 30, 40, 512, 512, 0, 7) == 0
+
+
 def test_hot_kernels_stay_inside_their_register_budgets():
     """The compiler's per-kernel report of the current build (hipcc -Rpass-analysis=kernel-resource-usage,
     kept by openibl_amd.build): the kernels of the default path do not spill — ring convolutions and
