@@ -151,8 +151,8 @@ int oibl_conv3x3_nhwc_flagged(const void* in, int N, int H, int W, int cin, cons
 /* The same with scratch: a layer whose tiling would leave most of the chip idle — conv4 / conv5 of a few
  * images — is then contracted split-K (several workgroups per output tile, fp32 partial tiles in `ws`, a
  * fixed-order reduction that also applies bias / ReLU / pool: deterministic, equal to the one-pass result up
- * to fp32 association), in every precision.  oibl_conv3x3_workspace_bytes may return 0 (ws may then be NULL).
- * This is what oibl_vgg16_conv5_forward runs per layer. */
+ * to fp32 association), in every precision.  oibl_conv3x3_workspace_bytes may return 0; ws == NULL runs the
+ * layer in one pass whatever its size.  This is what oibl_vgg16_conv5_forward runs per layer. */
 size_t oibl_conv3x3_workspace_bytes(int N, int H, int W, int cin, int cout, int pool, int precision);
 int oibl_conv3x3_nhwc_ws(const void* in, int N, int H, int W, int cin, const void* packed_w,
                          const float* bias, int cout, int relu, int pool, int precision, void* out,

@@ -686,10 +686,11 @@ OIBL_HOOK(int, g_ring_ablate, 0);                     // test hook: see RingPara
 // ring-schedule kernel (conv_ring.h): bf16, Cin % 64 == 0; WM = 2: 256 x 256 tile (Cout % 256 == 0),
 // WM = 4: 512 x 128 tile (Cout % 128 == 0)
 // BAR1: the one-barrier-per-phase schedule (ring_core.h).  g_ring_bar1 (test hook): 0 = two barriers per
-// phase (the default), 1 = one.  Measured (profiles/r04_a_bar1_ab.txt): bit-identical, race-free, and 3-8 %
-// SLOWER on every layer but conv2_1 (+5 %) in all three arithmetics — kept behind the hook as the tested
-// negative result it is.
-OIBL_HOOK(int, g_ring_bar1, 0);
+// phase (rounds 1-3), 1 = one (the default).  Measured, bit-identical and race-free both times: with the
+// stagger group tested at run time inside the loop 3-8 % SLOWER (profiles/r04_a_bar1_ab.txt); with one kernel
+// body per group 1-4 % faster per layer, 11 % on conv2_1 — f16mx ring + halo layers 7.47 -> 7.25 ms, bf16
+// 4.26 -> 4.19, bf16x3 11.04 -> 10.90 (profiles/r04_b_bar1_ab.txt).
+OIBL_HOOK(int, g_ring_bar1, 1);
 // a launch over a row sub-range and / or a K split of the layer (conv_ring.h, RingParams; f16mx split-K)
 struct RingSub {
   int tiles_m;       // M tiles of this launch, starting at GEMM row m_base
@@ -3151,8 +3152,9 @@ int oibl_conv3x3_nhwc_ws(const void* in, int N, int H, int W, int cin, const voi
                          int cout, int relu, int pool, int precision, void* out, void* ws, size_t ws_bytes,
                          uint32_t* range_flag, void* stream) {
   OIBL_REQUIRE(range_flag == nullptr || (uintptr_t)range_flag % 4 == 0, "conv3x3: range flag must be 4-byte aligned");
-  const size_t need = oibl_conv3x3_workspace_bytes(N, H, W, cin, cout, pool, precision);
-  if (need && (ws == nullptr || ws_bytes < need)) {
+  // ws == NULL: the layer runs in one pass whatever its size (exactly oibl_conv3x3_nhwc_flagged)
+  const size_t need = ws ? oibl_conv3x3_workspace_bytes(N, H, W, cin, cout, pool, precision) : 0;
+  if (need && ws_bytes < need) {
     set_error("conv3x3: workspace %zu < required %zu bytes", ws_bytes, need);
     return OIBL_E_WORKSPACE;
   }

@@ -838,7 +838,7 @@ extern "C" {
 OIBL_HOOK(int, g_match_ring, 1);  // test hook: 0 = never, 1 = auto, 2 = whenever legal
 OIBL_HOOK(int, g_match_group, 4);  // test hook: query tiles per ordering group of the ring kernel
 OIBL_HOOK(int, g_match_splitk, 1);  // test hook: 0 = never split the threshold sample's contraction
-OIBL_HOOK(int, g_match_bar1, 0);    // test hook: 1 = one barrier per phase in the ring kernel (ring_core.h, BAR1: 3-7 % slower)
+OIBL_HOOK(int, g_match_bar1, 1);    // test hook: 0 = two barriers per phase in the ring kernel (ring_core.h, BAR1: 1 = 0-2.5 % faster)
 
 #ifdef OIBL_DEBUG_HOOKS
 int oibl_debug_set_match_splitk(int on) {

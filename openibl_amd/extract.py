@@ -87,12 +87,15 @@ class GraphedForward:
 
     f16mx range guard.  A backbone that runs in f16mx raises a device flag when an activation is beyond
     fp16 (models.VGG.features_nhwc); a replayed graph cannot branch on it, so the flag travels to a pinned
-    host word behind every backbone replay and is CHECKED BEFORE THE SLOT IS USED AGAIN (or in `wait()`):
-    the host then waits for that batch's `done` event — two batches back with two lanes, so the lanes never
-    run dry — and a flagged batch is recomputed eagerly in bf16x3 from the slot's still-resident input,
-    into the slot's output and into its `dest`.  With the guard `wait()` therefore blocks the host, and a
-    one-lane forward checks before it returns.  `range_guard`: the object with `last_range_flag()` /
-    `features_fallback(x)` (default: the object `backbone_fn` is bound to, if it has them).
+    host word behind every backbone replay (one word per call, a ring of RING) and every call first POLLS the
+    batches in flight: one whose `done` event has fired has its flag read, and a flagged batch is recomputed
+    eagerly in bf16x3 — from the caller's tensor `x`, which the queue keeps referenced (a pinned loader batch, a
+    device tensor), into its `dest` (and into the slot's output while the slot still holds that batch).  The
+    host only BLOCKS on a batch when its slot is needed again and the batch has no other source than the
+    slot's input (`x=None`, or `stable_src=False`: a staging buffer the caller reuses), when RING - 2 batches
+    are unchecked, in `wait()`, and — one lane — before the call returns.  So the input copies of the next
+    batches are enqueued as far ahead as without the guard.  `range_guard`: the object with
+    `last_range_flag()` / `features_fallback(x)` (default: the object `backbone_fn` is bound to, if it has them).
     `keep`: optional callable returning tensors (in nested dicts / lists) the captured kernels point into —
     packed weights — evaluated after the capture; they stay referenced for the life of this object."""
 
@@ -122,9 +125,10 @@ class GraphedForward:
         self.guard = range_guard
         self.head_fn = head_fn
         self.flag_dev = [None] * self.depth       # the lane's range flag (device), None: not an f16mx capture
-        self.flag_host = [None] * self.depth      # its pinned host copy, refreshed behind every backbone replay
-        self.unsettled = [False] * self.depth     # a batch of this slot has not had its flag checked yet
-        self.pending_dest = [None] * self.depth
+        self.flag_ring = None                     # pinned host words: call c's flag lands in word c % RING
+        self.ev_ring = []                         # call c's completion event (flag copy + hand-off behind it)
+        self.pending = []                         # calls whose flag has not been checked: oldest first
+        self.slot_call = [-1] * self.depth        # the last call that ran on each slot
         self.range_fallbacks = 0
         with torch.no_grad():
             head_fn(backbone_fn(self.static_in[0]))   # packs weights, sizes every workspace, warms up
@@ -143,8 +147,10 @@ class GraphedForward:
                 flag = self.guard.last_range_flag() if self.guard is not None else None
                 if flag is not None:
                     self.flag_dev[j] = flag
-                    self.flag_host[j] = torch.zeros(1, dtype=torch.int32).pin_memory()
                     self._keep.append(flag)
+                    if self.flag_ring is None:
+                        self.flag_ring = torch.zeros(self.RING, dtype=torch.int32).pin_memory()
+                        self.ev_ring = [torch.cuda.Event() for _ in range(self.RING)]
                 gh = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gh, capture_error_mode="thread_local", **kw):
                     out = head_fn(feat)
@@ -157,35 +163,57 @@ class GraphedForward:
                 self._keep += _tensors_in(keep())     # packed weights the graphs recorded pointers into
             torch.cuda.synchronize(dev)
 
-    def _settle(self, j: int) -> None:
-        """Check the range flag of the batch slot j ran last; recompute the batch in bf16x3 if it is set."""
-        if not self.unsettled[j]:
-            return
-        self.unsettled[j] = False
-        dest, self.pending_dest[j] = self.pending_dest[j], None
-        if self.flag_dev[j] is None:
-            return
-        self.done[j].synchronize()
-        if int(self.flag_host[j][0]) == 0:
-            return
+    RING = 16     # range-guard bookkeeping: calls that may be in flight with their flag unchecked
+
+    def _settle(self, entry, block: bool) -> bool:
+        """Check the range flag of one call in flight (block: wait for it); recompute its batch in bf16x3 if
+        the flag is set.  False = not finished yet (and not blocking)."""
+        c, j, src, dest = entry
+        ev = self.ev_ring[c % self.RING]
+        if block:
+            ev.synchronize()
+        elif not ev.query():
+            return False
+        if int(self.flag_ring[c % self.RING]) == 0:
+            return True
         self.range_fallbacks += 1
         lane = self.lanes[j] if self.pipeline else torch.cuda.current_stream(self.device)
         with torch.no_grad(), torch.cuda.stream(lane):
-            out = self.head_fn(self.guard.features_fallback(self.static_in[j]))
-            self.out[j].copy_(out)
+            x = self.static_in[j] if src is None else src.to(self.device, non_blocking=True)
+            out = self.head_fn(self.guard.features_fallback(x))
+            if self.slot_call[j] == c:            # the slot still holds this batch: its static output too
+                self.out[j].copy_(out)
             if dest is not None:
                 dest.copy_(out)
             self.done[j].record(lane)
+        return True
+
+    def _poll(self, need_slot: Optional[int] = None) -> None:
+        """Settle what has finished; block on the calls that must be settled before slot `need_slot` is
+        overwritten (their only source is the slot's input) and on the oldest ones when the ring is full."""
+        keep = []
+        for n, entry in enumerate(self.pending):
+            c, j, src, dest = entry
+            must = (need_slot is not None and j == need_slot and src is None) or \
+                   len(self.pending) - n > self.RING - 2
+            if not self._settle(entry, must):
+                keep.append(entry)
+        self.pending = keep
 
     @property
     def shape(self):
         return self.static_in[0].shape
 
     def __call__(self, x: Optional[torch.Tensor] = None, events=None,
-                 dest: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 dest: Optional[torch.Tensor] = None, stable_src: bool = True) -> torch.Tensor:
+        """stable_src=False: `x` is a buffer the caller will overwrite (a staging area): with the range guard
+        the batch is then checked before its slot is used again instead of being kept referenced."""
         j = self.calls % self.depth
+        c = self.calls
         self.calls += 1
-        self._settle(j)
+        guarded = self.flag_dev[j] is not None
+        if guarded:
+            self._poll(need_slot=j)
         main = torch.cuda.current_stream(self.device)
         if x is not None and (x.shape != self.static_in[j].shape or x.dtype != self.static_in[j].dtype):
             raise ValueError(f"graphed forward was captured for {tuple(self.static_in[j].shape)} "
@@ -199,15 +227,15 @@ class GraphedForward:
             self.g_backbone[j].replay()
             if events is not None:
                 events[1].record()
-            if self.flag_dev[j] is not None:
-                self.flag_host[j].copy_(self.flag_dev[j], non_blocking=True)
+            if guarded:
+                self.flag_ring[c % self.RING: c % self.RING + 1].copy_(self.flag_dev[j], non_blocking=True)
             self.g_head[j].replay()
             if dest is not None:
                 dest.copy_(self.out[j], non_blocking=True)
-            if self.flag_dev[j] is not None:      # one lane: the result is final when the call returns
-                self.done[j].record(main)
-                self.unsettled[j], self.pending_dest[j] = True, dest
-                self._settle(j)
+            self.slot_call[j] = c
+            if guarded:                           # one lane: the result is final when the call returns
+                self.ev_ring[c % self.RING].record(main)
+                self._settle((c, j, None, dest), True)
             return self.out[j]
         lane = self.lanes[j]
         if x is not None:
@@ -235,20 +263,25 @@ class GraphedForward:
             self.bb_done[j].record(lane)
             if events is not None:
                 events[1].record(lane)
-            if self.flag_dev[j] is not None:
-                self.flag_host[j].copy_(self.flag_dev[j], non_blocking=True)
+            if guarded:
+                self.flag_ring[c % self.RING: c % self.RING + 1].copy_(self.flag_dev[j], non_blocking=True)
             self.g_head[j].replay()
             if dest is not None:
                 dest.copy_(self.out[j], non_blocking=True)
             self.done[j].record(lane)
-        self.unsettled[j], self.pending_dest[j] = True, dest
+            if guarded:
+                self.ev_ring[c % self.RING].record(lane)
+        self.slot_call[j] = c
+        if guarded:
+            self.pending.append((c, j, x if (x is not None and stable_src) else None, dest))
         return self.out[j]
 
     def wait(self) -> None:
         """Make the current stream wait for every batch (and hand-off copy) launched so far.  With the f16mx
         range guard this first checks the flags of the batches in flight (the host waits for them)."""
-        for j in range(self.depth):
-            self._settle(j)
+        for entry in self.pending:
+            self._settle(entry, True)
+        self.pending = []
         if self.pipeline:
             main = torch.cuda.current_stream(self.device)
             for ev in self.done:
@@ -457,7 +490,7 @@ def extract_descriptors(model, data_loader, vlad=True, pca=None, gpu=None, print
                 if fwd is not None:
                     if last_fwd is not None and last_fwd is not fwd:
                         last_fwd.wait()               # another shape's lanes: keep the order simple
-                    out = fwd(imgs, dest=dst)
+                    out = fwd(imgs, dest=dst, stable_src=slot is None)   # (a staged batch's buffer is reused)
                     if slot is not None:
                         stage.mark(slot, fwd.last_stream)
                     last_fwd = fwd

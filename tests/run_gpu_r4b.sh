@@ -13,7 +13,4 @@ grep -E "^(FAILED|ERROR)|passed|failed" $OUT/pytest_gpu.log | tail -n 40
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke exit $?" | tee -a $OUT/smoke.log
 timeout 900 python bench.py --skip-cpu-baseline 2> $OUT/bench_err.log | tee $OUT/bench.json | cut -c1-700
 tail -n 3 $OUT/bench_err.log
-timeout 600 python tests/gpu_bar1_ab.py --reps 24 2>&1 | grep -v amdgpu.ids | tee $OUT/bar1_ab.log
 timeout 600 python tests/gpu_latency.py $OUT/latency.md 2>&1 | grep -v amdgpu.ids | tee $OUT/latency.log
-timeout 300 python tests/gpu_shardbench.py 1,8 f16mx 2>&1 | grep -v amdgpu.ids | tee -a $OUT/shardbench.log
-timeout 300 python tests/gpu_shardbench.py 1,8 bf16 2>&1 | grep -v amdgpu.ids | tee -a $OUT/shardbench.log

@@ -1,0 +1,64 @@
+#!/bin/bash
+# One GPU call per evidence set (round 4): full GPU parity suite, smoke, the bench line (f16mx headline), the
+# self-launched 2-rank flow check, per-layer timing, single-image latency (f16mx now split-K), shard projection
+# with the exchange emulated, a sustained run with clock / power, rocprofv3 kernel stats (f16mx, bf16, matching),
+# the HBM PMC passes for f16mx AND bf16, and the MFMA-busy / L2-hit / LDS-conflict PMC passes (f16mx step +
+# matching).  Everything lands in gpurun_out/<tag>/; tools/prof_summary.py + tools/pmc_summary.py condense it.
+# usage: tests/run_gpu_round4.sh <tag> [quick]
+cd "$(dirname "$0")/.."
+R=$(pwd)
+TAG=${1:-r04}
+QUICK=${2:-}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+export PYTHONDONTWRITEBYTECODE=1
+rocm-smi --showproductname 2>/dev/null | head -8 > $OUT/gpu.txt
+if [ -z "$QUICK" ]; then
+  timeout 1500 python -m pytest tests -m gpu -q --tb=short --timeout 600 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1
+  echo "pytest exit $?" | tee -a $OUT/pytest_gpu.log
+  tail -n 5 $OUT/pytest_gpu.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke exit $?" | tee -a $OUT/smoke.log
+fi
+timeout 900 python bench.py 2> $OUT/bench_err.log | tee $OUT/bench.json | cut -c1-400
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 \
+  bench.py --gpus 1 --steps 10 --warmup 3 --skip-cpu-baseline --skip-api 2> $OUT/bench_torchrun_err.log | tee $OUT/bench_torchrun.json | cut -c1-300
+OIBL_BENCH_SHARED_GPU=1 timeout 600 python bench.py --gpus 2 --steps 5 --warmup 2 --skip-cpu-baseline --skip-api \
+  2> $OUT/bench_2ranks_shared_err.log | tee $OUT/bench_2ranks_shared.json | cut -c1-300
+timeout 600 python tests/gpu_precbench.py 2>&1 | grep -v amdgpu.ids | tee $OUT/precbench.log
+if [ -z "$QUICK" ]; then
+  timeout 600 python tests/gpu_latency.py $OUT/latency.md 2>&1 | grep -v amdgpu.ids | tee $OUT/latency.log
+  for p in f16mx bf16x3 bf16; do
+    timeout 300 python tests/gpu_shardbench.py 1,2,4,8 $p 2>&1 | grep -v amdgpu.ids | tee -a $OUT/shardbench.log
+  done
+  timeout 200 python tests/gpu_mfma_peak.py 6 $OUT/mfma_peak.md 2>&1 | grep -v amdgpu.ids | tee $OUT/mfma_peak.log
+  timeout 300 python bench.py --sustain 12 --precision f16mx 2>> $OUT/bench_err.log > $OUT/sustain_f16mx.json
+  timeout 300 python bench.py --sustain 12 --precision bf16 2>> $OUT/bench_err.log > $OUT/sustain_bf16.json
+  timeout 120 python tests/gpu_mx_stamps.py 2>&1 | grep -v amdgpu.ids | tee $OUT/mx_stamps.log
+  timeout 120 python tests/gpu_stem_mx_bench.py 0 2>&1 | grep -v amdgpu.ids | tee $OUT/stem_mx.log
+fi
+cd /tmp && export TMPDIR=/tmp
+# --no-pipeline: one lane, so that the per-kernel durations are those of the roofline's span leg
+SKIP="--no-pipeline --skip-matching --skip-cpu-baseline --skip-api --skip-fast-mode"
+for p in f16mx bf16; do
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_$p -o bench -- python $R/bench.py --precision $p --steps 40 --warmup 5 $SKIP > $OUT/prof_stats_$p.log 2>&1
+done
+if [ -z "$QUICK" ]; then
+  for p in f16mx bf16; do
+    timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch_$p -o bench -- python $R/bench.py --precision $p --steps 5 --warmup 2 $SKIP > $OUT/prof_fetch_$p.log 2>&1
+    timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write_$p -o bench -- python $R/bench.py --precision $p --steps 5 --warmup 2 $SKIP > $OUT/prof_write_$p.log 2>&1
+  done
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_match -o bench -- python $R/bench.py --steps 2 --warmup 1 --skip-cpu-baseline --skip-api > $OUT/prof_match.log 2>&1
+  # MFMA busy / clock / L2 hit / LDS bank conflicts per kernel (tools/pmc_summary.py): counters only, separate passes
+  CMD="python $R/bench.py --precision f16mx --steps 3 --warmup 1 --eager --skip-cpu-baseline --skip-api --skip-fast-mode"
+  i=0
+  for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+             "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
+    i=$((i+1))
+    timeout 400 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -o pmc -- $CMD > $OUT/p$i.log 2>&1
+    tail -1 $OUT/p$i.log
+  done
+fi
+cd $R
+# keep the merged output small: drop per-dispatch traces larger than 8 MiB
+find $OUT -type f -size +8M -print -delete
+find $OUT -type f | wc -l

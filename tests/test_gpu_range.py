@@ -187,3 +187,52 @@ def test_matching_marks_out_of_range_rows(dev):
     assert np.abs(d.numpy()[:, keep] - want[:, keep]).max() < 2e-5
     pr = ops.PreparedRows(g2.to(dev), "f16mx")
     assert torch.isinf(pr.norms[7]) and torch.isfinite(pr.norms[keep]).all()
+
+
+def test_extract_features_reruns_only_the_flagged_batches(dev, state_dict):
+    """The replayed two-lane extraction (ibl.evaluators.extract_features) with the guard in its non-blocking
+    form: batches in flight are polled, a flagged one is recomputed in bf16x3 from the loader's (pinned) batch
+    into its rows of the output matrix — pinned and pageable (staged) batches, overflowing and ordinary ones
+    mixed; bit-identical to the eager batch-by-batch route."""
+    import torch.distributed as dist
+    from openibl_amd import evaluators as ev
+    from openibl_amd.extract import _GRAPH_STORES, unwrap_model
+    mine = not dist.is_initialized()
+    if mine:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1)
+    try:
+        _extract_flow(dev, state_dict, ev, _GRAPH_STORES, unwrap_model)
+    finally:
+        if mine:
+            dist.destroy_process_group()
+
+
+def _extract_flow(dev, state_dict, ev, _GRAPH_STORES, unwrap_model):
+    sd = _scaled(state_dict, 2000.0)
+    model = _model(sd, dev)
+
+    class Loader:
+        def __init__(self, batches):
+            self.batches = batches
+            self.sampler = range(sum(int(b[0].shape[0]) for b in batches))
+
+        def __iter__(self):
+            return iter(self.batches)
+
+        def __len__(self):
+            return len(self.batches)
+
+    big = {1, 2, 5, 8}                                     # these batches leave the fp16 range
+    batches = []
+    for k in range(10):
+        x = synth.images(3, 64, 96, seed=900 + k) * (2000.0 if k in big else 1.0)
+        batches.append((x.pin_memory() if k % 3 else x, [f"b{k}_{i}" for i in range(3)]))   # every third one pageable
+    names = [(f, 0, 0.0, 0.0) for b in batches for f in b[1]]
+    feats = ev.extract_features(model, Loader(batches), names, gpu=dev.index)
+    fwd = next(iter(_GRAPH_STORES[unwrap_model(model)][1].values()))
+    # batch 0 runs eagerly, batch 1 is captured (its warm-up runs eagerly); replays: batches 1..9
+    assert fwd.range_fallbacks == len(big) and not fwd.pending
+    before = model.base_model.range_fallbacks
+    eager = torch.cat([ev.extract_cnn_feature(model, b[0], gpu=dev.index).cpu() for b in batches])
+    assert model.base_model.range_fallbacks - before == len(big)
+    assert torch.equal(torch.stack(list(feats.values())), eager)
