@@ -183,16 +183,28 @@ def time_extraction(c, model, x, precision, steps, warmup, eager=False, pipeline
     span_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
     # launches inside the span and their algorithmic FLOPs (2 flop per MAC of the convolution; the
     # hi/lo split of bf16x3 is an implementation detail of the arithmetic, not more algorithm)
+    extra = 0
     if precision in ("bf16", "bf16x3", "f16mx"):
-        # conv1_1 + conv1_2 + pool are ONE launch (the fused stem) and the span starts with it
-        launches, fl = 12, (igemm_flops_per_image() + conv11_flops_per_image()) * batch
+        # conv1_1 + conv1_2 + pool are ONE launch (the fused stem) and the span starts with it; a layer whose
+        # last round is contracted split-K (f16mx: conv5_x at batch 32) is three launches: full rounds,
+        # split remainder, reduction
+        if precision == "f16mx":
+            from openibl_amd import lib as _l, ops as _o
+            hh, ww = HEIGHT // 2, WIDTH // 2
+            for (cin, cout, _relu, pool) in _o.VGG16_CFG[2:]:
+                if _l.load().oibl_conv3x3_workspace_bytes(batch, hh, ww, cin, cout, pool, _o.F16MX) > 0:
+                    extra += 2
+                if pool:
+                    hh, ww = hh // 2, ww // 2
+        launches, fl = 12 + extra, (igemm_flops_per_image() + conv11_flops_per_image()) * batch
         kernel = {"bf16": "oibl::vgg_stem_kernel (conv1_1+conv1_2+pool) + oibl::conv3x3_ring_kernel "
                           "(conv2_1..conv5_3), 12 launches/step",
                   "bf16x3": "oibl::vgg_stem_x3_kernel (conv1_1+conv1_2+pool) + oibl::conv3x3_ring_kernel<..., RING_X3> "
                             "(conv2_1..conv5_3), 12 launches/step",
                   "f16mx": "oibl::vgg_stem_x3_kernel<MX> (conv1_1 in bf16x3 + conv1_2 in f16mx + pool) + "
                            "oibl::conv3x3_ring_kernel<..., RING_MX> (conv2_x, conv4_x, conv5_x) + "
-                           "oibl::conv3x3_halo_kernel (conv3_x), 12 launches/step"}[precision]
+                           "oibl::conv3x3_halo_kernel (conv3_x): 12 layers in %d launches/step (conv5_x: full round "
+                           "+ split-K remainder + oibl::conv_mx_splitk_reduce_kernel)" % (12 + extra)}[precision]
     elif fwd is not None:
         # fp32: the replayed backbone graph holds conv1_1 too: 13 launches inside the span
         launches, fl = 13, (igemm_flops_per_image() + conv11_flops_per_image()) * batch
@@ -211,7 +223,9 @@ def time_extraction(c, model, x, precision, steps, warmup, eager=False, pipeline
             ent = tdata.get(precision) if isinstance(tdata.get(precision), dict) else \
                 (tdata if precision == "bf16" and "bytes_per_launch" in tdata else None)
             if ent:
-                traffic, traffic_src = round(float(ent["bytes_per_launch"])), ent["source"]
+                # per launch like `achieved`: the digest's bytes per forward over this run's launch count
+                per = float(ent["bytes_per_forward"]) / launches if "bytes_per_forward" in ent else float(ent["bytes_per_launch"])
+                traffic, traffic_src = round(per), ent["source"]
         except Exception:
             traffic = None
     roof = {

@@ -399,6 +399,11 @@ int oibl_first_hit_rank(const int32_t* topk_idx, int m, int k, const int32_t* gt
 int oibl_cluster_means(const float* x, const int32_t* labels, int n, int d, int num_clusters,
                        float* centers, int32_t* counts, void* stream);
 
+/* n 32-bit words src -> dst, by a kernel (one workgroup) on `stream`: dst may be pinned (host-coherent)
+ * memory mapped into the device — how the f16mx range flag reaches the host behind a replayed graph without a
+ * DMA-engine copy that would queue behind the next batch's input transfer. */
+int oibl_copy_words(const void* src, void* dst, int n, void* stream);
+
 /* ---- diagnostics ------------------------------------------------------------------ */
 
 /* Elapsed milliseconds between two recorded hipEvent_t (HOST pointer ms_host) — also when the events

@@ -230,6 +230,14 @@ __global__ __launch_bounds__(512) void mfma_peak_kernel(long iters, float* out) 
 }
 #endif
 
+// n 32-bit words src -> dst by a KERNEL (one workgroup): for the f16mx range flag's trip to pinned host memory.
+// A hipMemcpyAsync of the same 4 bytes queues on a DMA engine behind whatever that engine is moving — next
+// to a 118 MB input copy of the following batch it held the lane up by milliseconds (-7 % through
+// extract_features from fp32 host batches); a kernel's store to host-coherent memory does not.
+__global__ void copy_words_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int n) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+
 }  // namespace oibl
 
 using namespace oibl;
@@ -254,6 +262,15 @@ int oibl_debug_set_regstage(int on) {
   return OIBL_OK;
 }
 #endif
+
+int oibl_copy_words(const void* src, void* dst, int n, void* stream) {
+  OIBL_REQUIRE(src && dst && n > 0, "copy_words: bad arguments");
+  OIBL_REQUIRE((uintptr_t)src % 4 == 0 && (uintptr_t)dst % 4 == 0, "copy_words: unaligned pointer");
+  hipLaunchKernelGGL(copy_words_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint32_t*)src,
+                     (uint32_t*)dst, n);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
 
 int oibl_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_host) {
   OIBL_REQUIRE(ev_start && ev_stop && ms_host, "event_elapsed: null pointer");

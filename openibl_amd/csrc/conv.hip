@@ -770,7 +770,7 @@ static int launch_conv_ring(const ConvParams& p, hipStream_t st, const RingSub* 
       return g_ring_bar1 ? launch_conv_ring_impl<WM, POOL, true, P, false, true>(p, st)
                          : launch_conv_ring_impl<WM, POOL, true>(p, st);
   }
-  if constexpr (P == RING_BF16 || P == RING_X3 || P == RING_MX_EARLY) {
+  if constexpr (P == RING_BF16 || P == RING_X3 || P == RING_MX_EARLY || P == RING_MX) {
     if (g_ring_bar1) return launch_conv_ring_impl<WM, POOL, false, P, (P >= RING_MX), true>(p, st, sub);
   }
   return launch_conv_ring_impl<WM, POOL, false, P>(p, st, sub);

@@ -228,7 +228,7 @@ class GraphedForward:
             if events is not None:
                 events[1].record()
             if guarded:
-                self.flag_ring[c % self.RING: c % self.RING + 1].copy_(self.flag_dev[j], non_blocking=True)
+                ops.flag_to_host(self.flag_dev[j], self.flag_ring, c % self.RING)
             self.g_head[j].replay()
             if dest is not None:
                 dest.copy_(self.out[j], non_blocking=True)
@@ -264,7 +264,7 @@ class GraphedForward:
             if events is not None:
                 events[1].record(lane)
             if guarded:
-                self.flag_ring[c % self.RING: c % self.RING + 1].copy_(self.flag_dev[j], non_blocking=True)
+                ops.flag_to_host(self.flag_dev[j], self.flag_ring, c % self.RING)
             self.g_head[j].replay()
             if dest is not None:
                 dest.copy_(self.out[j], non_blocking=True)

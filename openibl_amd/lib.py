@@ -101,6 +101,7 @@ SIGNATURES = {
     "oibl_gemm_nt": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t,
                              c_void_p]),
     "oibl_event_elapsed_ms": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "oibl_copy_words": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
 }
 # test hooks: exported ONLY by libopenibl_amd_dbg.so (the same sources compiled with -DOIBL_DEBUG_HOOKS);
 # the value after the signature is the default the hook is reset to between tests (None: no reset)

@@ -670,6 +670,17 @@ def first_hit_rank(topk_idx: torch.Tensor, gt_offsets: torch.Tensor, gt_values: 
     return out
 
 
+def flag_to_host(flag_dev: torch.Tensor, ring: torch.Tensor, index: int) -> None:
+    """The int32 device word `flag_dev` -> word `index` of the PINNED host tensor `ring`, by a kernel on the
+    current stream (oibl_copy_words: no DMA-engine copy to queue behind a large input transfer).  The host
+    reads ring[index] once an event recorded behind this call has fired."""
+    dev = _need_cuda(flag_dev)
+    if not ring.is_pinned() or ring.dtype != torch.int32 or flag_dev.dtype != torch.int32:
+        raise ValueError("flag_to_host: ring must be a pinned int32 host tensor, the flag an int32 device tensor")
+    _lib.check(_lib.load().oibl_copy_words(_ptr(flag_dev), ring.data_ptr() + 4 * int(index), 1, _stream(dev)),
+               "copy_words")
+
+
 def event_elapsed_ms(start: "torch.cuda.Event", stop: "torch.cuda.Event") -> float:
     """hipEventElapsedTime on the raw handles — works for events recorded by the event nodes of a
     replayed hipGraph, which torch's own bookkeeping does not see."""

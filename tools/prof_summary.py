@@ -69,7 +69,7 @@ def main():
                     "over gloo (not a performance number)\n"
                     + "\n".join(l[:600] for l in (d / "bench_2ranks_shared.json").read_text().splitlines()
                                 if l.startswith("{")) + "\n\n")
-        for n in ("gpu.txt", "precbench.log", "mx_stamps.log", "mx_probe.log", "timing_bf16x3.log", "timing_bf16.log", "timing_bf16x3_raster1.log",
+        for n in ("gpu.txt", "precbench.log", "bar1_ab.log", "stem_mx.log", "mx_stamps.log", "mx_probe.log", "timing_bf16x3.log", "timing_bf16.log", "timing_bf16x3_raster1.log",
                   "timing_bf16_raster1.log", "timing_fp32.log", "pcie.log", "convbench.log", "shardbench.log"):
             if (d / n).exists():
                 f.write(f"==== {n}\n" + (d / n).read_text() + "\n")
@@ -169,19 +169,27 @@ def traffic_table(fp, wp, prof, tag, prec):
         (prof / (f"{tag}_hbm_traffic_{prec}.md" if prec else f"{tag}_hbm_traffic.md")).write_text("\n".join(lines) + "\n")
         # machine-readable digest for bench.py's roofline.traffic: corrected HBM bytes of the
         # matrix-core convolution launches, averaged per launch
-        tot_b, tot_n = 0.0, 0
+        tot_b, tot_n, forwards = 0.0, 0, 0
         for k, (n, v, t) in fe.items():
             if not any(tag_ in k for tag_ in ("conv3x3_ring_kernel", "conv3x3_halo_kernel", "mx_pack_rows_kernel", "vgg_stem_kernel",
-                                              "vgg_stem_x3_kernel", "conv3x3_igemm_kernel", "conv3x3_c64_kernel")):
+                                              "vgg_stem_x3_kernel", "conv3x3_igemm_kernel", "conv3x3_c64_kernel",
+                                              "conv_mx_splitk_reduce_kernel", "conv_splitk_reduce_kernel")):
                 continue
             w = wr.get(k, [1, 0.0, 1])
             tot_b += 2 * v * 1024 + w[1] * 1024 * (n / max(w[0], 1))
             tot_n += n
+            if "vgg_stem" in k:
+                forwards += n          # one fused stem launch per forward
         if tot_n:
             name = f"{tag}_hbm_traffic_{prec}.md" if prec else f"{tag}_hbm_traffic.md"
-            return {"source": f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
-                              "FETCH doubled per MI355X_MICROARCH.md; counts Infinity-Cache hits)",
-                    "conv_launches": tot_n, "bytes_per_launch": tot_b / tot_n}
+            ent = {"source": f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                             "FETCH doubled per MI355X_MICROARCH.md; counts Infinity-Cache hits)",
+                   "conv_launches": tot_n, "bytes_per_launch": tot_b / tot_n}
+            if forwards:
+                ent["forwards"] = forwards
+                ent["bytes_per_forward"] = tot_b / forwards
+                ent["launches_per_forward"] = tot_n / forwards
+            return ent
     return None
 
 
