@@ -179,12 +179,17 @@ int oibl_nchw_f32_to_nhwc(const float* x, int N, int C, int P, int precision, vo
 /* The same backbone fed with the loader's RAW image: x_nhwc [N][H][W][3] uint8 (what
  * PIL / cv2 decode to), ToTensor + Normalize (ibl/utils/data/__init__.py:37-42:
  * (u / 255 - mean) / std, fp32) folded into the first kernel.  mean3_host / std3_host: 3 floats
- * each, HOST pointers.  Results are bit-identical to oibl_vgg16_conv5_forward on the normalised
- * fp32 tensor; the host -> device copy shrinks 4x (0.9 MB instead of 3.7 MB per 480x640 image).
+ * each, HOST pointers.  The host -> device copy shrinks 4x (0.9 MB instead of 3.7 MB per 480x640 image).
  * OIBL_BF16: the fused stem looks the normalised bf16 operand up in a 3 x 257 table built with
- * exactly that arithmetic; OIBL_F32 (and shapes the stem does not take): a normalising
- * uint8 -> fp32 NCHW pass into the workspace, then the regular path.  ev_*: optional hipEvent_t
- * recorded around the matrix-core launches (as oibl_vgg16_conv5_forward_ev), may be NULL.      */
+ * exactly that arithmetic — bit-identical to oibl_vgg16_conv5_forward on the normalised fp32 tensor.
+ * OIBL_BF16X3 / OIBL_F16MX: the fused stems gather the bytes themselves (three 12-byte loads per window)
+ * and evaluate Normalize as ONE fma per value, u * 1/(255 std) - mean/std: within 2^-16 of the loader's
+ * three rounded operations on values up to 151 (identical bf16 hi parts of conv1_1's operand for all 768
+ * (channel, byte) pairs, 42 lo parts one unit apart) — the conv5_3 map is within ~1e-6 (bf16x3) / ~1e-5
+ * (f16mx: the size of its own rounding) of the fp32-input result, not bit-identical.
+ * OIBL_F32 (and shapes the stems do not take): a normalising uint8 -> fp32 NCHW pass into the workspace,
+ * then the regular path (bit-identical).  ev_*: optional hipEvent_t recorded around the matrix-core
+ * launches (as oibl_vgg16_conv5_forward_ev), may be NULL.      */
 size_t oibl_vgg16_u8_workspace_bytes(int N, int H, int W, int precision);
 int oibl_vgg16_conv5_forward_u8(const uint8_t* x_nhwc, int N, int H, int W, const float* mean3_host,
                                 const float* std3_host, const void* const* packed_w_host,

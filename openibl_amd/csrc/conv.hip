@@ -1479,6 +1479,7 @@ constexpr int ST_LDS_BYTES_U8 = ST_LDS_BYTES + 1552;
 constexpr int ST_BLOCKS = (ST_HALO_PX + 31) / 32;    // 11 blocks of 32 halo pixels
 constexpr unsigned ST_OOB = 0xF0000000u;
 OIBL_HOOK(int, g_stem_fused, 1);
+OIBL_HOOK(int, g_stem_u8, 1);     // test hook: 0 = uint8 input of the bf16x3 / f16mx stems through the normalising pass
 OIBL_HOOK(int, g_stem3_prio, 0);  // bf16x3 stem, test hook: producer issue priority | consumer priority << 2
 
 struct StemParams {
@@ -1948,7 +1949,21 @@ constexpr int S3_LDS_BYTES = S3_BIAS_OFF + 256 + 128;
 //     registers (a workgroup's 32 output channels are exactly one group);
 //   * conv1_2's weights are the packed f16mx tensor of oibl_pack_conv3x3_weights(OIBL_F16MX).
 // conv1_1 itself stays split bf16 (K = 27: 6 MFMAs per 32 pixels x 32 channels, a quarter of a pass).
-template <bool MX>
+// U8 = true: the input is the loader's raw uint8 NHWC image (StemParams::x [N][H][W][3]).  The producers gather
+// a pixel's 3 x 3 x 3 window as THREE 12-byte loads (one per window row: 9 consecutive bytes = 3 pixels x RGB,
+// fetched from the enclosing aligned dwords and shifted into place), the K slots of conv1_1 then follow the
+// bytes — (ky, kx, c) order, the lower lane half the first 16 of the 27, the upper half the rest — and
+// ToTensor + Normalize become ONE fma per value: v = u * a_c + b_c with a_c = 1 / (255 std_c), b_c =
+// -mean_c / std_c (StemParams::mean = a, ::stdv = b, rounded from double on the host).  That is NOT the loader's
+// three rounded operations (u / 255 - mean) / std, but within 2^-16 of them on values up to 151 — the rounding
+// the loader's own intermediate carries (u / 255 - mean is rounded at magnitude <= 1, then scaled by 255); over
+// all 768 (channel, byte) pairs the bf16 hi parts conv1_1 multiplies are identical and 42 lo parts differ by one
+// unit (tests/test_stem_u8_cpu.py, exhaustive) — far inside the arithmetic's own error.  (The
+// exact route, a 3 x 257 table of split values as in the bf16 stem, needs 3 KB of LDS: this kernel has 1.6 KB
+// left; three exactly rounded operations per value are ~110 more VALU instructions per tile and lane on the
+// role that is already issue-bound.)  Out-of-image taps are zeroed AFTER the normalisation (conv1_1 pads the
+// normalised tensor), from a 27-bit validity mask per lane, on border tiles only.
+template <bool MX, bool U8 = false>
 __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const wl = smem;                 // [pass h][tap][32 cout][32 hi | 32 lo of input channels 32h..]
@@ -2012,6 +2027,10 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
           const int idx = 8 * s + e;
           k = idx < (half ? 12 : 15) ? (idx / 3 + (half ? 5 : 0)) * 3 + idx % 3 : 27;
         }
+        if (U8) {   // slot 8 s + e of lane half `half` = window byte idx in (ky, kx, c) order; w1 is [c][ky][kx]
+          const int idx = 16 * half + 8 * s + e;
+          k = idx < 27 ? (idx % 3) * 9 + (idx / 9) * 3 + (idx % 9) / 3 : 27;
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int ch = MX ? 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3) : l31;   // channel of row l31
@@ -2072,12 +2091,65 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
     };
     float xv[1][16];
     int xfix[1] = {0};   // f16mx, image edge: 1 = this pixel's rows were fetched from x (not x - 1), 2 = from x - 2
+    // U8: the three window rows as fetched (aligned dwords), the byte shift of row 0, the validity mask of the
+    // 27 taps (border tiles) and whether the tile in flight is a border tile
+    unsigned xr[3][3] = {}, xsh = 0, xmask = 0;
+    bool xborder = false;
+    // per-lane Normalize constants in slot order: slot s of this lane half is channel (s + half) % 3
+    float ka[3] = {0.f, 0.f, 0.f}, kb[3] = {0.f, 0.f, 0.f};
+    if constexpr (U8) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        ka[i] = half ? p.mean[(i + 1) % 3] : p.mean[i];
+        kb[i] = half ? p.stdv[(i + 1) % 3] : p.stdv[i];
+      }
+    }
     auto issue_loads = [&](int tile) __attribute__((always_inline)) {
       int n, ty, tx;
       decode(tile, n, ty, tx);
       const int y0 = ty * 8 - 1, x0 = tx * 32 - 1;
       const int origin = ((n * 3) * p.H + y0) * p.W + x0;
-      if constexpr (MX) {
+      if constexpr (U8) {
+        const bool interior = is_interior(ty, tx);
+        xborder = !interior;
+        if (has_block) {
+          constexpr int bi = 0;
+          // byte offset of the window's first byte: pixel (y - 1, x - 1), channel 0 (negative at the image's
+          // first pixels: the unsigned offset is then out of range and the load returns zeros)
+          const int b0 = ((n * p.H + y0) * p.W + x0 + g_rel[bi] - p.W - 1) * 3;
+          xsh = (unsigned)b0 & 3u;
+          bool in = true, ya = true, yc = true;
+          if (!interior) {
+            int hy, hx;
+            hyx_of(bi, hy, hx);
+            const int y = y0 + hy, x = x0 + hx;
+            in = y >= 0 && y < p.H && x >= 0 && x < p.W;
+            ya = y > 0;
+            yc = y + 1 < p.H;
+            const bool xa = x > 0, xc = x + 1 < p.W;
+            // bit ky * 9 + kx * 3 + c: the tap is inside the image
+            const unsigned rows = (ya ? 0x1ffu : 0u) | 0x3fe00u | (yc ? 0x7fc0000u : 0u);
+            const unsigned cols = (xa ? 0x0040201u * 7u : 0u) | (0x0040201u * 7u << 3) | (xc ? 0x0040201u * 7u << 6 : 0u);
+            xmask = in ? rows & cols : 0u;
+          }
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            const int offs = (b0 + ky * 3 * p.W) & ~3;
+            unsigned off = (unsigned)offs;
+            bool early = false;   // the tensor's very first pixel: its row starts 3 bytes before the tensor
+            if (!interior) {
+              const bool ok = in && (ky == 0 ? ya : ky == 2 ? yc : true);
+              early = ok && offs < 0;
+              off = !ok ? ST_OOB : early ? 0u : off;
+            }
+            const auto d = __builtin_amdgcn_raw_buffer_load_b96(rs_x, (int)off, 0, 0);
+            const unsigned d0 = d[0], d1 = d[1], d2 = d[2];   // (elements through scalars: see the f16mx branch)
+            xr[ky][0] = early ? 0u : d0;          // (fetched from 0: one dword late)
+            xr[ky][1] = early ? d0 : d1;
+            xr[ky][2] = early ? d1 : d2;
+          }
+        }
+      } else if constexpr (MX) {
         // The 3 x 3 x 3 window as nine ROWS (c, ky) of three consecutive pixels x - 1 .. x + 1: five 12-byte
         // loads per lane (the lower lane half rows 0-4, the upper half rows 5-8 and row 8 once more under zero
         // weights) instead of sixteen 4-byte ones — the sixteen were ~3k cycles of the texture path per tile.
@@ -2163,7 +2235,40 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
 #pragma unroll
       for (int bi = 0; bi < 1; ++bi) {
         if (!has_block) continue;
-        if constexpr (MX) {
+        if constexpr (U8) {
+          // each row's 9 window bytes shifted into place: w[ky][0..1] = bytes 0-7, w[ky][2] byte 0 = byte 8
+          const unsigned w3 = (unsigned)(3 * p.W) & 3u;
+          unsigned w[3][3];
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            const unsigned sh = (xsh + ky * w3) & 3u;
+            w[ky][0] = __builtin_amdgcn_alignbyte(xr[ky][1], xr[ky][0], sh);
+            w[ky][1] = __builtin_amdgcn_alignbyte(xr[ky][2], xr[ky][1], sh);
+            w[ky][2] = xr[ky][2] >> (8u * sh);
+          }
+          // the 16 bytes of this lane half: lower = row 0 bytes 0-8, row 1 bytes 0-6; upper = row 1 bytes 7-8,
+          // row 2 bytes 0-8, five slots under zero weights (any finite value)
+          const unsigned a2 = __builtin_amdgcn_perm(w[1][0], w[0][2], 0x06050400u);
+          const unsigned a3 = __builtin_amdgcn_alignbyte(w[1][1], w[1][0], 3u);
+          const unsigned t = __builtin_amdgcn_perm(w[1][2], w[1][1], 0x00000403u);
+          const unsigned b0 = __builtin_amdgcn_perm(w[2][0], t, 0x05040100u);
+          const unsigned b1 = __builtin_amdgcn_alignbyte(w[2][1], w[2][0], 2u);
+          const unsigned b2 = __builtin_amdgcn_alignbyte(w[2][2], w[2][1], 2u) & 0x00ffffffu;
+          int hsel = half;
+          asm volatile("" : "+v"(hsel));
+          const unsigned dw[4] = {hsel ? b0 : w[0][0], hsel ? b1 : w[0][1], hsel ? b2 : a2, hsel ? 0u : a3};
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const float u = (float)((dw[j >> 2] >> (8 * (j & 3))) & 0xffu);   // v_cvt_f32_ubyteN
+            xv[bi][j] = fmaf(u, ka[j % 3], kb[j % 3]);
+          }
+          if (xborder) {   // wave-uniform: zero the taps outside the image (conv1_1 pads the NORMALISED tensor)
+            const unsigned mk = xmask >> (hsel ? 16 : 0);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) xv[bi][j] = ((mk >> j) & 1u) ? xv[bi][j] : 0.f;
+          }
+        }
+        if constexpr (MX && !U8) {
           if (__builtin_amdgcn_ballot_w64(xfix[bi] != 0) != 0) {   // an image edge inside this block (rare)
             const bool left = xfix[bi] == 1, right = xfix[bi] == 2;
 #pragma unroll
@@ -2752,18 +2857,28 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
   }
 }
 
-static int launch_vgg_stem_x3(const float* x, int N, int H, int W, const float* w1, const float* b1,
+// u8_mean3 / u8_std3 (host pointers, both or neither): x is the raw uint8 NHWC image and the kernel normalises
+// (vgg_stem_x3_kernel, U8)
+static int launch_vgg_stem_x3(const void* x, int N, int H, int W, const float* w1, const float* b1,
                               const void* packed_w2, const float* b2, void* out, hipStream_t st,
-                              bool mx = false, unsigned* range_flag = nullptr) {
+                              bool mx = false, unsigned* range_flag = nullptr, const float* u8_mean3 = nullptr,
+                              const float* u8_std3 = nullptr) {
   StemParams p = {};
   p.range_flag = range_flag;
+  const bool u8 = u8_mean3 != nullptr && u8_std3 != nullptr;
+  if (u8) {
+    for (int c = 0; c < 3; ++c) {   // v = u * a + b (see the kernel): a in `mean`, b in `stdv`
+      p.mean[c] = (float)(1.0 / (255.0 * (double)u8_std3[c]));
+      p.stdv[c] = (float)(-(double)u8_mean3[c] / (double)u8_std3[c]);
+    }
+  }
   p.x = x;
   p.w1 = w1;
   p.b1 = b1;
   p.w2 = (const char*)packed_w2;
   p.b2 = b2;
   p.out = (char*)out;
-  p.x_bytes = (unsigned)((size_t)N * 3 * H * W * 4);
+  p.x_bytes = (unsigned)((size_t)N * 3 * H * W * (u8 ? 1 : 4));
   p.N = N;
   p.H = H;
   p.W = W;
@@ -2778,8 +2893,16 @@ static int launch_vgg_stem_x3(const float* x, int N, int H, int W, const float* 
   p.prod_prio = (mx && g_stem3_prio == 0) ? 14 : g_stem3_prio;
   int gx = 128;  // two workgroups (output-channel halves) per tile range: one persistent workgroup per CU
   if (gx > p.ntiles) gx = p.ntiles;
-  if (mx) {
+  if (mx && u8) {
+    auto kern = vgg_stem_x3_kernel<true, true>;
+    OIBL_SET_MAX_LDS(kern, S3_LDS_BYTES);
+    hipLaunchKernelGGL(kern, dim3(gx, 2), dim3(1024), S3_LDS_BYTES, st, p);
+  } else if (mx) {
     auto kern = vgg_stem_x3_kernel<true>;
+    OIBL_SET_MAX_LDS(kern, S3_LDS_BYTES);
+    hipLaunchKernelGGL(kern, dim3(gx, 2), dim3(1024), S3_LDS_BYTES, st, p);
+  } else if (u8) {
+    auto kern = vgg_stem_x3_kernel<false, true>;
     OIBL_SET_MAX_LDS(kern, S3_LDS_BYTES);
     hipLaunchKernelGGL(kern, dim3(gx, 2), dim3(1024), S3_LDS_BYTES, st, p);
   } else {
@@ -3063,6 +3186,13 @@ int oibl_debug_set_conv_korder(int mode) {
 #endif
 
 #ifdef OIBL_DEBUG_HOOKS
+int oibl_debug_set_stem_u8(int on) {
+  g_stem_u8 = on ? 1 : 0;
+  return OIBL_OK;
+}
+#endif
+
+#ifdef OIBL_DEBUG_HOOKS
 int oibl_debug_set_mx_splitk(int on) {
   g_mx_splitk = on ? 1 : 0;
   return OIBL_OK;
@@ -3327,7 +3457,13 @@ static int vgg_forward_impl(const void* x, int u8, const float* mean3, const flo
   const bool fused = precision == OIBL_BF16 && g_stem_fused && stem_eligible(N, H, W) &&
                      !g_regstage && !g_conv_ablate;
   const float* x_f32 = (const float*)x;
-  if (u8 && !fused) {  // normalise into the fp32 staging area behind the activation buffers
+  const bool mx = precision == OIBL_F16MX;
+  const bool fused3 = (precision == OIBL_BF16X3 || mx) && g_stem_fused && stem_eligible(N, H, W) && !g_regstage &&
+                      !g_conv_ablate && g_conv_tile == 0;
+  // uint8 input: every fused stem normalises inside the kernel (g_stem_u8 = 0, test hook: the 4-byte stems
+  // take the normalising pass below instead)
+  const bool u8_fused3 = u8 && fused3 && g_stem_u8;
+  if (u8 && !fused && !u8_fused3) {  // normalise into the fp32 staging area behind the activation buffers
     float* stage = (float*)((char*)ws + base_need);
     const long npix = (long)N * H * W;
     hipLaunchKernelGGL(u8_nhwc_to_nchw_f32_kernel, dim3(2048), dim3(256), 0, st, (const uint8_t*)x,
@@ -3336,9 +3472,6 @@ static int vgg_forward_impl(const void* x, int u8, const float* mean3, const flo
     OIBL_LAUNCH_CHECK();
     x_f32 = stage;
   }
-  const bool mx = precision == OIBL_F16MX;
-  const bool fused3 = (precision == OIBL_BF16X3 || mx) && g_stem_fused && stem_eligible(N, H, W) && !g_regstage &&
-                      !g_conv_ablate && g_conv_tile == 0;
   // f16mx has no unfused front (Cout = 64 fits no f16mx tile): conv1_2's weights are packed for the stem
   OIBL_REQUIRE(!mx || fused3, "vgg16: the f16mx backbone needs the fused stem (input below 3.5 GB, no stem / tile hooks)");
   // ... and only 32-bit-offset kernels behind it: the largest activation they read is conv2_2's input
@@ -3348,8 +3481,10 @@ static int vgg_forward_impl(const void* x, int u8, const float* mean3, const flo
   if (fused3) {
     // bf16x3 / f16mx: conv1_1 + conv1_2 + pool in one launch (the uint8 entry has normalised into x_f32)
     if (ev_igemm_begin) OIBL_HIP_CHECK(hipEventRecord((hipEvent_t)ev_igemm_begin, st));
-    rc = launch_vgg_stem_x3(x_f32, N, H, W, (const float*)packed_w_host[0], bias_host[0], packed_w_host[1],
-                            bias_host[1], bufB, st, mx, range_flag);
+    rc = u8_fused3 ? launch_vgg_stem_x3(x, N, H, W, (const float*)packed_w_host[0], bias_host[0], packed_w_host[1],
+                                        bias_host[1], bufB, st, mx, range_flag, mean3, std3)
+                   : launch_vgg_stem_x3(x_f32, N, H, W, (const float*)packed_w_host[0], bias_host[0], packed_w_host[1],
+                                        bias_host[1], bufB, st, mx, range_flag);
     if (rc) return rc;
     h /= 2;
     w /= 2;

@@ -350,7 +350,8 @@ def vgg16_conv5(x: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequen
     """conv5_3 feature map [N][h][w][512] T (NHWC), h = H//16, w = W//16, of
       x [N][3][H][W] float32, already normalised (what the reference's loader hands over), or
       x [N][H][W][3] uint8, the raw decoded image: ToTensor + Normalize(mean, std) are folded into
-        the first kernel (bit-identical results, a quarter of the bytes over PCIe).
+        the first kernel (a quarter of the bytes over PCIe; bit-identical results in bf16 / fp32, within
+        ~1e-6 / ~1e-5 of the fp32-input result in bf16x3 / f16mx: include/openibl_amd.h).
 
     weights[0] is the plain conv1_1 tensor, weights[1:] come from pack_conv3x3.
     `events`: optional pair of already-recorded torch.cuda.Event(enable_timing=True); they are
