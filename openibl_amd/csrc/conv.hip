@@ -2878,7 +2878,10 @@ static int launch_vgg_stem_x3(const void* x, int N, int H, int W, const float* w
   p.w2 = (const char*)packed_w2;
   p.b2 = b2;
   p.out = (char*)out;
-  p.x_bytes = (unsigned)((size_t)N * 3 * H * W * (u8 ? 1 : 4));
+  // (uint8: the descriptor covers the tensor rounded up to whole dwords — the 12-byte window loads are dword
+  //  aligned, and the range check drops a dword that is only partly inside; the up to 3 extra bytes share the
+  //  last valid byte's dword, hence its page, and are never used: the taps they belong to are masked)
+  p.x_bytes = u8 ? (unsigned)align_up((size_t)N * 3 * H * W, 4) : (unsigned)((size_t)N * 3 * H * W * 4);
   p.N = N;
   p.H = H;
   p.W = W;
@@ -2913,6 +2916,8 @@ static int launch_vgg_stem_x3(const void* x, int N, int H, int W, const float* w
   OIBL_LAUNCH_CHECK();
   return OIBL_OK;
 }
+
+__global__ void clear_word_kernel(unsigned* w) { *w = 0u; }
 
 // uint8 NHWC -> normalised fp32 NCHW with the loader's arithmetic ((u / 255 - mean) / std, fp32,
 // correctly rounded divisions): the route of the uint8 entry point whenever the fused stem is not
@@ -3448,8 +3453,14 @@ static int vgg_forward_impl(const void* x, int u8, const float* mean3, const flo
   char* splitk = vgg_splitk_bytes(N, H, W, precision) ? bufB + align_up(eb * es, 256) : nullptr;
   hipStream_t st = (hipStream_t)stream;
   // f16mx: the pass starts with a clear range flag; every packer of the pass may raise it (common.h)
+  // (cleared by a one-thread KERNEL: a hipMemsetAsync of 4 bytes goes to a DMA engine and, replayed inside a
+  //  graph, waited there behind the next batch's 118 MB input copy — extract_features from fp32 host batches
+  //  lost 8 % to it)
   unsigned* const range_flag = precision == OIBL_F16MX ? (unsigned*)ws : nullptr;
-  if (range_flag) OIBL_HIP_CHECK(hipMemsetAsync(range_flag, 0, sizeof(unsigned), st));
+  if (range_flag) {
+    hipLaunchKernelGGL(clear_word_kernel, dim3(1), dim3(1), 0, st, range_flag);
+    OIBL_LAUNCH_CHECK();
+  }
 
   int rc;
   int h = H, w = W, l0 = 1;

@@ -27,7 +27,9 @@ def _u8_and_normalised(N, H, W, seed):
     return u8, x.contiguous()
 
 
-@pytest.mark.parametrize("precision,tol_stem", [("bf16x3", 2e-6), ("f16mx", 3e-5)])
+# (42 of the 768 (channel, byte) pairs hand conv1_1 a lo part one unit apart: ~1e-6 on its output, ~1e-5 on the
+#  conv5_3 map twelve layers later; the two f16mx routes additionally round their lines independently)
+@pytest.mark.parametrize("precision,tol_stem", [("bf16x3", 3e-5), ("f16mx", 6e-5)])
 @pytest.mark.parametrize("N,H,W", [(2, 64, 96), (1, 70, 90), (3, 37, 53), (1, 16, 16), (1, 480, 640), (2, 33, 131)])
 def test_uint8_stems_against_the_normalised_input(dev, state_dict, precision, tol_stem, N, H, W):
     import hubconf

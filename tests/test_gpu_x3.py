@@ -179,7 +179,7 @@ def test_embednetpca_x3_vs_fp64_oracle(model, dev, state_dict):
 def test_x3_graphed_and_uint8(model, dev):
     """hipGraph replay (both pipeline slots) reproduces the eager forward bit for bit; so does the uint8 entry
     through the normalising pass (test hook) — the fused uint8 stem (the default since round 4: Normalize as
-    one fma per value, tests/test_gpu_u8.py) is within 2e-6 of it."""
+    one fma per value, tests/test_gpu_u8.py) is within 2e-5 of it."""
     from ibl.utils.data import MEAN, STD
     from openibl_amd import lib
     g = torch.Generator().manual_seed(3)
@@ -188,7 +188,7 @@ def test_x3_graphed_and_uint8(model, dev):
     std = torch.tensor(STD, dtype=torch.float32).view(1, 3, 1, 1)
     x = ((u8.permute(0, 3, 1, 2).float() / 255.0 - mean) / std).to(dev)
     want = model(x).clone()
-    assert rel_l2(model(u8.to(dev)).cpu(), want.cpu()) < 2e-6
+    assert rel_l2(model(u8.to(dev)).cpu(), want.cpu()) < 2e-5
     lib.debug_hooks().oibl_debug_set_stem_u8(0)
     try:
         assert torch.equal(model(u8.to(dev)), want)

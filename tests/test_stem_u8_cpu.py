@@ -65,14 +65,19 @@ def _lane_slots(img, y, x, half):
     """What one producer lane (halo pixel (y, x) inside the image) hands conv1_1: 16 bytes in slot order, and
     the 27-bit validity mask, following vgg_stem_x3_kernel<., true> step by step."""
     H, W, _ = img.shape
-    flat = np.concatenate([img.reshape(-1), np.zeros(16, dtype=np.uint8)])
+    flat = np.concatenate([img.reshape(-1), np.full(16, 77, dtype=np.uint8)])   # (whatever follows the tensor)
 
-    def load96(off):                      # raw_buffer_load_b96 at a dword-aligned offset; out of range -> zeros
-        if off < 0 or off >= img.size:
+    records = (img.size + 3) & ~3         # the descriptor covers the tensor rounded up to whole dwords
+
+    def load96(off):                      # raw_buffer_load_b96 at a dword-aligned offset: a dword that is not
+        if off < 0:                       # wholly inside num_records reads as zero
             return [0, 0, 0]
-        b = flat[off:off + 12].astype(np.uint64)
-        b = np.where(np.arange(off, off + 12) < img.size, b, 0)
-        return [int(b[4 * i] | b[4 * i + 1] << 8 | b[4 * i + 2] << 16 | b[4 * i + 3] << 24) for i in range(3)]
+        out = []
+        for i in range(3):
+            o = off + 4 * i
+            b = flat[o:o + 4].astype(np.uint64) if o + 4 <= records else np.zeros(4, dtype=np.uint64)
+            out.append(int(b[0] | b[1] << 8 | b[2] << 16 | b[3] << 24))
+        return out
 
     b0 = ((y - 1) * W + (x - 1)) * 3
     xsh = b0 & 3
@@ -107,7 +112,7 @@ def _lane_slots(img, y, x, half):
 
 def test_window_bytes_reach_their_k_slots_for_every_alignment_and_border():
     rng = np.random.default_rng(7)
-    for (H, W) in ((9, 13), (8, 32), (5, 6), (12, 7)):          # 3 * W mod 4 = 3, 0, 2, 1
+    for (H, W) in ((9, 13), (8, 32), (5, 6), (12, 7), (3, 5)):   # 3 * W mod 4 = 3, 0, 2, 1; sizes 3, 0, 2, 0, 1 mod 4
         img = rng.integers(1, 256, size=(H, W, 3), dtype=np.uint8)   # no zero bytes: a zeroed tap is visible
         for y in range(H):
             for x in range(W):
