@@ -38,6 +38,8 @@ from . import ops
 
 __all__ = ["GraphedForward", "extract_descriptors", "unwrap_model", "release_graphs", "MAX_CACHED_SHAPES"]
 
+GUARD_REPLAYS = True      # diagnostic switch (tests/gpu_api_guard_ab.py): False = replayed forwards do not check the
+                          # f16mx range flag (the eager path still does)
 MAX_CACHED_SHAPES = 3     # captured (shape, dtype) entries kept per extraction (each owns its
                           # activation workspaces: ~2.5 GB for 32 x 480x640 in bf16)
 
@@ -118,7 +120,7 @@ class GraphedForward:
         self.done = [torch.cuda.Event() for _ in range(self.depth)]
         self.g_backbone, self.g_head, self.out = [], [], []
         self._keep = []
-        if range_guard is None:
+        if range_guard is None and GUARD_REPLAYS:
             owner = getattr(backbone_fn, "__self__", None)
             if hasattr(owner, "last_range_flag") and hasattr(owner, "features_fallback"):
                 range_guard = owner
