@@ -265,13 +265,14 @@ class GraphedForward:
             self.bb_done[j].record(lane)
             if events is not None:
                 events[1].record(lane)
-            if guarded:
-                ops.flag_to_host(self.flag_dev[j], self.flag_ring, c % self.RING)
             self.g_head[j].replay()
             if dest is not None:
                 dest.copy_(self.out[j], non_blocking=True)
             self.done[j].record(lane)
             if guarded:
+                # behind the head and the hand-off (the flag stays valid until this lane's next backbone clears
+                # it): nothing sits between the two graph launches of a batch
+                ops.flag_to_host(self.flag_dev[j], self.flag_ring, c % self.RING)
                 self.ev_ring[c % self.RING].record(lane)
         self.slot_call[j] = c
         if guarded:
