@@ -326,7 +326,7 @@ def time_matching(c, precision, Q, G, msteps=10):
     # local top-k then runs in query blocks whose exchange + merge overlap the next block's matrix work.
     gp = ops.PreparedRows(g, precision)
     qs, qper, _ = sharded.slice_bounds(Q, c.rank, c.world)
-    q_local = torch.stack([q[(qs + i) % Q] for i in range(qper)]) if c.world > 1 else q
+    q_local = q[(qs + torch.arange(qper, device=dev)) % Q].contiguous() if c.world > 1 else q   # (wrapped slice)
     blocks = 2 if c.world > 1 else 1
 
     def step():
