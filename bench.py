@@ -295,7 +295,9 @@ def time_api(c, model, precision, batch, n_batches, u8):
         base = ((base * std + mean) * 255.0).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
     pinned = [base.roll(s, 0).contiguous().pin_memory() for s in range(3)]
     names = [(f"im{i:06d}.jpg", i, 0.0, 0.0) for i in range(n_batches * batch)]
-    extract_features(model, _MemLoader(pinned, 3), names[: 3 * batch], print_freq=10 ** 9, gpu=c.dev.index)
+    # one untimed pass of the timed length: captures the graphs, and pays what a process pays once on this path
+    # (the first pass from freshly pinned fp32 batches measured 5-8 % below the following ones)
+    extract_features(model, _MemLoader(pinned, n_batches), names, print_freq=10 ** 9, gpu=c.dev.index)
     torch.cuda.synchronize(c.dev)
     t0 = time.perf_counter()
     feats = extract_features(model, _MemLoader(pinned, n_batches), names, print_freq=10 ** 9, gpu=c.dev.index)
