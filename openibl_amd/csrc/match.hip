@@ -838,6 +838,7 @@ extern "C" {
 OIBL_HOOK(int, g_match_ring, 1);  // test hook: 0 = never, 1 = auto, 2 = whenever legal
 OIBL_HOOK(int, g_match_group, 4);  // test hook: query tiles per ordering group of the ring kernel
 OIBL_HOOK(int, g_match_splitk, 1);  // test hook: 0 = never split the threshold sample's contraction
+OIBL_HOOK(int, g_match_mx_early, 0);  // test hook: f16mx distances with the LDS-DMA issue in the LOAD segments (as the convolutions)
 OIBL_HOOK(int, g_match_bar1, 1);    // test hook: 0 = two barriers per phase in the ring kernel (ring_core.h, BAR1: 1 = 0-2.5 % faster)
 
 #ifdef OIBL_DEBUG_HOOKS
@@ -847,6 +848,10 @@ int oibl_debug_set_match_splitk(int on) {
 }
 int oibl_debug_set_match_bar1(int on) {
   g_match_bar1 = on ? 1 : 0;
+  return OIBL_OK;
+}
+int oibl_debug_set_match_mx_early(int on) {
+  g_match_mx_early = on ? 1 : 0;
   return OIBL_OK;
 }
 #endif
@@ -1007,7 +1012,8 @@ static int pairwise_launch(const void* xo, const void* yo, const float* xn, cons
         q.m = pr;
         q.n = pc;
         q.d = d;
-        const int rc = launch_pairwise_ring<false, RING_MX>(q, st);
+        const int rc = g_match_mx_early ? launch_pairwise_ring<false, RING_MX_EARLY>(q, st)
+                                        : launch_pairwise_ring<false, RING_MX>(q, st);
         if (rc) return rc;
       }
     return OIBL_OK;
@@ -1218,7 +1224,8 @@ static int sqdist_topk_core(const void* xo, const float* xn, int m, const void* 
       q.part_stride = half;
       q.yn_max = (unsigned*)(cnt + m);
     }
-    rc = mx   ? launch_pairwise_ring<false, RING_MX>(q, st, t.ksplit)
+    rc = mx   ? (g_match_mx_early ? launch_pairwise_ring<false, RING_MX_EARLY>(q, st, t.ksplit)
+                                  : launch_pairwise_ring<false, RING_MX>(q, st, t.ksplit))
          : x3 ? launch_pairwise_ring<false, RING_X3>(q, st, t.ksplit)
               : launch_pairwise_ring<false>(q, st, t.ksplit);
     if (rc) return rc;
@@ -1243,7 +1250,8 @@ static int sqdist_topk_core(const void* xo, const float* xn, int m, const void* 
     q.cap = t.cap;
     q.index_base = index_base;
     q.index_stride = 1;
-    rc = mx   ? launch_pairwise_ring<true, RING_MX>(q, st)
+    rc = mx   ? (g_match_mx_early ? launch_pairwise_ring<true, RING_MX_EARLY>(q, st)
+                                  : launch_pairwise_ring<true, RING_MX>(q, st))
          : x3 ? launch_pairwise_ring<true, RING_X3>(q, st)
               : launch_pairwise_ring<true>(q, st);
     if (rc) return rc;
