@@ -39,6 +39,11 @@ CXXFLAGS = [
 ]
 
 
+# compile-time experiments ride in the DEBUG library only (a script times the same layer through the product
+# library and through this one): round 4: the f16mx fragment tail as one ds_read_b128 instead of b64 + b32
+DBG_EXPERIMENT_FLAGS = ["-DOIBL_MX_TAIL_B128"]
+
+
 def _hipcc() -> str:
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not Path(exe).exists():
@@ -123,7 +128,7 @@ def _build_locked(verbose: bool) -> Path:
         src, obj, dbg = job
         # -Rpass-analysis: the compiler's per-kernel register / scratch / LDS report, kept next to the
         # objects (build/resource_usage.json; tests/test_abi.py holds the hot kernels to their budgets)
-        cmd = [hipcc, *CXXFLAGS, *(["-DOIBL_DEBUG_HOOKS"] if dbg else []),
+        cmd = [hipcc, *CXXFLAGS, *(["-DOIBL_DEBUG_HOOKS", *DBG_EXPERIMENT_FLAGS] if dbg else []),
                "-Rpass-analysis=kernel-resource-usage", "-c", str(src), "-o", str(obj)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

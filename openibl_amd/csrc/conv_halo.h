@@ -89,8 +89,13 @@ __device__ static inline void halo_phase_mma(f32x16_t& acc0, f32x16_t& acc1, con
     auto mx = [&](f32x16_t& acc, int i2) __attribute__((always_inline)) {
       const i32x8_t a8 = __builtin_shufflevector(__builtin_bit_cast(i4, fa[i2][2]), __builtin_bit_cast(i4, fa[i2][3]),
                                                  0, 1, 2, 3, 4, 5, 6, 7);
-      acc = SWAP ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8, a8, acc, 2, 2, 0, b8[6], 0, a8[6])
-                 : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc, 2, 2, 0, a8[6], 0, b8[6]);
+#ifdef OIBL_MX_TAIL_B128
+      constexpr int SC = 7;   // (ring_core.h)
+#else
+      constexpr int SC = 6;
+#endif
+      acc = SWAP ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8, a8, acc, 2, 2, 0, b8[SC], 0, a8[SC])
+                 : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc, 2, 2, 0, a8[SC], 0, b8[SC]);
     };
     f16(acc0, 0, 0);
     f16(acc1, 1, 0);
@@ -242,6 +247,7 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloParams& p, char* sme
 
   bf16x8_t fa[2][4], fbx[4], fby[4];
   auto ld_frag = [&](const char* a, int kk) __attribute__((always_inline)) -> bf16x8_t {
+#ifndef OIBL_MX_TAIL_B128
     if constexpr (MX) {
       if (kk == 3) {
         typedef __attribute__((ext_vector_type(2))) unsigned u2;   // (not uint2: see ring_core.h, read_frag)
@@ -251,6 +257,7 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloParams& p, char* sme
         return __builtin_bit_cast(bf16x8_t, (u4){d.x, d.y, sc, 0u});
       }
     }
+#endif
     return *reinterpret_cast<const bf16x8_t*>(a);
   };
   auto read_a = [&](int hb, auto h_c, auto tap_c) __attribute__((always_inline)) {

@@ -1,6 +1,7 @@
 // Query x gallery squared-L2 distance matrix and per-row top-k on gfx950.
 // Reference behaviour: pairwise_distance (ibl/evaluators.py:105-130) and the argsort consumed by
 // evaluate_all (ibl/evaluators.py:142-159).
+#undef OIBL_MX_TAIL_B128   // the distance kernels have no registers for the 16-byte tail (ring_core.h)
 #include "gemm_core.h"
 #include "ring_core.h"
 
@@ -838,7 +839,9 @@ extern "C" {
 OIBL_HOOK(int, g_match_ring, 1);  // test hook: 0 = never, 1 = auto, 2 = whenever legal
 OIBL_HOOK(int, g_match_group, 4);  // test hook: query tiles per ordering group of the ring kernel
 OIBL_HOOK(int, g_match_splitk, 1);  // test hook: 0 = never split the threshold sample's contraction
-OIBL_HOOK(int, g_match_mx_early, 0);  // test hook: f16mx distances with the LDS-DMA issue in the LOAD segments (as the convolutions)
+// f16mx distances: 1 = LDS-DMA issue in the LOAD segments (as the convolutions; the default since the one-barrier
+// schedule: 7.72-7.76 ms against 7.85-7.93 for 8192 x 81920 x 4096 + top-10, same bits), 0 = inside COMPUTE
+OIBL_HOOK(int, g_match_mx_early, 1);
 OIBL_HOOK(int, g_match_bar1, 1);    // test hook: 0 = two barriers per phase in the ring kernel (ring_core.h, BAR1: 1 = 0-2.5 % faster)
 
 #ifdef OIBL_DEBUG_HOOKS

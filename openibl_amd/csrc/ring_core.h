@@ -231,6 +231,7 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
   // (coalesced by the allocator); with a b128 tail the operand had to be re-assembled by copies into
   // fresh registers, ~20 VGPRs the distance kernels do not have.
   auto read_frag = [&](const char* s, int kk) __attribute__((always_inline)) -> bf16x8_t {
+#ifndef OIBL_MX_TAIL_B128
     if constexpr (MX) {
       if (kk == 3) {
         // (an ext_vector load, not HIP's uint2 struct: a struct load carries no TBAA, and the compiler
@@ -242,6 +243,7 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
         return __builtin_bit_cast(bf16x8_t, (u4){d.x, d.y, sc, 0u});
       }
     }
+#endif
     return *reinterpret_cast<const bf16x8_t*>(s + frag_off[kk]);
   };
   auto read_a = [&](int buf, int h) __attribute__((always_inline)) {
@@ -288,9 +290,14 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
         const i32x8_t a8 = __builtin_shufflevector(__builtin_bit_cast(i4, fa[i2][2]),
                                                    __builtin_bit_cast(i4, fa[i2][3]), 0, 1, 2, 3, 4, 5, 6, 7);
         // e2m3 x e2m3 (cbsz = blgp = 2); scales: byte 0 of dword 6 of either operand
+#ifdef OIBL_MX_TAIL_B128
+        constexpr int SC = 7;   // the tail slot read as one ds_read_b128: [d4 d5 0 scale]
+#else
+        constexpr int SC = 6;
+#endif
         acc[2 * h + i2][j] =
-            SWAP ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8, a8, acc[2 * h + i2][j], 2, 2, 0, b8[6], 0, a8[6])
-                 : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[2 * h + i2][j], 2, 2, 0, a8[6], 0, b8[6]);
+            SWAP ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8, a8, acc[2 * h + i2][j], 2, 2, 0, b8[SC], 0, a8[SC])
+                 : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[2 * h + i2][j], 2, 2, 0, a8[SC], 0, b8[SC]);
       };
       f16(0, 0);
       f16(1, 0);

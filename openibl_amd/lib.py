@@ -153,7 +153,7 @@ _HOOK_DEFAULTS = {"oibl_debug_set_regstage": 0, "oibl_debug_set_conv11_valu": 0,
                   "oibl_debug_set_conv_korder": -1, "oibl_debug_set_mx_variant": 0, "oibl_debug_set_conv_splitk": 1,
                   "oibl_debug_set_stem3_prio": 0, "oibl_debug_set_match_group": 4, "oibl_debug_set_match_splitk": 1,
                   "oibl_debug_set_pca_small": 1, "oibl_debug_set_netvlad_slabs": 1,
-                  "oibl_debug_set_ring_bar1": 1, "oibl_debug_set_match_bar1": 1, "oibl_debug_set_match_mx_early": 0, "oibl_debug_set_mx_splitk": 1, "oibl_debug_set_stem_u8": 1,
+                  "oibl_debug_set_ring_bar1": 1, "oibl_debug_set_match_bar1": 1, "oibl_debug_set_match_mx_early": 1, "oibl_debug_set_mx_splitk": 1, "oibl_debug_set_stem_u8": 1,
                   "oibl_debug_set_prof_buffer": None}
 
 
