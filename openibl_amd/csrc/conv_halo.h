@@ -73,7 +73,9 @@ struct HaloParams {
 template <int P, bool SWAP, typename Prep>
 __device__ static inline void halo_phase_mma(f32x16_t& acc0, f32x16_t& acc1, const bf16x8_t (&fa)[2][4],
                                              const bf16x8_t (&fb)[4], Prep&& prep, bool prio2 = false) {
+#ifdef OIBL_RING_LGKM0   // (ring_core.h, read_a: the compiler's counted waits instead)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
   __builtin_amdgcn_sched_barrier(0);
   if (prio2) __builtin_amdgcn_s_setprio(2);   // (BAR1, group 0, a compile-time constant at every call: ring_core.h)
   else __builtin_amdgcn_s_setprio(1);
@@ -122,6 +124,7 @@ __device__ static inline void halo_phase_mma(f32x16_t& acc0, f32x16_t& acc1, con
       mma(acc1, 1, pr, pr);
     }
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (P3's pre-read of the next B0: ring_core.h, compute)
   __builtin_amdgcn_s_setprio(0);
   __builtin_amdgcn_sched_barrier(0);
 }
@@ -269,14 +272,18 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloParams& p, char* sme
     int rp_ = row_pitch;
     asm volatile("" : "+s"(rp_));
     const int tapoff = hb * HALO_BYTES + dyi * rp_ + dxi * 128;
+    int a0[2];
 #pragma unroll
     for (int i2 = 0; i2 < 2; ++i2) {
-      int a0 = pre[h][i2][dxi];
-      asm volatile("" : "+v"(a0));   // (see above: keeps the XORed fragment addresses out of scratch)
-      a0 += tapoff;
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) fa[i2][kk] = ld_frag(smem + (a0 ^ ((kk << 5) ^ cdy)), kk);
+      a0[i2] = pre[h][i2][dxi];
+      asm volatile("" : "+v"(a0[i2]));   // (see above: keeps the XORed fragment addresses out of scratch)
+      a0[i2] += tapoff;
     }
+    // in the order the MFMAs consume them (k-chunk outer: ring_core.h, read_a)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2) fa[i2][kk] = ld_frag(smem + (a0[i2] ^ ((kk << 5) ^ cdy)), kk);
   };
   auto read_b = [&](int buf, int h, bf16x8_t (&f)[4]) __attribute__((always_inline)) {
     const char* s = rd_b + buf * HALO_B_TILE + h * G::B_UNIT;

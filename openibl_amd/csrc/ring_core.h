@@ -15,7 +15,7 @@
 //   * a K-tile is four PHASES, one per 64 x 32 quadrant of the wave's 128 x 64 accumulator
 //     (8 MFMAs 32x32x16 each).  Every phase is a LOAD segment (fragment ds_reads of the operand
 //     half that changes: 8, 4, 8, 4 reads; the LDS-DMA instructions of one unit; the counted wait)
-//     and a COMPUTE segment (lgkmcnt(0); 8 MFMAs), separated by raw s_barriers;
+//     and a COMPUTE segment (8 MFMAs behind counted lgkmcnt waits), separated by raw s_barriers;
 //   * the two stagger groups (waves 0-3 / 4-7: one wave of each on every SIMD) run ONE BARRIER
 //     APART: while one wave of a SIMD is in its COMPUTE segment the other is in its LOAD segment,
 //     so the matrix pipe of the SIMD always has a wave with operands in registers (s_setprio 1
@@ -27,8 +27,8 @@
 //     LOAD is still to come), each LOAD segment in the shadow of the partner's COMPUTE, and the barrier
 //     latency + arrival skew is paid once per 2 x COMPUTE instead of once per COMPUTE (with 6 MFMAs =
 //     192 pipe cycles per f16mx phase the two-barrier interval measured 245-277 cycles).  Hazards, with
-//     intervals counted like phases: the fragment reads of phase r are retired by the lgkmcnt(0) in front
-//     of C(r): in interval r (group 1) or at the head of interval r+1 (group 0) — a unit re-staged in
+//     intervals counted like phases: the fragment reads of phase r are retired inside C(r) (counted
+//     waits in front of the MFMAs that use them, lgkmcnt(0) behind the last one): in interval r (group 1) or at the head of interval r+1 (group 0) — a unit re-staged in
 //     L(q), q >= r+2, is issued in interval >= r+2 by either group: WAR as before.  A wait in L(w) is
 //     followed by barrier w in both groups (directly in group 0, behind C(w) in group 1); the reads of
 //     L(w+1) come after barrier w in both: RAW as before (read >= 1 phase after the retiring wait).
@@ -249,10 +249,21 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
   auto read_a = [&](int buf, int h) __attribute__((always_inline)) {
     if constexpr (P == RING_MX_NOREAD) return;
     const char* s = rd_a + buf * G::TILE + (h ? OFF_A1 : OFF_A0);
+    // Fragments in the order the MFMAs consume them (k-chunk outer), and NO lgkmcnt(0) in front of COMPUTE:
+    // the compiler's own counted waits (lgkmcnt(9), (8), (7), (6), (2), (0) in an f16mx A phase) let the first
+    // MFMAs start while the tails are still in flight.  +1.5 % on the f16mx layers, nothing in bf16, same bits
+    // (profiles/r04_h_lgkm_ab.txt; OIBL_RING_LGKM0 restores the row-outer order and the full wait).
+#ifndef OIBL_RING_LGKM0
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2) fa[i2][kk] = read_frag(s + i2 * 4096, kk);
+#else
 #pragma unroll
     for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) fa[i2][kk] = read_frag(s + i2 * 4096, kk);
+#endif
   };
   auto read_b = [&](int buf, int h, bf16x8_t (&f)[4]) __attribute__((always_inline)) {
     if constexpr (P == RING_MX_NOREAD) return;
@@ -263,7 +274,9 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
 
   auto compute = [&](auto h_c, auto j_c, const bf16x8_t (&fb)[4], auto&& issue) __attribute__((always_inline)) {
     constexpr int h = decltype(h_c)::value, j = decltype(j_c)::value;
+#ifdef OIBL_RING_LGKM0
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (BAR1 && GROUP == 0) {   // both groups compute inside one barrier interval: the one that still
       __builtin_amdgcn_s_setprio(2);      // has to LOAD goes first
@@ -328,6 +341,10 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
         for (int i2 = 0; i2 < 2; ++i2) mma(i2, kk, kk);
       }
     }
+    // every fragment read of this phase is retired INSIDE it (the WAR rule above counts on that): the ones this
+    // phase multiplies were waited for by its MFMAs, P3's pre-read of the next tile's B0 — issued a whole
+    // COMPUTE segment ago — is waited for here, behind the last MFMA's issue
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
   };

@@ -139,16 +139,21 @@ class VGG(_PrecisionMixin, nn.Module):
     def _convs(self) -> List[nn.Conv2d]:
         return [m for m in self.base if isinstance(m, nn.Conv2d)]
 
-    # Rounds 1-3 ran f16mx batches whose conv4 layers gave fewer than F16MX_MIN_TILES ring tiles in bf16x3
-    # (every Tokyo 24/7 query, every ragged last batch).  Since round 4 the f16mx ring kernels split K for
-    # layers that would leave the chip idle (csrc/conv.hip, mx_split_plan): the threshold is 0 — what was asked
-    # for is what runs — and only kept as a knob (set it to 256 for the old behaviour).
-    F16MX_MIN_TILES = 0
+    # Rounds 1-3 ran f16mx batches whose conv4 layers gave fewer than 256 ring tiles in bf16x3 (every Tokyo 24/7
+    # query, every ragged last batch).  Since round 4 the f16mx ring kernels split K for layers that would leave
+    # the chip idle (csrc/conv.hip, mx_split_plan) and a single 480x640 image runs f16mx in 0.82 ms (bf16x3:
+    # 0.95).  Below about 12 tiles of 256 conv4 pixels (one image of 384x384, three of 224x224) the split layers'
+    # extra launches cost more than the cheaper products save and bf16x3 — the other 1e-4 mode, three times as
+    # exact — is the faster of the two (profiles/r04_i_small_sizes.md: 0.50 against 0.62 ms at 224x224), so THAT
+    # is what such a batch runs in.  In ring tiles (256 pixels x 256 of the 512 channels): 24.  A knob: 0 = f16mx
+    # whenever it can run (the kernel tests), 256 = rounds 1-3.
+    F16MX_MIN_TILES = 24
 
     def effective_precision(self, x: torch.Tensor) -> str:
         """The arithmetic the backbone runs this input in: the module's precision, except for f16mx batches
-        beyond the 32-bit offsets of its kernels (95 images of 480x640 and more), which run in bf16x3 — and
-        F16MX_MIN_TILES, 0 by default.  `precision_runs` counts what actually ran."""
+        beyond the 32-bit offsets of its kernels (95 images of 480x640 and more) and for f16mx batches of fewer
+        than F16MX_MIN_TILES conv4 ring tiles (where it is the slower of the two 1e-4 modes), which run in
+        bf16x3.  `precision_runs` counts what actually ran."""
         p = self.precision
         if ops.precision_code(p) != ops.F16MX:
             return p

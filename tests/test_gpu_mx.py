@@ -336,15 +336,19 @@ def test_conv_mx_repeatable_under_load(dev):
 
 def test_small_batch_threshold_is_a_knob_and_off_by_default(dev, state_dict):
     """Rounds 1-3 served small f16mx batches in bf16x3 (F16MX_MIN_TILES = 256); the ring kernels now split K
-    for them (tests/test_gpu_splitk.py), so the threshold is 0.  Set, it still works as before — same bits as an
-    explicit bf16x3 model — and what actually ran is visible through effective_precision() / precision_runs."""
+    for them (tests/test_gpu_splitk.py) and the threshold is 24: only problems below 12 tiles of conv4 pixels,
+    where bf16x3 is the faster 1e-4 mode.  Set higher, it works as before — same bits as an explicit bf16x3
+    model — and what actually ran is visible through effective_precision() / precision_runs."""
     import hubconf
     m = hubconf.vgg16_netvlad(pretrained=False)
     m.load_state_dict(state_dict)
     m = m.to(dev).eval().set_precision("f16mx")
     one = synth.images(1, 480, 640, seed=3).to(dev)
     many = torch.empty((8, 3, 480, 640), device=dev)
-    assert m.base_model.effective_precision(one) == "f16mx"
+    assert m.base_model.effective_precision(one) == "f16mx"                      # 19 tiles of 256 pixels
+    small = synth.images(1, 224, 224, seed=4).to(dev)                                # 4 tiles
+    assert m.base_model.effective_precision(small) == "bf16x3"
+    assert m.base_model.effective_precision(torch.empty((4, 3, 224, 224), device="meta")) == "f16mx"   # 13
     m.base_model.F16MX_MIN_TILES = 256
     assert m.base_model.effective_precision(one) == "bf16x3"
     assert m.base_model.effective_precision(many) == "f16mx"

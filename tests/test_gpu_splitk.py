@@ -74,6 +74,7 @@ def test_small_batches_run_f16mx_and_match_the_oracle(dev, state_dict, n, H, W):
     model.load_state_dict(state_dict)
     model = model.to(dev).eval().set_precision("f16mx")
     vgg = model.base_model
+    vgg.F16MX_MIN_TILES = 0          # the kernels are the subject here, not the rule that picks the faster mode
     xd = x.to(dev)
     assert vgg.effective_precision(xd) == "f16mx"
     got = model(xd).clone()
