@@ -27,6 +27,7 @@ OIBL_BENCH_SHARED_GPU=1 timeout 600 python bench.py --gpus 2 --steps 5 --warmup 
 timeout 600 python tests/gpu_precbench.py 2>&1 | grep -v amdgpu.ids | tee $OUT/precbench.log
 if [ -z "$QUICK" ]; then
   timeout 600 python tests/gpu_latency.py $OUT/latency.md 2>&1 | grep -v amdgpu.ids | tee $OUT/latency.log
+  timeout 300 python tests/gpu_small_sizes.py $OUT/small_sizes.md 2>&1 | grep -v amdgpu.ids | tee $OUT/small_sizes.log
   for p in f16mx bf16x3 bf16; do
     timeout 300 python tests/gpu_shardbench.py 1,2,4,8 $p 2>&1 | grep -v amdgpu.ids | tee -a $OUT/shardbench.log
   done
@@ -48,6 +49,11 @@ if [ -z "$QUICK" ]; then
     timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write_$p -o bench -- python $R/bench.py --precision $p --steps 5 --warmup 2 $SKIP > $OUT/prof_write_$p.log 2>&1
   done
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_match -o bench -- python $R/bench.py --steps 2 --warmup 1 --skip-cpu-baseline --skip-api > $OUT/prof_match.log 2>&1
+  # where a single image's time goes (200 eager forwards each)
+  for cfg in "f16mx 480 640" "f16mx 224 224" "bf16x3 224 224"; do
+    set -- $cfg
+    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_single_$1_$2 -o one -- python $R/tests/gpu_small_sizes.py --loop $1 $2 $3 1 > $OUT/prof_single_$1_$2.log 2>&1
+  done
   # MFMA busy / clock / L2 hit / LDS bank conflicts per kernel (tools/pmc_summary.py): counters only, separate passes
   CMD="python $R/bench.py --precision f16mx --steps 3 --warmup 1 --eager --skip-cpu-baseline --skip-api --skip-fast-mode"
   i=0
