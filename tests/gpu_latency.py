@@ -54,6 +54,9 @@ def main():
                 r_med, r_min = med(lambda: fwd())
                 a_med, a_min = med(lambda: extract_cnn_feature(model, x_host))
                 del fwd
+            eff = model.base_model.effective_precision(x)      # (small f16mx problems run in bf16x3: models.py)
+            if eff != prec:
+                prec = f"{prec} (runs in {eff})"
             rows.append((f"{h}x{w}", prec, e_med, e_min, r_med, r_min, a_med, a_min))
             print(f"{h}x{w} {prec:7s} eager {e_med:7.3f} (min {e_min:.3f})  replay {r_med:7.3f} (min {r_min:.3f})  "
                   f"api {a_med:7.3f} (min {a_min:.3f}) ms", flush=True)
