@@ -964,7 +964,7 @@ struct MxSplitPlan {
   long m_base;      // first GEMM row of the split part
   long rows_part;   // GEMM rows of the split part
 };
-OIBL_HOOK(int, g_mx_splitk, 1);   // test hook: 0 = never split
+OIBL_HOOK(int, g_mx_splitk, 1);   // test hook: 0 = never split; 2 = split, reduced by conv_mx_splitk_reduce_kernel
 static MxSplitPlan mx_split_plan(long m_plain, int cin, int cout, int pool, int korder, int wm) {
   MxSplitPlan pl = {};
   pl.wm = wm;
@@ -1087,6 +1087,82 @@ __global__ void conv_mx_splitk_reduce_kernel(const float* __restrict__ partial, 
   }
 }
 
+// The same reduction with EIGHT threads per (output row, 32-channel group), four channels each: the sums are
+// formed by 8x as many threads as above with fully coalesced 16-byte loads (a single image's conv5_x has 19200
+// lines — 75 workgroups of one-thread-per-line, each thread a chain of 9 x 8 loads: the reduce kernels were 22 %
+// of a single image's forward, profiles/r04_j_single_image_kernels.md), then handed over through LDS to one
+// thread per line that packs and stores it (fp32 output: stored by the eight threads directly).  Same
+// operations in the same order per element as the kernel above: bit-identical (tests/test_gpu_splitk.py).
+constexpr int RED_LINES = 32;    // lines per workgroup pass = 256 threads / 8
+constexpr int RED_PITCH = 36;    // floats per staged line (16-byte aligned rows; a line's reader meets 4-way conflicts)
+template <bool POOL>
+__global__ __launch_bounds__(256) void conv_mx_splitk_reduce8_kernel(
+    const float* __restrict__ partial, const float* __restrict__ bias, char* __restrict__ out, long out_row0,
+    long out_rows_here, long rows_part, int cout, int s, int relu, int out_f32, int H, int W, unsigned* range_flag) {
+  __shared__ __attribute__((aligned(16))) float stage[RED_LINES * RED_PITCH];
+  const int groups = cout >> 5;
+  const long items = out_rows_here * groups;
+  const size_t part = (size_t)rows_part * cout;
+  const int Ho = H >> 1, Wo = W >> 1;
+  const int ln = threadIdx.x >> 3, k = threadIdx.x & 7;
+  for (long base = (long)blockIdx.x * RED_LINES; base < items; base += (long)gridDim.x * RED_LINES) {
+    const long it = base + ln;
+    const bool live = it < items;
+    const long r = live ? it / groups : 0;
+    const int g = live ? (int)(it - r * groups) : 0;
+    float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    if (live) {
+      const float4 b = *reinterpret_cast<const float4*>(bias + g * 32 + 4 * k);
+#pragma unroll
+      for (int q = 0; q < (POOL ? 4 : 1); ++q) {
+        long src = r;
+        if constexpr (POOL) {
+          const long n = r / ((long)Ho * Wo), rem = r - n * (long)Ho * Wo;
+          const int yo = (int)(rem / Wo), xo = (int)(rem - (long)yo * Wo);
+          src = (n * H + 2 * yo + (q >> 1)) * W + 2 * xo + (q & 1);
+        }
+        float4 a = b;
+        const float* pp = partial + (size_t)src * cout + g * 32 + 4 * k;
+        for (int ks = 0; ks < s; ++ks) {
+          const float4 t = *reinterpret_cast<const float4*>(pp + ks * part);
+          a.x += t.x;
+          a.y += t.y;
+          a.z += t.z;
+          a.w += t.w;
+        }
+        v = make_float4(fmaxf(v.x, a.x), fmaxf(v.y, a.y), fmaxf(v.z, a.z), fmaxf(v.w, a.w));
+      }
+      if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+    }
+    if (out_f32) {   // (uniform)
+      if (live) *reinterpret_cast<float4*>(out + ((size_t)(out_row0 + r) * cout + g * 32 + 4 * k) * 4) = v;
+      continue;
+    }
+    *reinterpret_cast<float4*>(&stage[ln * RED_PITCH + 4 * k]) = v;
+    __syncthreads();
+    if (threadIdx.x < RED_LINES && base + threadIdx.x < items) {
+      const long it2 = base + threadIdx.x;
+      const long r2 = it2 / groups;
+      const int g2 = (int)(it2 - r2 * groups);
+      float w[32];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float4 t = *reinterpret_cast<const float4*>(&stage[threadIdx.x * RED_PITCH + 4 * j]);
+        w[4 * j] = t.x;
+        w[4 * j + 1] = t.y;
+        w[4 * j + 2] = t.z;
+        w[4 * j + 3] = t.w;
+      }
+      uint4 line[8];
+      mx_pack_line(w, line, range_flag);
+      uint4* dst = reinterpret_cast<uint4*>(out + ((size_t)(out_row0 + r2) * cout + g2 * 32) * 4);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dst[j] = line[j];
+    }
+    __syncthreads();
+  }
+}
+
 // f16mx: ring kernels (Cin % 64 == 0, Cout % 128 == 0 — every layer of the backbone behind the stem).
 // g_mx_variant (test hook): 0 = that; 3 = the halo kernel (conv_halo.h) for the 256-channel-tile layers —
 // 0.58x the LDS-DMA bytes, +5 % on conv3_x, -5 % on conv4_x / conv5_x since the ring's K cursor left its
@@ -1124,6 +1200,20 @@ static int launch_conv_mx_split(const ConvParams& p, int pool, const MxSplitPlan
   const long out_row0 = pool ? 0 : pl.m_base;
   const long out_rows_here = pool ? p.out_rows : pl.rows_part;
   const long items = out_rows_here * (p.cout / 32);
+  if (g_mx_splitk != 2) {   // (2 = test hook: the one-thread-per-line reduction below)
+    unsigned blocks8 = (unsigned)((items + RED_LINES - 1) / RED_LINES);
+    if (blocks8 > 16384) blocks8 = 16384;
+    if (pool)
+      hipLaunchKernelGGL(conv_mx_splitk_reduce8_kernel<true>, dim3(blocks8), dim3(256), 0, st, p.partial, p.bias,
+                         (char*)p.out, out_row0, out_rows_here, pl.rows_part, p.cout, pl.s, p.relu, p.out_f32, p.H,
+                         p.W, p.range_flag);
+    else
+      hipLaunchKernelGGL(conv_mx_splitk_reduce8_kernel<false>, dim3(blocks8), dim3(256), 0, st, p.partial, p.bias,
+                         (char*)p.out, out_row0, out_rows_here, pl.rows_part, p.cout, pl.s, p.relu, p.out_f32, p.H,
+                         p.W, p.range_flag);
+    OIBL_LAUNCH_CHECK();
+    return OIBL_OK;
+  }
   unsigned blocks = (unsigned)((items + 255) / 256);
   if (blocks > 8192) blocks = 8192;
   if (pool)
@@ -3199,7 +3289,7 @@ int oibl_debug_set_stem_u8(int on) {
 
 #ifdef OIBL_DEBUG_HOOKS
 int oibl_debug_set_mx_splitk(int on) {
-  g_mx_splitk = on ? 1 : 0;
+  g_mx_splitk = on == 2 ? 2 : (on ? 1 : 0);
   return OIBL_OK;
 }
 #endif

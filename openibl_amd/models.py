@@ -142,12 +142,13 @@ class VGG(_PrecisionMixin, nn.Module):
     # Rounds 1-3 ran f16mx batches whose conv4 layers gave fewer than 256 ring tiles in bf16x3 (every Tokyo 24/7
     # query, every ragged last batch).  Since round 4 the f16mx ring kernels split K for layers that would leave
     # the chip idle (csrc/conv.hip, mx_split_plan) and a single 480x640 image runs f16mx in 0.82 ms (bf16x3:
-    # 0.95).  Below about 12 tiles of 256 conv4 pixels (one image of 384x384, three of 224x224) the split layers'
-    # extra launches cost more than the cheaper products save and bf16x3 — the other 1e-4 mode, three times as
-    # exact — is the faster of the two (profiles/r04_i_small_sizes.md: 0.50 against 0.62 ms at 224x224), so THAT
-    # is what such a batch runs in.  In ring tiles (256 pixels x 256 of the 512 channels): 24.  A knob: 0 = f16mx
-    # whenever it can run (the kernel tests), 256 = rounds 1-3.
-    F16MX_MIN_TILES = 24
+    # 0.95).  Below 8 tiles of 256 conv4 pixels (one image of 320x320, two of 224x224) the split layers' extra
+    # launches cost what the cheaper products save and bf16x3 — the other 1e-4 mode, three times as exact — is as
+    # fast or faster (profiles/r04_l_small_sizes.md: 0.49 against 0.51 ms at 224x224, 0.44 against 0.49 at
+    # 128x160; from 9 tiles on f16mx wins by 7 % and more), so THAT is what such a batch runs in.  In ring tiles
+    # (256 pixels x 256 of the 512 channels): 16.  A knob: 0 = f16mx whenever it can run (the kernel tests),
+    # 256 = rounds 1-3.
+    F16MX_MIN_TILES = 16
 
     def effective_precision(self, x: torch.Tensor) -> str:
         """The arithmetic the backbone runs this input in: the module's precision, except for f16mx batches

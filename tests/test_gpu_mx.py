@@ -336,7 +336,7 @@ def test_conv_mx_repeatable_under_load(dev):
 
 def test_small_batch_threshold_is_a_knob_and_off_by_default(dev, state_dict):
     """Rounds 1-3 served small f16mx batches in bf16x3 (F16MX_MIN_TILES = 256); the ring kernels now split K
-    for them (tests/test_gpu_splitk.py) and the threshold is 24: only problems below 12 tiles of conv4 pixels,
+    for them (tests/test_gpu_splitk.py) and the threshold is 16: only problems below 8 tiles of conv4 pixels,
     where bf16x3 is the faster 1e-4 mode.  Set higher, it works as before — same bits as an explicit bf16x3
     model — and what actually ran is visible through effective_precision() / precision_runs."""
     import hubconf

@@ -50,6 +50,11 @@ def test_split_layers_against_fp64_and_the_one_pass_kernel(dev, N, H, W, cin, co
     assert_rel_l2(f"split-K f16mx {N}x{H}x{W} {cin}->{cout}", got, want, TOL_LAYER)
     assert torch.equal(run(), y) and torch.equal(run(), y)          # fixed-order reduction: the same bits every time
     h = lib.debug_hooks()
+    h.oibl_debug_set_mx_splitk(2)                                    # the one-thread-per-line reduction: same bits
+    try:
+        assert torch.equal(ops.conv3x3_nhwc(xd, wp, bd, relu, pool, "f16mx"), y)
+    finally:
+        h.oibl_debug_set_mx_splitk(1)
     h.oibl_debug_set_mx_splitk(0)
     h.oibl_debug_set_mx_variant(1)                                   # the one-pass ring kernel
     try:

@@ -463,8 +463,8 @@ def test_public_surface_of_the_reference_is_present():
 def test_effective_precision_and_its_counters_host_side():
     """`VGG.effective_precision` is shape arithmetic (no device work): f16mx runs what was asked for from one
     480x640 image up since round 4 (the ring kernels split K), except beyond the 32-bit offsets of its kernels —
-    the largest activation they read is conv2_2's input, N (H/2) (W/2) 128 x 4 bytes — and below 12 tiles of 256
-    conv4 pixels, where bf16x3 is the faster 1e-4 mode (profiles/r04_i_small_sizes.md); the threshold is a knob.
+    the largest activation they read is conv2_2's input, N (H/2) (W/2) 128 x 4 bytes — and below 8 tiles of 256
+    conv4 pixels, where bf16x3 is the faster 1e-4 mode (profiles/r04_l_small_sizes.md); the threshold is a knob.
     uint8 NHWC inputs are sized the same way."""
     from openibl_amd import models
     m = models.create("vgg16", pretrained=False)
@@ -472,15 +472,16 @@ def test_effective_precision_and_its_counters_host_side():
         m.set_precision(p)
         assert m.effective_precision(torch.empty((1, 3, 480, 640), device="meta")) == p
     m.set_precision("f16mx")
-    assert m.F16MX_MIN_TILES == 24 and m.precision_runs == {} and m.range_fallbacks == 0
+    assert m.F16MX_MIN_TILES == 16 and m.precision_runs == {} and m.range_fallbacks == 0
     for n in (1, 2, 6, 7, 32, 94):
         assert m.effective_precision(torch.empty((n, 3, 480, 640), device="meta")) == "f16mx"
         assert m.effective_precision(torch.empty((n, 480, 640, 3), dtype=torch.uint8, device="meta")) == "f16mx"
     assert m.effective_precision(torch.empty((96, 3, 480, 640), device="meta")) == "bf16x3"
     assert m.effective_precision(torch.empty((96, 480, 640, 3), dtype=torch.uint8, device="meta")) == "bf16x3"
     assert m.effective_precision(torch.empty((24, 3, 960, 1280), device="meta")) == "bf16x3"
-    for shape, want in (((1, 3, 224, 224), "bf16x3"), ((3, 3, 224, 224), "bf16x3"), ((4, 3, 224, 224), "f16mx"),
-                        ((1, 3, 384, 384), "bf16x3"), ((1, 3, 480, 480), "f16mx"), ((1, 3, 64, 96), "bf16x3")):
+    for shape, want in (((1, 3, 224, 224), "bf16x3"), ((2, 3, 224, 224), "bf16x3"), ((3, 3, 224, 224), "f16mx"),
+                        ((1, 3, 320, 320), "bf16x3"), ((1, 3, 384, 384), "f16mx"), ((1, 3, 480, 480), "f16mx"),
+                        ((1, 3, 64, 96), "bf16x3")):
         assert m.effective_precision(torch.empty(shape, device="meta")) == want, shape
     m.F16MX_MIN_TILES = 0
     assert m.effective_precision(torch.empty((1, 3, 64, 96), device="meta")) == "f16mx"
