@@ -204,7 +204,7 @@ def time_extraction(c, model, x, precision, steps, warmup, eager=False, pipeline
                   "f16mx": "oibl::vgg_stem_x3_kernel<MX> (conv1_1 in bf16x3 + conv1_2 in f16mx + pool) + "
                            "oibl::conv3x3_ring_kernel<..., RING_MX> (conv2_x, conv4_x, conv5_x) + "
                            "oibl::conv3x3_halo_kernel (conv3_x): 12 layers in %d launches/step (conv5_x: full round "
-                           "+ split-K remainder + oibl::conv_mx_splitk_reduce_kernel)" % (12 + extra)}[precision]
+                           "+ split-K remainder + oibl::conv_mx_splitk_reduce8_kernel)" % (12 + extra)}[precision]
     elif fwd is not None:
         # fp32: the replayed backbone graph holds conv1_1 too: 13 launches inside the span
         launches, fl = 13, (igemm_flops_per_image() + conv11_flops_per_image()) * batch

@@ -173,7 +173,8 @@ def traffic_table(fp, wp, prof, tag, prec):
         for k, (n, v, t) in fe.items():
             if not any(tag_ in k for tag_ in ("conv3x3_ring_kernel", "conv3x3_halo_kernel", "mx_pack_rows_kernel", "vgg_stem_kernel",
                                               "vgg_stem_x3_kernel", "conv3x3_igemm_kernel", "conv3x3_c64_kernel",
-                                              "conv_mx_splitk_reduce_kernel", "conv_splitk_reduce_kernel")):
+                                              "conv_mx_splitk_reduce_kernel", "conv_mx_splitk_reduce8_kernel",
+                                              "conv_splitk_reduce_kernel")):
                 continue
             w = wr.get(k, [1, 0.0, 1])
             tot_b += 2 * v * 1024 + w[1] * 1024 * (n / max(w[0], 1))
