@@ -40,8 +40,9 @@ CXXFLAGS = [
 
 
 # compile-time experiments ride in the DEBUG library only (a script times the same layer through the product
-# library and through this one).  Round 4: ["-DOIBL_MX_TAIL_B128"] — the f16mx fragment tail as one ds_read_b128
-# instead of b64 + b32 (tests/gpu_tail_ab.py: same bits, 6.950 -> 6.936 ms over the layers: nothing) — off again.
+# library and through this one: tests/gpu_dbgvariant_ab.py).  Round 4: ["-DOIBL_MX_TAIL_B128"] — the f16mx fragment
+# tail as one ds_read_b128 instead of b64 + b32 (same bits, 6.950 -> 6.936 ms over the layers: nothing; off again);
+# ["-DOIBL_RING_LGKM0"] — lgkmcnt(0) in front of every COMPUTE segment, the schedule before the counted waits.
 DBG_EXPERIMENT_FLAGS = []
 
 

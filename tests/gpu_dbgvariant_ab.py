@@ -2,8 +2,9 @@
 macro (openibl_amd/build.py, DBG_EXPERIMENT_FLAGS): per-layer timings of the ring / halo kernels at batch 32 and
 bit-identity of the results (diagnostic, not a pytest).     python tests/gpu_dbgvariant_ab.py [f16mx bf16 ...]
 
-Experiments run this way: OIBL_MX_TAIL_B128 (profiles/r04_f_tail_ab.txt), OIBL_RING_LGKM_AUTO
-(profiles/r04_h_lgkm_ab.txt)."""
+Experiments run this way: OIBL_MX_TAIL_B128 (profiles/r04_f_tail_ab.txt: not adopted); the counted fragment waits
+(profiles/r04_h_lgkm_ab.txt: adopted — the product library has them now, -DOIBL_RING_LGKM0 in the debug library
+gives the old lgkmcnt(0) schedule back, i.e. "variant" is then the OLD code)."""
 import sys
 from pathlib import Path
 
