@@ -691,6 +691,7 @@ OIBL_HOOK(int, g_ring_ablate, 0);                     // test hook: see RingPara
 // body per group 1-4 % faster per layer, 11 % on conv2_1 — f16mx ring + halo layers 7.47 -> 7.25 ms, bf16
 // 4.26 -> 4.19, bf16x3 11.04 -> 10.90 (profiles/r04_b_bar1_ab.txt).
 OIBL_HOOK(int, g_ring_bar1, 1);
+OIBL_HOOK(int, g_ring_stagger, 0);   // experiment: phase groups of the first round (conv_ring.h, RingParams::stagger)
 // a launch over a row sub-range and / or a K split of the layer (conv_ring.h, RingParams; f16mx split-K)
 struct RingSub {
   int tiles_m;       // M tiles of this launch, starting at GEMM row m_base
@@ -753,6 +754,7 @@ static int launch_conv_ring_impl(const ConvParams& p, hipStream_t st, const Ring
   q.raster = g_ring_raster;
   q.korder = p.korder;
   q.range_flag = p.range_flag;
+  q.stagger = g_ring_stagger;
   constexpr int lds = ring_lds_bytes<WM, POOL, P, OUTMX>();
   auto kern = conv3x3_ring_kernel<WM, POOL, ODD, P, OUTMX, BAR1>;
   OIBL_SET_MAX_LDS(kern, lds);
@@ -3290,6 +3292,13 @@ int oibl_debug_set_stem_u8(int on) {
 #ifdef OIBL_DEBUG_HOOKS
 int oibl_debug_set_mx_splitk(int on) {
   g_mx_splitk = on == 2 ? 2 : (on ? 1 : 0);
+  return OIBL_OK;
+}
+#endif
+
+#ifdef OIBL_DEBUG_HOOKS
+int oibl_debug_set_ring_stagger(int sleeps) {
+  g_ring_stagger = sleeps < 0 ? 0 : sleeps;
   return OIBL_OK;
 }
 #endif

@@ -55,6 +55,11 @@ struct RingParams {
   // row (m - m_base); conv_mx_splitk_reduce_kernel adds bias and partials in a fixed order.
   int m_base, nsteps_part, k_outer_step;
   size_t part_stride;
+  // Experiment (test hook, 0 = off): the workgroups of the FIRST round start (blockIdx & 3) * stagger sleeps of
+  // 8128 cycles late.  All workgroups of a layer run for the same time, so the rounds stay in phase across the
+  // chip: every CU loads, then every CU stores its tile (conv2_1: 64 MB of lines per round inside ~9 us); four
+  // phase groups spread those bursts over the round.
+  int stagger;
 };
 
 // mul, sh with floor(m / d) == (m * mul) >> sh for every m < 2^31 (d >= 1):  sh = 31 + ceil(log2 d),
@@ -552,6 +557,10 @@ __global__ __launch_bounds__(512) void conv3x3_ring_kernel(RingParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (p.stagger > 0 && blockIdx.x < 256 && blockIdx.y == 0) {
+    const int n = (int)(blockIdx.x & 3) * p.stagger;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   if constexpr (BAR1) {
     if ((wave >> 2) == 0) conv3x3_ring_body<WM, POOL, ODD, P, OUTMX, true, 0>(p, smem, lane, wave);
     else conv3x3_ring_body<WM, POOL, ODD, P, OUTMX, true, 1>(p, smem, lane, wave);

@@ -124,6 +124,7 @@ _HOOKS = {"oibl_debug_set_regstage": (c_int, [c_int]),
           "oibl_debug_set_pca_small": (c_int, [c_int]),
           "oibl_debug_set_netvlad_slabs": (c_int, [c_int]),
           "oibl_debug_set_ring_bar1": (c_int, [c_int]),
+          "oibl_debug_set_ring_stagger": (c_int, [c_int]),
           "oibl_debug_set_mx_splitk": (c_int, [c_int]),
           "oibl_debug_set_stem_u8": (c_int, [c_int]),
           "oibl_debug_set_match_bar1": (c_int, [c_int]),
@@ -153,7 +154,7 @@ _HOOK_DEFAULTS = {"oibl_debug_set_regstage": 0, "oibl_debug_set_conv11_valu": 0,
                   "oibl_debug_set_conv_korder": -1, "oibl_debug_set_mx_variant": 0, "oibl_debug_set_conv_splitk": 1,
                   "oibl_debug_set_stem3_prio": 0, "oibl_debug_set_match_group": 4, "oibl_debug_set_match_splitk": 1,
                   "oibl_debug_set_pca_small": 1, "oibl_debug_set_netvlad_slabs": 1,
-                  "oibl_debug_set_ring_bar1": 1, "oibl_debug_set_match_bar1": 1, "oibl_debug_set_match_mx_early": 1, "oibl_debug_set_mx_splitk": 1, "oibl_debug_set_stem_u8": 1,
+                  "oibl_debug_set_ring_bar1": 1, "oibl_debug_set_ring_stagger": 0, "oibl_debug_set_match_bar1": 1, "oibl_debug_set_match_mx_early": 1, "oibl_debug_set_mx_splitk": 1, "oibl_debug_set_stem_u8": 1,
                   "oibl_debug_set_prof_buffer": None}
 
 
