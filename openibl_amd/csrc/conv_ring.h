@@ -246,6 +246,16 @@ __device__ __forceinline__ void conv3x3_ring_body(const RingParams& p, char* sme
   const int wm = wave / G::WN, wn = wave % G::WN;
   const bool prof = p.prof != nullptr && blockIdx.x == 0 && wave == 0;
   const unsigned long long t_start = prof ? __builtin_amdgcn_s_memtime() : 0;
+  // (test hook, tests/gpu_wg_turnover.py: every workgroup's start / end stamp and the CU it ran on — what a CU
+  //  does between two tiles is not visible from inside one workgroup)
+  const bool wgprof = OUTMX && p.prof != nullptr && wave == 0 && lane == 0 && blockIdx.y == 0;
+  if (wgprof) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    p.prof[64 + 4 * (size_t)blockIdx.x] = __builtin_amdgcn_s_memtime();
+    p.prof[64 + 4 * (size_t)blockIdx.x + 1] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+  }
   int tm, tn;
   xcd_tile(blockIdx.x, (unsigned)p.tiles_m, (unsigned)p.tiles_n, p.raster, tm, tn);
   const int m0 = p.m_base + tm * G::BM, n0 = tn * G::BN;
@@ -306,6 +316,7 @@ __device__ __forceinline__ void conv3x3_ring_body(const RingParams& p, char* sme
                                                 (P == RING_MX_PROF && blockIdx.x == 0 && p.prof) ? p.prof + 8 : nullptr);
   // (the main loop ends on a workgroup barrier: the staging LDS is free for the epilogue)
   const unsigned long long t_epi = prof ? __builtin_amdgcn_s_memtime() : 0;
+  if (wgprof) p.prof[64 + 4 * (size_t)blockIdx.x + 3] = __builtin_amdgcn_s_memtime();
 
   // ---- epilogue: bias (+ReLU) (+2x2 max-pool over register quads), transpose through LDS,
   //      full-line NHWC stores.
@@ -434,6 +445,7 @@ __device__ __forceinline__ void conv3x3_ring_body(const RingParams& p, char* sme
         p.prof[7] = PASSES > 1 ? ep_[5] - ep_[4] : 0;
       }
     }
+    if (wgprof) p.prof[64 + 4 * (size_t)blockIdx.x + 2] = __builtin_amdgcn_s_memtime();   // (stores issued, not drained)
     return;
   }
   constexpr int EB = X3 ? 4 : 2;
