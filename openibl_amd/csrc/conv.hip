@@ -1248,6 +1248,7 @@ static int launch_conv_mx(const ConvParams& p, int pool, hipStream_t st) {
     if (rv == 4) return pool ? launch_conv_ring<4, true, RING_MX>(p, st) : launch_conv_ring<4, false, RING_MX>(p, st);
   }
   if (g_mx_variant == 8 && rv == 2 && !pool) return launch_conv_ring<2, false, RING_MX_PROF>(p, st);
+  if (g_mx_variant == 8 && rv == 4 && !pool) return launch_conv_ring<4, false, RING_MX_PROF>(p, st);
   if (g_mx_variant >= 4 && g_mx_variant <= 7 && rv == 2 && !pool) {   // timing experiments (wrong results)
     switch (g_mx_variant) {
       case 4: return launch_conv_ring<2, false, RING_MX_NOMFMA>(p, st);

@@ -35,6 +35,14 @@ def timed(fn, iters=4, rounds=5):
     return sorted(ts)[len(ts) // 2]
 
 
+def _diff(a, b, prec):
+    """rel-L2 between the two results when an experiment changes the summation order"""
+    if torch.equal(a, b):
+        return ""
+    fa, fb = (ops.mx_join(a), ops.mx_join(b)) if prec == "f16mx" else (a.float(), b.float())
+    return f" (rel-L2 {float((fa.double() - fb.double()).norm() / fb.double().norm()):.2e})"
+
+
 PRECS = sys.argv[1:] or ["f16mx"]
 for prec in PRECS:
   tot = [0.0, 0.0]
@@ -58,7 +66,7 @@ for prec in PRECS:
       tot[0] += t0
       tot[1] += t1
       print(f"{cin:4d}->{cout:4d} {H:3d}x{W:3d}{' pool' if pool else '     '}: {prec} product {t0:6.3f} ms | variant {t1:6.3f} ms "
-            f"({t0 / t1:4.2f}x) | same bits: {torch.equal(out[0], out[1])}", flush=True)
+            f"({t0 / t1:4.2f}x) | same bits: {torch.equal(out[0], out[1])}{_diff(out[0], out[1], prec)}", flush=True)
   print(f"{prec}: layers behind the stem (conv5 once): {tot[0]:.3f} -> {tot[1]:.3f} ms")
 
 # the fused distance + top-k kernels (match.hip shares ring_core.h)
