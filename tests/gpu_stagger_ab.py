@@ -13,6 +13,8 @@ from openibl_amd import lib, ops  # noqa: E402
 LAYERS = [(64, 128, 240, 320, 1, 0), (128, 128, 240, 320, 1, 1), (256, 512, 60, 80, 1, 0), (512, 512, 60, 80, 1, 0),
           (512, 512, 60, 80, 1, 1), (512, 512, 30, 40, 1, 0)]
 STAGGERS = (0, 1, 2, 3, 5, 0)
+if "early" in sys.argv[1:]:      # the two 512 x 128 layers only, alternating settings (boxes drift by several per cent)
+    LAYERS, STAGGERS = LAYERS[:2], (0, 2, 0, 2, 0, 2, 0, 3, 0, 3, 0)
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(5)
 h = lib.debug_hooks()
@@ -33,7 +35,7 @@ def timed(fn, iters=4, rounds=5):
     return sorted(ts)[len(ts) // 2]
 
 
-for prec in ("f16mx", "bf16"):
+for prec in (("f16mx",) if "early" in sys.argv[1:] else ("f16mx", "bf16")):
     for cin, cout, H, W, relu, pool in LAYERS:
         xf = torch.relu(torch.randn((32, H, W, cin), generator=g, device=dev)) * 3.0
         w = torch.randn((cout, cin, 3, 3), generator=g, device=dev) * (2.0 / (9 * cin)) ** 0.5
