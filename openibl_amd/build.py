@@ -119,6 +119,61 @@ def resource_usage() -> dict:
     return json.loads(p.read_text())
 
 
+def kernel_text() -> dict:
+    """{kernel symbol: {"instructions": n, "mfma": matrix instructions in its text, "bytes": code size}} of the
+    PRODUCT objects of the current build, from the gfx950 code objects themselves (llvm-objcopy the .hip_fatbin
+    section out of each object, clang-offload-bundler --unbundle, llvm-objdump -d).  A hot kernel's text is
+    part of what is measured: round 4 lost 4.5 % of the step to a kernel body the compiler had cloned around a
+    diagnostic flag that was off (tests/test_abi.py pins the matrix-instruction counts).  Returns {} when the
+    LLVM tools are not next to hipcc."""
+    import re
+    import tempfile
+    build(verbose=False)
+    cache = BUILD_DIR / "kernel_text.json"
+    stamp = (BUILD_DIR / "stamp").read_text()
+    if cache.exists():
+        hit = json.loads(cache.read_text())
+        if hit.get("stamp") == stamp:
+            return hit["kernels"]
+    bindir = None
+    for cand in (Path(_hipcc()).resolve().parent, Path("/opt/rocm/lib/llvm/bin"), Path("/opt/rocm/llvm/bin")):
+        if (cand / "llvm-objdump").exists() and (cand / "clang-offload-bundler").exists():
+            bindir = cand
+            break
+    if bindir is None:
+        return {}
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        for src in sources():
+            obj = BUILD_DIR / (src.stem + ".o")
+            fat, co = Path(td) / (src.stem + ".fat"), Path(td) / (src.stem + ".co")
+            r = subprocess.run([str(bindir / "llvm-objcopy"), f"--dump-section=.hip_fatbin={fat}", str(obj)],
+                               capture_output=True, text=True)
+            if r.returncode != 0 or not fat.exists():
+                continue
+            r = subprocess.run([str(bindir / "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}",
+                                f"--targets=hipv4-amdgcn-amd-amdhsa--{ARCH}", f"--output={co}"],
+                               capture_output=True, text=True)
+            if r.returncode != 0:
+                continue
+            r = subprocess.run([str(bindir / "llvm-objdump"), "-d", "--no-show-raw-insn", str(co)],
+                               capture_output=True, text=True)
+            cur, first = None, 0
+            for line in r.stdout.splitlines():
+                m = re.match(r"^([0-9a-f]+) <(\S+)>:", line)
+                if m:
+                    cur = out.setdefault(m.group(2), {"instructions": 0, "mfma": 0, "bytes": 0})
+                    first = int(m.group(1), 16)
+                    continue
+                m = re.match(r"^\s+(\S.*?)\s*// ([0-9A-Fa-f]+):", line)
+                if m and cur is not None:
+                    cur["instructions"] += 1
+                    cur["mfma"] += 1 if "v_mfma" in m.group(1) else 0
+                    cur["bytes"] = int(m.group(2), 16) - first
+    cache.write_text(json.dumps({"stamp": stamp, "kernels": out}))
+    return out
+
+
 def _build_locked(verbose: bool) -> Path:
     hipcc = _hipcc()
     srcs = sources()

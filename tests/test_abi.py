@@ -237,3 +237,32 @@ def test_hot_kernels_stay_inside_their_register_budgets():
             if re.search(r"ELb1EEE", name):
                 assert scratch == 0, (name, u)
     assert len(seen) >= 4
+
+
+def test_hot_kernels_hold_exactly_their_matrix_instructions():
+    """The TEXT of the hot kernels, from the gfx950 code objects of the current build (openibl_amd.build.kernel_text):
+    a ring kernel holds one copy of its K loop and one peeled pair of last K-tiles per stagger-group body — 16
+    phases (20 with an odd number of K-tiles) of 8 (bf16), 12 (bf16x3) or 6 (f16mx) matrix instructions, twice that
+    with one body per group (BAR1).  More means the compiler has cloned the body: in round 4 three correlated
+    branches on a diagnostic flag did, and the product step lost 4.5 % with the flag off."""
+    import re
+    from openibl_amd import build
+    text = build.kernel_text()
+    if not text:
+        import pytest
+        pytest.skip("llvm-objdump / clang-offload-bundler not found next to hipcc")
+    per_phase = {0: 8, 1: 12, 2: 6, 3: 6, 4: 0, 5: 6, 6: 6, 7: 6, 8: 6}
+    ring = 0
+    for name, t in text.items():
+        m = re.search(r"conv3x3_ring_kernelILi(\d)ELb([01])ELb([01])ELi(\d)ELb([01])ELb([01])EEE", name)
+        if m and not name.endswith(".kd"):
+            odd, p, bar1 = int(m.group(3)), int(m.group(4)), int(m.group(6))
+            want = per_phase[p] * (20 if odd else 16) * (2 if bar1 else 1)
+            assert t["mfma"] == want, (name, t, want)
+            assert t["bytes"] < 64 * 1024, (name, t)          # the instruction cache two CUs share
+            ring += 1
+    assert ring >= 40
+    halo = {n: t for n, t in text.items() if "conv3x3_halo_kernel" in n and not n.endswith(".kd")}
+    assert halo and all(t["mfma"] == (864 if re.search(r"ELb1EEE", n) else 432) for n, t in halo.items()), halo
+    stems = {n: t["mfma"] for n, t in text.items() if "vgg_stem" in n and not n.endswith(".kd")}
+    assert sorted(set(stems.values())) == [126, 168, 234], stems
