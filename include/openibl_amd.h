@@ -186,7 +186,10 @@ int oibl_nchw_f32_to_nhwc(const float* x, int N, int C, int P, int precision, vo
  * and evaluate Normalize as ONE fma per value, u * 1/(255 std) - mean/std: within 2^-16 of the loader's
  * three rounded operations on values up to 151 (identical bf16 hi parts of conv1_1's operand for all 768
  * (channel, byte) pairs, 42 lo parts one unit apart) — the conv5_3 map is within ~1e-6 (bf16x3) / ~1e-5
- * (f16mx: the size of its own rounding) of the fp32-input result, not bit-identical.
+ * (f16mx: the size of its own rounding) of the fp32-input result, not bit-identical.  These stems read the image
+ * through dword-aligned loads over a descriptor rounded up to whole dwords (a partly covered last dword reads as
+ * zero, nothing beyond the rounded size is touched): x_nhwc that is NOT 4-byte aligned takes the normalising
+ * pass of OIBL_F32 below instead (same results as the fp32-input route), it is never read misaligned.
  * OIBL_F32 (and shapes the stems do not take): a normalising uint8 -> fp32 NCHW pass into the workspace,
  * then the regular path (bit-identical).  ev_*: optional hipEvent_t recorded around the matrix-core
  * launches (as oibl_vgg16_conv5_forward_ev), may be NULL.      */

@@ -3573,7 +3573,10 @@ static int vgg_forward_impl(const void* x, int u8, const float* mean3, const flo
                       !g_conv_ablate && g_conv_tile == 0;
   // uint8 input: every fused stem normalises inside the kernel (g_stem_u8 = 0, test hook: the 4-byte stems
   // take the normalising pass below instead)
-  const bool u8_fused3 = u8 && fused3 && g_stem_u8;
+  // (the 4-byte stems fetch the image with dword-aligned 12-byte buffer loads over a descriptor rounded up to whole
+  //  dwords: an input that does not start on a 4-byte boundary — an odd-offset slice of a caller's buffer — takes
+  //  the normalising pass instead, which reads bytes)
+  const bool u8_fused3 = u8 && fused3 && g_stem_u8 && (uintptr_t)x % 4 == 0;
   if (u8 && !fused && !u8_fused3) {  // normalise into the fp32 staging area behind the activation buffers
     float* stage = (float*)((char*)ws + base_need);
     const long npix = (long)N * H * W;

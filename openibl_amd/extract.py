@@ -207,9 +207,13 @@ class GraphedForward:
         return self.static_in[0].shape
 
     def __call__(self, x: Optional[torch.Tensor] = None, events=None,
-                 dest: Optional[torch.Tensor] = None, stable_src: bool = True) -> torch.Tensor:
-        """stable_src=False: `x` is a buffer the caller will overwrite (a staging area): with the range guard
-        the batch is then checked before its slot is used again instead of being kept referenced."""
+                 dest: Optional[torch.Tensor] = None, stable_src: bool = False) -> torch.Tensor:
+        """stable_src=False (default): `x` only has to stay unchanged until the lane has copied it (the
+        contract above) — with the range guard the batch is then settled from the SLOT's copy before the slot
+        is used again.  stable_src=True: the caller promises that `x` stays alive and unchanged until the
+        batch is settled (up to RING - 2 calls later; `extract_descriptors` says so for the loader batches it
+        owns): the queue keeps `x` referenced and re-reads it if the f16mx range flag fires, and the host never
+        blocks on a slot."""
         j = self.calls % self.depth
         c = self.calls
         self.calls += 1
@@ -308,10 +312,17 @@ def _tensors_in(obj, out=None):
 # ---------------------------------------------------------------------------------------------
 def _head_fn(core, vlad: bool, pca, store_dtype):
     """What extract_cnn_feature (+ PCA.infer, + descriptor storage) computes behind the conv5_3 map
-    (ibl/evaluators.py:22-34, 55-57), as a function of the NHWC feature map."""
+    (ibl/evaluators.py:22-34, 55-57), as a function of the NHWC feature map.  The closure holds the model
+    WEAKLY: a GraphedForward keeps its head function, and the graph store is weakly keyed on the model — a
+    strong reference from the value to its own key would keep captured graphs (2.5-5 GB per shape) alive
+    after the model is dropped."""
     from .models import EmbedNetPCA
+    core_ref = weakref.ref(core)
 
     def head(feat):
+        core = core_ref()
+        if core is None:
+            raise RuntimeError("openibl_amd: the model behind this captured forward has been dropped")
         if isinstance(core, EmbedNetPCA):
             out = core.head_from_features(feat)
         elif vlad:

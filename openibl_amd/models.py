@@ -197,7 +197,12 @@ class VGG(_PrecisionMixin, nn.Module):
         read here — one 4-byte copy per batch — and a flagged batch is recomputed in bf16x3, the other mode
         inside the 1e-4 tolerance, which has no range limit (`range_fallbacks` counts them).  Under a
         hipGraph capture nothing can be read: the capturer takes `last_range_flag()` and checks it after
-        every replay (extract.GraphedForward does)."""
+        every replay (extract.GraphedForward does).
+        Cost, stated: the eager f16mx pass ends in `flag.item()` — one host synchronisation per
+        batch, so eager extraction has no host / device overlap in f16mx (the replayed two-lane path settles the
+        flag lazily through a pinned ring and keeps it; `GraphedForward(pipeline=False)` blocks once per call by
+        design: its result is final when the call returns).  `_range_flag` is per-module state of the LAST call:
+        one thread and one stream per model object at a time."""
         if x.dtype != torch.uint8 and x.dtype != torch.float32:
             x = x.float()
         x = x.contiguous()

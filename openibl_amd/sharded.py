@@ -149,28 +149,39 @@ def sharded_topk(q_all: torch.Tensor, g_local: torch.Tensor, k: int, index_base:
         on_gpu = probe.is_cuda
         main = torch.cuda.current_stream(probe.device) if on_gpu else None
         side = _side_stream(probe.device) if on_gpu else None
-        parts = []
-        for lo, hi in bounds:
+
+        def local_block(lo, hi, exact):
             qb = _query_block(q_all, lo, hi)
-            res = local_topk_fn(qb, g_local, k, index_base, precision)
+            res = local_topk_fn(qb, g_local, k, index_base, precision, exact) if exact else \
+                local_topk_fn(qb, g_local, k, index_base, precision)
             if len(res) == 2:
                 res = (res[0], res[1], torch.zeros(1, dtype=torch.int32, device=res[0].device))
+            return res
+
+        parts = []
+        for lo, hi in bounds:
+            res = local_block(lo, hi, False)
             if on_gpu:
                 side.wait_stream(main)                  # this block's lists are complete
                 with torch.cuda.stream(side):
                     out = gather_and_merge(*res)
-                for t in (*res, *out):
-                    t.record_stream(side)
+                for t in res:
+                    t.record_stream(side)               # allocated on main, read by the exchange on side
+                for t in out:
+                    t.record_stream(main)               # allocated on side, read by the concatenation on main
                 parts.append(out)
             else:
                 parts.append(gather_and_merge(*res))
         if on_gpu:
             main.wait_stream(side)
-        v = torch.cat([p_[0] for p_ in parts])
-        i = torch.cat([p_[1] for p_ in parts])
-        flags = torch.cat([p_[2].reshape(-1) for p_ in parts])
-    else:
-        v, i, flags = gather_and_merge(*local(False))
+        # the only host synchronisation, after everything has been enqueued; identical on every rank (each block's
+        # flags are the gathered flags of all ranks).  Only the FLAGGED blocks are repeated on the exact path.
+        flagged = torch.stack([p_[2].reshape(-1).ne(0).any() for p_ in parts]).tolist()
+        for b, (lo, hi) in enumerate(bounds):
+            if flagged[b]:
+                parts[b] = gather_and_merge(*local_block(lo, hi, True))
+        return torch.cat([p_[0] for p_ in parts]), torch.cat([p_[1] for p_ in parts])
+    v, i, flags = gather_and_merge(*local(False))
     # the only host synchronisation, after everything has been enqueued; identical on every rank
     if bool(flags.any().item()):
         v, i, _ = gather_and_merge(*local(True))

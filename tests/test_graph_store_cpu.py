@@ -53,3 +53,25 @@ def test_store_follows_the_state_it_was_captured_in():
     e = _graph_store(core, p1, True, None, dev)
     assert _graph_store(core, p1, True, None, dev) is e
     assert _graph_store(core, p2, True, None, dev) is not e
+
+
+def test_store_dies_with_the_model():
+    """the store is weakly keyed on the model, so nothing a stored GraphedForward holds may
+    reference the model strongly — its head closure (extract._head_fn) holds it weakly, its range guard is the
+    backbone CHILD (a module does not reference its parent).  `del model; gc.collect()` must empty the store."""
+    import gc
+    import types
+    import weakref
+    from openibl_amd.extract import _GRAPH_STORES, _head_fn, release_graphs
+    release_graphs()
+    model = hubconf.vgg16_netvlad(pretrained=False).eval()
+    core = unwrap_model(model)
+    store = _graph_store(core, None, True, None, torch.device("cuda", 0))
+    # what a captured forward keeps (GraphedForward.head_fn / .guard), without a GPU
+    store[((1, 3, 64, 96), torch.float32)] = types.SimpleNamespace(
+        head_fn=_head_fn(core, True, None, None), guard=core.base_model)
+    assert len(_GRAPH_STORES) == 1
+    ref = weakref.ref(core)
+    del model, core, store
+    gc.collect()
+    assert ref() is None and len(_GRAPH_STORES) == 0

@@ -79,6 +79,21 @@ def _overflowing_local_topk(q, g, k, index_base, precision, exact=False):
 _overflowing_local_topk.calls = []
 
 
+def _first_block_overflows(q, g, k, index_base, precision, exact=False):
+    """As above, but only the FIRST non-exact call of rank 1 overflows: with query blocks, only that block may
+    be repeated on the exact path.  Records (exact, query rows) per call."""
+    v, i = _oracle_local_topk(q, g, k, index_base, precision)
+    flag = torch.zeros(1, dtype=torch.int32)
+    first = not _first_block_overflows.calls
+    if not exact and first and dist.get_rank() == 1:
+        v, i, flag = torch.zeros_like(v), torch.zeros_like(i), torch.ones(1, dtype=torch.int32)
+    _first_block_overflows.calls.append((bool(exact), int(q.shape[0])))
+    return v, i, flag
+
+
+_first_block_overflows.calls = []
+
+
 def _oracle_merge(vals, idx, k):
     key = np.lexsort((idx.numpy().astype(np.int64) & 0xFFFFFFFF, vals.numpy()), axis=1)[:, :k]
     return (torch.from_numpy(np.take_along_axis(vals.numpy(), key, 1)),
@@ -134,8 +149,15 @@ def _worker(rank, world, port, G, ret):
         _overflowing_local_topk.calls = []
         v7, i7 = sharded.sharded_topk(q, g[start:start + n_valid], 10, start, blocks=2,
                                       local_topk_fn=_overflowing_local_topk, merge_fn=_oracle_merge)
-        ok_topk = ok_topk and _overflowing_local_topk.calls == [False, False, True] and \
+        # every block of rank 1 overflowed: every block is repeated, block by block
+        ok_topk = ok_topk and _overflowing_local_topk.calls == [False, False, True, True] and \
             bool(np.array_equal(i7.numpy(), wi))
+        # only the first of three blocks overflows (on rank 1): every rank repeats THAT block on the exact path
+        _first_block_overflows.calls = []
+        v8, i8 = sharded.sharded_topk(q, g[start:start + n_valid], 10, start, blocks=3,
+                                      local_topk_fn=_first_block_overflows, merge_fn=_oracle_merge)
+        ok_topk = ok_topk and _first_block_overflows.calls == [(False, 8), (False, 8), (False, 8), (True, 8)] and \
+            bool(np.array_equal(i8.numpy(), wi) and np.allclose(v8.numpy(), wv))
         rec = evaluators.recalls_from_topk(idx.numpy(), gt)
         ok_rec = bool(np.array_equal(rec, om.evaluate_all(d, gt, pids)))
 
@@ -186,3 +208,60 @@ def test_shard_count_does_not_change_the_result():
             is_.append(i)
         mv, mi = _oracle_merge(torch.cat(vs, 1), torch.cat(is_, 1), 12)
         assert np.array_equal(mi.numpy(), wi), W
+
+
+def _worker8(rank, world, port, ret):
+    """World size 8 at BASELINE configs[3]'s gallery size: G = 83 952 dealt as 8 x 10 494 (DistributedSliceSampler),
+    tiny d, the local step replaced by the oracle; one shard overflows in one query block."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from openibl_amd import sharded
+        from oracle import matching as om
+        G, Q, d, k = 83952, 30, 16, 10
+        gen = torch.Generator().manual_seed(5)
+        g = torch.nn.functional.normalize(torch.randn(G, d, generator=gen), dim=1)
+        q = torch.nn.functional.normalize(torch.randn(Q, d, generator=gen), dim=1)
+        g[10494 * 3 + 7] = g[10494 * 6 + 1]          # an exact tie across two shards: lowest global index wins
+        q[0] = g[10494 * 6 + 1]
+        start, per, n_valid = sharded.slice_bounds(G, rank, world)
+        ok = (per, n_valid) == (10494, 10494)
+        dm = om.pairwise_distance(q, g).numpy()
+        wv, wi = om.topk(dm, k)
+        ok = ok and wi[0, 0] == 10494 * 3 + 7 and wi[0, 1] == 10494 * 6 + 1
+        # queries: every rank "extracted" ceil(Q / 8) = 4 of them (the last slice wraps), exchanged in prepared form
+        qs, qper, _ = sharded.slice_bounds(Q, rank, world)
+        q_loc = torch.stack([q[(qs + i) % Q] for i in range(qper)])
+        qp = sharded.gather_prepared_queries(q_loc, Q, "fp32", prepare_fn=_CpuPrepared)
+        ok = ok and torch.equal(qp.x, q)
+        for nb in (1, 2, 3):
+            v, i = sharded.sharded_topk(qp, g[start:start + n_valid], k, start, blocks=nb,
+                                        local_topk_fn=_prepared_local_topk, merge_fn=_oracle_merge)
+            ok = ok and bool(np.array_equal(i.numpy(), wi) and np.allclose(v.numpy(), wv))
+        _first_block_overflows.calls = []
+        v, i = sharded.sharded_topk(q, g[start:start + n_valid], k, start, blocks=3,
+                                    local_topk_fn=_first_block_overflows, merge_fn=_oracle_merge)
+        ok = ok and bool(np.array_equal(i.numpy(), wi)) and \
+            _first_block_overflows.calls == [(False, 10), (False, 10), (False, 10), (True, 10)]
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_8_at_pitts250k_gallery_size():
+    """8 real processes over gloo, 8 x 10 494 gallery rows, 1 / 2 / 3 query blocks, one
+    shard overflowing in one block (only that block is repeated, on every rank)."""
+    world = 8
+    port = 29950 + os.getpid() % 40
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        procs = [ctx.Process(target=_worker8, args=(r, world, port, ret)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=300)
+            assert p.exitcode == 0
+        assert [ret[r] for r in range(world)] == [True] * world
