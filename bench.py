@@ -120,6 +120,8 @@ def time_extraction(c, model, x, precision, steps, warmup, eager=False, pipeline
     # the roofline is measured in a second timed region of K steps on ONE lane (events recorded on
     # the launching stream around the backbone graph).  --eager times `model(x)` launch by launch.
     launch_mode, fwd, fwd1 = "eager", None, None
+    bm = model.base_model
+    runs0, fb0 = dict(bm.precision_runs), bm.range_fallbacks
     with torch.no_grad():
         ref = model(x).clone()          # packs the weights, sizes the workspaces (not a timed path)
         if not eager:
@@ -166,6 +168,9 @@ def time_extraction(c, model, x, precision, steps, warmup, eager=False, pipeline
         elapsed = float(elapsed.item())
         assert tuple(out.shape) == (x.shape[0], 4096) and bool(torch.isfinite(out).all())
         assert torch.equal(out, ref), "timed forward differs from model(x)"
+        # f16mx range guard: batches of the TIMED region that were re-run in bf16x3 (a replayed forward counts them
+        # itself, the eager path on the backbone module) — a fallback-heavy run must not report the f16mx rate
+        timed_fallbacks = (fwd.range_fallbacks if fwd is not None else bm.range_fallbacks - fb0)
         one_lane = None
         if fwd1 is not None:            # the span leg: the same K steps on one lane, with events
             for _ in range(max(warmup, 0)):
@@ -262,8 +267,13 @@ def time_extraction(c, model, x, precision, steps, warmup, eager=False, pipeline
         c11 = conv11_flops_per_image() / (igemm_flops_per_image() + conv11_flops_per_image())
         roof["matrix_pipe_time_per_product_vs_bf16"] = round((1.0 - c11) * 1.5 + c11 * 3.0 * 2.0 * 32.0 / 27.0, 3)
         roof["issued_frac"] = round(roof["matrix_pipe_time_per_product_vs_bf16"] * achieved / peak, 4)
+    runs = {k_: v_ - runs0.get(k_, 0) for k_, v_ in bm.precision_runs.items() if v_ - runs0.get(k_, 0)}
     return {"value": round(value, 2), "ms_per_step": round(elapsed / steps * 1e3, 4),
-            "launch": launch_mode, "roofline": roof, "dtype": precision}
+            "launch": launch_mode, "roofline": roof, "dtype": precision,
+            "range_fallbacks": int(timed_fallbacks + (fwd1.range_fallbacks if fwd1 is not None else 0)),
+            "range_fallbacks_timed_region": int(timed_fallbacks), "timed_batches": int(steps),
+            # backbone passes by the arithmetic they RAN in, eager + captured (a replay repeats its capture's)
+            "precision_runs": runs}
 
 
 class _MemLoader:
@@ -306,16 +316,23 @@ def time_api(c, model, precision, batch, n_batches, u8):
     with torch.no_grad():
         eager = extract_cnn_feature(model, pinned[0], gpu=c.dev.index).cpu()
     assert torch.equal(first, eager), "extract_features differs from the eager extract_cnn_feature"
+    from openibl_amd import extract as _ex
+    store = _ex._GRAPH_STORES.get(_ex.unwrap_model(model))
+    fallbacks = sum(f.range_fallbacks for f in store[1].values()) if store else 0
     return {"value": round(n_batches * batch / dt, 1), "unit": "images/s", "images": n_batches * batch,
-            "seconds": round(dt, 4), "precision": precision,
+            "seconds": round(dt, 4), "precision": precision, "range_fallbacks": int(fallbacks),
             "input": "uint8 NHWC, pinned host batches" if u8 else "fp32 NCHW (normalised), pinned host batches",
             "through": "ibl.evaluators.extract_features (H2D copy, forward, extra L2 normalise, D2H gather, "
                        "fname dict); descriptors torch.equal to extract_cnn_feature"}
 
 
 def time_matching(c, precision, Q, G, msteps=10):
+    """`precision` is the model's; the fused distance + top-k runs in ops.topk_precision(precision): an f16mx
+    model's fp32 descriptors are matched by the fp16 filter pass + exact rescoring ("f16r": fp32-exact lists)."""
     from openibl_amd import ops, sharded
     dev, dist = c.dev, c.dist
+    mp = {ops.BF16: "bf16", ops.F32: "fp32", ops.BF16X3: "bf16x3", ops.F16MX: "f16mx",
+          ops.F16R: "f16r"}[ops.topk_precision(precision)]
     start, per, n_valid = sharded.slice_bounds(G, c.rank, c.world)
     gq = torch.Generator(device=dev).manual_seed(7)
     q = torch.nn.functional.normalize(torch.randn((Q, 4096), generator=gq, device=dev), dim=1)
@@ -326,35 +343,90 @@ def time_matching(c, precision, Q, G, msteps=10):
     # the Q / W rows it extracted, prepares THOSE (norms + operand rows) and the prepared parts are
     # all-gathered (north_star's all-gather; sharded.gather_prepared_queries) — inside the timed step.  The
     # local top-k then runs in query blocks whose exchange + merge overlap the next block's matrix work.
-    gp = ops.PreparedRows(g, precision)
+    gp = ops.PreparedRows(g, mp)
     qs, qper, _ = sharded.slice_bounds(Q, c.rank, c.world)
     q_local = q[(qs + torch.arange(qper, device=dev)) % Q].contiguous() if c.world > 1 else q   # (wrapped slice)
     blocks = 2 if c.world > 1 else 1
 
     def step():
-        qp = sharded.gather_prepared_queries(q_local, Q, precision)
-        return sharded.sharded_topk(qp, gp, 10, start, precision, blocks=blocks)
+        qp = sharded.gather_prepared_queries(q_local, Q, mp)
+        return sharded.sharded_topk(qp, gp, 10, start, mp, blocks=blocks)
     for _ in range(3):
         step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(msteps)]
     c.barrier()
     t0 = time.perf_counter()
-    for _ in range(msteps):
+    for k_ in range(msteps):
+        ev[k_][0].record()
         vals, idx = step()
+        ev[k_][1].record()
     c.barrier()
     t1 = time.perf_counter()
     mt = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if c.use_dist:
         dist.all_reduce(mt, op=dist.ReduceOp.MAX)
     pairs = float(Q) * G * msteps / float(mt.item())
+    span_ms = sum(a.elapsed_time(b) for a, b in ev) / msteps
+    # correctness of the TIMED lists (rank 0's shard when sharded: world 1 only): a 256-row block against the
+    # top-k of the materialised matrix.  bf16 / f16mx / bf16x3: the fused lists ARE the top-k of their own matrix
+    # (torch.equal); f16r has no matrix of its own — its lists are those of the fp32 matrix except where fp64
+    # calls the two candidates a near-tie (the fp32 MFMA matrix carries ~1e-6 of rounding, the f16r values do not)
+    check = None
+    if c.world == 1:
+        rows = slice(Q // 2, Q // 2 + 256)
+        dm = ops.pairwise_sqdist(q[rows].contiguous(), g, "fp32" if mp == "f16r" else mp)
+        wv, wi = ops.row_topk(dm, 10)
+        if mp != "f16r":
+            assert torch.equal(idx[rows], wi) and torch.equal(vals[rows], wv), "timed matching lists != top-k of the matrix"
+            check = "timed lists torch.equal to row_topk of the materialised matrix on rows %d..%d" % (rows.start, rows.stop)
+        else:
+            assert float((vals[rows] - wv).abs().max()) <= 2e-6, "timed f16r values differ from the fp32 matrix"
+            differ = (idx[rows] != wi).nonzero()
+            worst = 0.0
+            for r_, c_ in differ.tolist():
+                qq = q[rows.start + r_].double()
+                a = float(((qq - g[int(idx[rows][r_, c_])].double()) ** 2).sum())
+                b = float(((qq - g[int(wi[r_, c_])].double()) ** 2).sum())
+                worst = max(worst, abs(a - b))
+            assert worst < 4e-6, "timed f16r lists differ from the fp32 matrix beyond fp32 near-ties"
+            check = ("timed lists against row_topk of the fp32 matrix on rows %d..%d: values within 2e-6, %d of 2560 "
+                     "indices differ, all fp64 near-ties within %.1e" % (rows.start, rows.stop, len(differ), worst))
+        del dm
+    flops = 8192.0 * Q * G
+    achieved = flops / (span_ms * 1e-3) / 1e12
+    traffic, traffic_src = None, None
+    tj = ROOT / "profiles" / "hbm_traffic_latest.json"
+    if tj.exists():
+        try:
+            ent = json.loads(tj.read_text()).get("matching_" + mp)
+            if ent:
+                traffic, traffic_src = round(float(ent["bytes_per_launch"])), ent["source"]
+        except Exception:
+            traffic = None
+    kern = {"f16r": "oibl::pairwise_f16r_kernel<true> (fp16 filter pass: 98 % of the step) + sample pass, row_topk x2, "
+                    "oibl::f16r_rescore_kernel",
+            "bf16": "oibl::pairwise_ring_kernel<true, RING_BF16> + sample pass, row_topk x2",
+            "f16mx": "oibl::pairwise_ring_kernel<true, RING_MX_EARLY> + sample pass, row_topk x2",
+            "bf16x3": "oibl::pairwise_ring_kernel<true, RING_X3> + sample pass, row_topk x2"}.get(mp, mp)
+    roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "kernel": kern, "span_ms": round(span_ms, 4),
+            "algorithmic_flops_per_step": flops,
+            "measured_with": "HIP events on the launching stream around every timed step (rank 0; the whole step: "
+                             "query preparation, sample pass, filter pass, selection, rescoring)"}
     del q, g, gp
     return {"metric": "query_gallery_pairs_per_sec", "value": pairs, "unit": "pairs/s",
             "ms_per_step": float(mt.item()) / msteps * 1e3, "scaling": "strong",
-            "tflops": round(pairs * 8192 / 1e12, 2),
+            "tflops": round(pairs * 8192 / 1e12, 2), "roofline": roof, "correctness": check,
             "config": {"workload": f"{Q} queries x {G} gallery x 4096-d squared-L2 + top-10, gallery sharded "
                                    f"{c.world}-way and resident as prepared operands; per step: every rank prepares "
                                    f"its Q/{c.world} queries, all_gather of the prepared queries, local top-k in "
                                    f"{blocks} query block(s), top-k all_gather + merge",
-                       "precision": precision}}
+                       "precision": mp, "model_precision": precision,
+                       "arithmetic": {"f16r": "fp16 filter pass (v_mfma_f32_32x32x16_f16, per-row power-of-two scales) "
+                                              "with a rigorous per-pair error bound + fp64-accumulated rescoring of the "
+                                              "k + few survivors per query from the resident fp32 rows: fp32-exact lists",
+                                      "bf16": "bf16 operands (fast mode: lists at bf16 accuracy)"}.get(mp, mp)}}
 
 
 def cpu_baselines():
@@ -584,6 +656,9 @@ def main():
                                       "fp32": "exact fp32 MFMA"}[args.precision]},
             "roofline": head["roofline"], "fast_mode": fast, "api": api, "cpu_baseline": cpu,
             "matching": matching,
+            # f16mx range guard (activations beyond fp16 re-run a batch in bf16x3): what the TIMED batches did
+            "range_fallbacks": head["range_fallbacks"], "range_fallbacks_timed_region": head["range_fallbacks_timed_region"],
+            "timed_batches": head["timed_batches"], "precision_runs": head["precision_runs"],
         }
         if shared_gpu:
             line["config"]["note"] = (f"FLOW CHECK ONLY: {c.world} ranks time-share ONE GPU over gloo "

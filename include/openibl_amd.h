@@ -362,6 +362,31 @@ int oibl_sqdist_topk_prepared(const void* xo, const float* xn, int m, const void
                               float* out_val, int32_t* out_idx, int32_t* overflow, void* ws,
                               size_t ws_bytes, void* stream);
 
+/* ---- "f16r": fp16 filter pass + exact rescoring ---------------------------------------------- *
+ * The k nearest gallery rows per query by fp32 squared-L2 (pairwise_distance + the argsort prefix evaluate_all
+ * reads, ibl/evaluators.py:105-130, 142-159) with EXACT lists at the cost of a 2-byte operand stream: every pair
+ * is contracted once in fp16 (v_mfma_f32_32x32x16_f16, power-of-two row scales), kept if its distance could
+ * belong to a member of the true top-k given a rigorous per-pair error bound (Cauchy-Schwarz on the fp16
+ * rounding residuals + the fp32 accumulation slack d 2^-24), and the survivors near the k-th distance (k + a few
+ * per query) are recomputed from the resident fp32 rows with fp64 accumulation.  out_val are
+ * fl32((|x|^2 + |y|^2) - 2 x.y) with correctly rounded dot products; ties: lowest index first.  The lists do not
+ * depend on the fp16 pass (csrc/match_f16r.h has the derivation).
+ *   oibl_match_prepare_f16r : x [rows][d] fp32 (d % 64 == 0) -> norms[rows] (the fp32 squared norms of
+ *       oibl_match_prepare), rows_f16 [rows][d] (IEEE binary16 of x 2^e, e per row), aux [rows][4] fp32 =
+ *       {2^-e, |x| rounded up, |x - rows_f16 2^-e| rounded up, 0}.  The fp32 rows themselves are the fourth
+ *       part of a prepared operand: they are read again by the rescoring.
+ *   oibl_sqdist_topk_f16r : k <= 1024; problems too small for the fused path, exact != 0, and the repeat after
+ *       *overflow (device int32, may be NULL: a candidate list outgrew its capacity, or more than 32 (k <= 16;
+ *       2k + 32 otherwise) candidates sat within the bound of the k-th distance — near-duplicate galleries)
+ *       run fp32 distance tiles + oibl_row_topk on the fp32 rows (what OIBL_F32 runs).                      */
+int oibl_match_prepare_f16r(const float* x, int rows, int d, float* norms, float* aux, void* rows_f16,
+                            void* stream);
+size_t oibl_sqdist_topk_f16r_workspace_bytes(int m, int n, int d, int k);
+int oibl_sqdist_topk_f16r(const void* xh, const float* xaux, const float* xn, const float* xsrc, int m,
+                          const void* yh, const float* yaux, const float* yn, const float* ysrc, int n, int d,
+                          int k, int index_base, int exact, float* out_val, int32_t* out_idx, int32_t* overflow,
+                          void* ws, size_t ws_bytes, void* stream);
+
 /* ---- top-k ------------------------------------------------------------------------ *
  * Replaces np.argsort(distmat, axis=1) (ibl/evaluators.py:143), of which evaluate_all only
  * consumes the first max(recall_topk) (or 12x that with nms) entries per row.

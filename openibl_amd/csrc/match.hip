@@ -832,6 +832,8 @@ __global__ __launch_bounds__(256) void first_hit_rank_kernel(const int32_t* __re
 
 }  // namespace oibl
 
+#include "match_f16r.h"   // fp16 filter + exact rescoring (uses ordered_bits and the ring kernel's tile order)
+
 using namespace oibl;
 
 extern "C" {
@@ -1355,6 +1357,177 @@ int oibl_sqdist_topk_prepared(const void* xo, const float* xn, int m, const void
   }
   return sqdist_topk_core(xo, xn, m, yo, yn, n, d, k, index_base, precision, exact, out_val, out_idx,
                           overflow, (char*)ws, t, (hipStream_t)stream);
+}
+
+// ---- f16r: fp16 filter pass + exact rescoring (match_f16r.h) --------------------------------------
+int oibl_match_prepare_f16r(const float* x, int rows, int d, float* norms, float* aux, void* rows_f16,
+                            void* stream) {
+  OIBL_REQUIRE(x && norms && aux && rows_f16, "match_prepare_f16r: null pointer");
+  OIBL_REQUIRE(rows > 0 && d > 0 && d % 64 == 0, "match_prepare_f16r: unsupported shape rows=%d d=%d", rows, d);
+  OIBL_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)rows_f16 % 16 == 0 && (uintptr_t)aux % 16 == 0,
+               "match_prepare_f16r: x, rows_f16 and aux must be 16-byte aligned");
+  hipLaunchKernelGGL(f16r_prepare_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, norms,
+                     (float4*)aux, (uint16_t*)rows_f16, rows, d);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
+
+// candidates kept per query for the rescoring (row_topk's register selection path up to 32)
+static int f16r_k2(int k) { return k <= 16 ? 32 : 2 * k + 32; }
+
+struct F16rPlan {
+  TopkPlan t;
+  bool fused;
+  int K2;
+  size_t off_lval, off_lidx, off_ymax, total;
+};
+static F16rPlan f16r_plan(int m, int n, int d, int k) {
+  F16rPlan f = {};
+  f.t = topk_plan(m, n, d, k, OIBL_BF16, 0);   // 2-byte operand rows: the bf16 plan's sample / capacity / legality
+  f.K2 = f16r_k2(k);
+  f.fused = f.t.fused && f.K2 <= F16R_MAX_K2 && f.K2 <= f.t.cap;
+  size_t o = f.t.total;
+  f.off_lval = o;
+  o += align_up((size_t)m * f.K2 * sizeof(float), 256);
+  f.off_lidx = o;
+  o += align_up((size_t)m * f.K2 * sizeof(int32_t), 256);
+  f.off_ymax = o;
+  o += 256;
+  f.total = o;
+  return f;
+}
+
+size_t oibl_sqdist_topk_f16r_workspace_bytes(int m, int n, int d, int k) {
+  if (m <= 0 || n <= 0 || d <= 0 || k <= 0) return 0;
+  return f16r_plan(m, n, d, k).total;
+}
+
+extern "C++" {
+template <bool FILTER>
+static int launch_pairwise_f16r(F16rParams& p, hipStream_t st, int ksplit = 1) {
+  p.tiles_m = (p.m + 255) / 256;
+  p.tiles_n = (p.n + 255) / 256;
+  p.group_m = g_match_group;
+  const long grid = (long)p.tiles_m * p.tiles_n;
+  OIBL_REQUIRE(grid > 0 && grid <= 0x7fffffffL, "sqdist_topk_f16r: grid out of range");
+  constexpr int lds = RingGeo<2>::MAIN_LDS;
+  if (g_match_bar1) {
+    auto kern = pairwise_f16r_kernel<FILTER, true>;
+    OIBL_SET_MAX_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)ksplit), dim3(512), lds, st, p);
+  } else {
+    auto kern = pairwise_f16r_kernel<FILTER, false>;
+    OIBL_SET_MAX_LDS(kern, lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid, (unsigned)ksplit), dim3(512), lds, st, p);
+  }
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
+}  // extern "C++"
+
+int oibl_sqdist_topk_f16r(const void* xh, const float* xaux, const float* xn, const float* xsrc, int m,
+                          const void* yh, const float* yaux, const float* yn, const float* ysrc, int n, int d,
+                          int k, int index_base, int exact, float* out_val, int32_t* out_idx, int32_t* overflow,
+                          void* ws, size_t ws_bytes, void* stream) {
+  OIBL_REQUIRE(xh && xaux && xn && xsrc && yh && yaux && yn && ysrc && out_val && out_idx && ws,
+               "sqdist_topk_f16r: null pointer");
+  int rc = topk_args_ok(m, n, d, k, index_base, OIBL_F32);
+  if (rc) return rc;
+  OIBL_REQUIRE((uintptr_t)ws % 256 == 0 && (uintptr_t)xh % 16 == 0 && (uintptr_t)yh % 16 == 0 &&
+                   (uintptr_t)xsrc % 16 == 0 && (uintptr_t)ysrc % 16 == 0 && (uintptr_t)xaux % 16 == 0 &&
+                   (uintptr_t)yaux % 16 == 0,
+               "sqdist_topk_f16r: workspace must be 256-byte, rows and aux 16-byte aligned");
+  const F16rPlan f = f16r_plan(m, n, d, k);
+  if (ws_bytes < f.total) {
+    set_error("sqdist_topk_f16r: workspace %zu < required %zu bytes", ws_bytes, f.total);
+    return OIBL_E_WORKSPACE;
+  }
+  char* wsb = (char*)ws;
+  hipStream_t st = (hipStream_t)stream;
+  const TopkPlan& t = f.t;
+  if (!f.fused || exact) {
+    // the exact path: fp32 distance tiles of the resident fp32 rows + row_topk (what OIBL_F32 runs)
+    return sqdist_topk_core(xsrc, xn, m, ysrc, yn, n, d, k, index_base, OIBL_F32, 1, out_val, out_idx, overflow, wsb,
+                            t, st);
+  }
+  if (overflow) OIBL_HIP_CHECK(hipMemsetAsync(overflow, 0, sizeof(int32_t), st));
+  float* sample = (float*)(wsb + t.off_sample);
+  float* sval = (float*)(wsb + t.off_sval);
+  int32_t* sidx = (int32_t*)(wsb + t.off_sidx);
+  int* cnt = (int*)(wsb + t.off_cnt);
+  unsigned* ymax = (unsigned*)(wsb + f.off_ymax);
+  OIBL_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)(m + 1) * sizeof(int), st));
+  OIBL_HIP_CHECK(hipMemsetAsync(ymax, 0, 16, st));
+  // 1. thresholds: k-th smallest filter distance to a strided sample of S gallery rows
+  F16rParams q = {};
+  q.x = xh;
+  q.y = yh;
+  q.xn = xn;
+  q.yn = yn;
+  q.xaux = (const float4*)xaux;
+  q.yaux = (const float4*)yaux;
+  q.dist = sample;
+  q.ldd = (size_t)t.S;
+  q.x_bytes = (unsigned)((size_t)m * d * 2);
+  q.y_bytes = (unsigned)((size_t)n * d * 2);
+  q.y_row_bytes = (long)d * 2 * t.stride;
+  q.y_stride = t.stride;
+  q.m = m;
+  q.n = t.S;
+  q.d = d;
+  q.ymax = ymax;
+  q.gamma = (float)d * 5.9604645e-8f;
+  const size_t half = align_up((size_t)m * t.S * sizeof(float), 256) / sizeof(float);
+  if (t.ksplit == 2) q.part_stride = half;
+  rc = launch_pairwise_f16r<false>(q, st, t.ksplit);
+  if (rc) return rc;
+  launch_row_topk(sample, nullptr, m, t.S, (size_t)t.S, k, 0, sval, sidx, nullptr, nullptr, st,
+                  t.ksplit == 2 ? sample + half : nullptr);
+  OIBL_LAUNCH_CHECK();
+  // 2. the full contraction, keeping the pairs whose filter distance could belong to a member of the true top-k
+  q.part_stride = 0;
+  q.dist = nullptr;
+  q.y_row_bytes = (long)d * 2;
+  q.y_stride = 1;
+  q.n = n;
+  q.thr = sval + (k - 1);
+  q.thr_stride = k;
+  q.cand_val = (float*)(wsb + t.off_cval);
+  q.cand_idx = (int32_t*)(wsb + t.off_cidx);
+  q.cand_cnt = cnt;
+  q.cap = t.cap;
+  q.index_base = index_base;
+  rc = launch_pairwise_f16r<true>(q, st);
+  if (rc) return rc;
+  // 3. the K2 smallest filter distances of every list, ascending (a list beyond its capacity raises *overflow)
+  float* lval = (float*)(wsb + f.off_lval);
+  int32_t* lidx = (int32_t*)(wsb + f.off_lidx);
+  launch_row_topk(q.cand_val, q.cand_idx, m, t.cap, (size_t)t.cap, f.K2, 0, lval, lidx, cnt, (int*)overflow, st);
+  OIBL_LAUNCH_CHECK();
+  // 4. exact distances of the rescore set, final selection
+  F16rRescoreParams r = {};
+  r.xsrc = xsrc;
+  r.ysrc = ysrc;
+  r.xn = xn;
+  r.yn = yn;
+  r.xaux = (const float4*)xaux;
+  r.yaux = (const float4*)yaux;
+  r.lval = lval;
+  r.lidx = lidx;
+  r.cnt = cnt;
+  r.ymax = ymax;
+  r.m = m;
+  r.d = d;
+  r.k = k;
+  r.K2 = f.K2;
+  r.index_base = index_base;
+  r.gamma = q.gamma;
+  r.out_val = out_val;
+  r.out_idx = out_idx;
+  r.overflow = (int*)overflow;
+  hipLaunchKernelGGL(f16r_rescore_kernel, dim3((unsigned)m), dim3(256), 0, st, r);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
 }
 
 int oibl_first_hit_rank(const int32_t* topk_idx, int m, int k, const int32_t* gt_offsets,

@@ -1,0 +1,422 @@
+// "f16r": fp16 FILTER pass + EXACT rescoring — fused distance + top-k with fp32-exact lists at the speed of a
+// 2-byte operand stream.  Included by match.hip behind the ring distance kernel.
+// Reference behaviour: pairwise_distance + the argsort prefix evaluate_all reads (ibl/evaluators.py:105-130,
+// 142-159), i.e. the k nearest gallery rows per query by fp32 squared-L2.
+//
+// Idea.  The parity modes pay 1.5 (f16mx) or 3 (bf16x3) matrix-instruction times per product for EVERY pair,
+// although only ~k of a query's n distances are ever read.  Here every pair costs ONE fp16 MFMA product, and
+// the few pairs that can reach the top-k are recomputed exactly:
+//
+//   prepare   a row x becomes xh = fp16(x * 2^e) (e: the row's largest element lands in [2^14, 2^15), results
+//             below the fp16 normals are flushed to zero EXPLICITLY), plus four fp32 scalars: 2^-e, |x|, and
+//             |r| = |x - xh 2^-e| — the residual is formed exactly (fp32 subtraction of a value and its own
+//             fp16 rounding) and its norm rounded up.  The fp32 rows stay resident for the rescoring.
+//   bound     for any pair, by Cauchy-Schwarz,
+//               |x.y - xh.yh| <= |rx||y| + |x||ry| + |rx||ry|,   and the fp32 accumulation of the 2-byte stream
+//               moves the computed dot product by at most g (|x| + |rx|)(|y| + |ry|), g = d 2^-24 (the figure
+//               the split-K sample slack of this file has always used), so the filter distance D_h and the
+//               distance D the rescoring returns differ by at most
+//               eps(i, j) = A_i |y_j| + B_i |ry_j| + tiny,  A_i = 2 (|rx_i| + g (|x_i| + |rx_i|)),
+//                                                              B_i = 2 (|x_i| + |rx_i|) (1 + g).
+//             Nothing here is statistical: a pair outside a threshold widened by eps is outside for D as well.
+//   filter    thr_i = k-th smallest D_h over a strided sample of S gallery rows (same kernel).  The k-th
+//             smallest TRUE distance of the whole gallery is <= thr_i + max_s eps(i, s), so every member of the
+//             true top-k has D_h <= thr_i + max_s eps(i, s) + eps(i, j): that is the filter's test (two fma per
+//             pair in the epilogue).  Survivors go to per-query candidate lists, as in the other modes.
+//   select    the K2 (32 for k <= 16) smallest D_h of every list, ascending (row_topk).  With T = the k-th of
+//             them, a member of the true top-k has D_h <= T + max_{e < k} eps_e + eps(i, j): the RESCORE SET,
+//             typically k + 2..5 entries.  If entry K2 - 1 is still inside it and the list was longer, the set
+//             may be truncated: *overflow is raised and the caller repeats on the exact fp32 path.
+//   rescore   for the set only: x.y from the resident fp32 rows, accumulated in fp64 (one wave per pair, a 16 KB
+//             contiguous gather per gallery row), D = fl32((|x|^2 + |y|^2) - 2 x.y) with the fp32 norms every
+//             mode uses; the k smallest (D, index) leave, lowest index first on ties.
+// The lists are therefore those of an fp32 matrix whose dot products are correctly rounded — closer to the fp64
+// oracle than the fp32 MFMA mode itself — and nothing about them depends on the fp16 pass except their cost.
+#pragma once
+
+#include "ring_core.h"
+
+namespace oibl {
+
+struct F16rParams {
+  const void* x;          // [m][d] fp16, scaled rows
+  const void* y;          // gallery rows at y_row_bytes
+  const float* xn;        // fp32 squared norms (of the fp32 rows)
+  const float* yn;        // yn[col * y_stride]
+  const float4* xaux;     // {2^-e, |x| (rounded up), |residual| (rounded up), 0}
+  const float4* yaux;     // yaux[col * y_stride]
+  float* dist;            // !FILTER: [m][ldd]
+  size_t ldd;
+  unsigned x_bytes, y_bytes;
+  long y_row_bytes;
+  int y_stride;
+  int m, n, d, tiles_m, tiles_n, group_m;
+  const float* thr;       // FILTER: thr[row * thr_stride]
+  int thr_stride;
+  float* cand_val;
+  int32_t* cand_idx;
+  int* cand_cnt;
+  int cap, index_base;
+  size_t part_stride;     // 2-way split-K of the sample pass (gridDim.y = 2): half h writes dist + h * part_stride
+  unsigned* ymax;         // [4] bit patterns of max |y|, max |ry|: [0], [1] over the SAMPLE columns — written
+                          // (atomicMax) by the !FILTER launch, read by the FILTER launch; [2], [3] over ALL gallery
+                          // columns — written by the FILTER launch, read by the rescoring
+  float gamma;            // d * 2^-24
+};
+
+// fp32 rows -> scaled fp16 rows + norms + the four scalars; one wave per row.  The squared norm is formed
+// exactly as row_sqnorm_kernel forms it (same loop, same reduction): bit-identical to the fp32 mode's.
+__global__ __launch_bounds__(256) void f16r_prepare_kernel(const float* __restrict__ x, float* __restrict__ norms,
+                                                           float4* __restrict__ aux, uint16_t* __restrict__ xh,
+                                                           int rows, int d) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * d;
+  float s = 0.f, mx = 0.f;
+  for (int i = lane * 4; i < d; i += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + i);
+    s = fmaf(v.x, v.x, s);
+    s = fmaf(v.y, v.y, s);
+    s = fmaf(v.z, v.z, s);
+    s = fmaf(v.w, v.w, s);
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  s = wave_sum(s);
+  mx = wave_max(mx);
+  int e = 0;
+  if (mx > 0.f && mx < INFINITY) {
+    int ex;
+    (void)frexpf(mx, &ex);   // mx = f 2^ex, f in [0.5, 1)
+    e = 15 - ex;             // mx 2^e in [2^14, 2^15)
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+  }
+  const float sc = ldexpf(1.0f, e), isc = ldexpf(1.0f, -e);
+  uint16_t* hr = xh + (size_t)row * d;
+  float rs = 0.f;
+  for (int i = lane * 4; i < d; i += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + i);
+    const float t[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};   // exact (power of two; no under/overflow: |e| <= 100)
+    uint16_t h[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      // below the fp16 normals the element is dropped here, whatever the matrix pipe would do with a denormal;
+      // it stays in the residual, so the bound holds either way
+      h[c] = fabsf(t[c]) < 6.103515625e-5f ? (uint16_t)0 : f32_to_f16_bits(t[c]);
+      const float r = t[c] - f16_bits_to_f32(h[c]);   // exact
+      rs = fmaf(r, r, rs);
+    }
+    uint2 o;
+    o.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+    o.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+    *reinterpret_cast<uint2*>(hr + i) = o;
+  }
+  rs = wave_sum(rs);
+  if (lane == 0) {
+    norms[row] = s;
+    // rounded UP: the fp32 sums above carry ~d 2^-24 relative error at most
+    const float up = 1.0f + 1.0f / 1024.0f;
+    aux[row] = make_float4(isc, sqrtf(s) * up, sqrtf(rs) * isc * up, 0.f);
+  }
+}
+
+// The ring distance kernel on fp16 rows (RING_F16: the bf16 stream with v_mfma_f32_32x32x16_f16), tile order and
+// main loop exactly pairwise_ring_kernel's; the epilogue undoes the row scales and, with FILTER, widens every
+// row's threshold by the pair's error bound.
+template <bool FILTER, bool BAR1>
+__global__ __launch_bounds__(512) void pairwise_f16r_kernel(F16rParams p) {
+  using G = RingGeo<2>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / G::WN, wn = wave % G::WN;
+  const unsigned id = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned gm = (unsigned)p.group_m;
+  const unsigned width = gm * (unsigned)p.tiles_n;
+  const unsigned grp = id / width, in_grp = id - grp * width;
+  const unsigned first_m = grp * gm;
+  const unsigned gsz = (unsigned)p.tiles_m - first_m < gm ? (unsigned)p.tiles_m - first_m : gm;
+  const int tm = (int)(first_m + in_grp % gsz), tn = (int)(in_grp / gsz);
+  const int m0 = tm * G::BM, n0 = tn * G::BN;
+
+  const int piece = ring_piece(wave, lane);
+  int rows_a[4], rows_b[4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      rows_a[2 * h + i] = ring_a_row<2>(wave, lane, h, i);
+      rows_b[2 * h + i] = ring_b_row<2>(wave, lane, h, i);
+    }
+  const int ksplit = (int)gridDim.y, kh = (int)blockIdx.y;
+  const int d_part = p.d / ksplit;
+  const unsigned koff = (unsigned)kh * (unsigned)d_part * 2u;
+  RingRowLoader<2> la, lb;
+  la.init(static_cast<const char*>(p.x) + koff, p.x_bytes - koff, m0, p.m, (long)p.d * 2, rows_a, piece);
+  lb.init(static_cast<const char*>(p.y) + koff, p.y_bytes - koff, n0, p.n, p.y_row_bytes, rows_b, piece);
+
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if constexpr (BAR1) {
+    if ((wave >> 2) == 0) ring_mainloop<2, false, false, RING_F16, true, 0>(acc, smem, wave, lane, la, lb, d_part >> 6);
+    else ring_mainloop<2, false, false, RING_F16, true, 1>(acc, smem, wave, lane, la, lb, d_part >> 6);
+  } else {
+    ring_mainloop<2, false, false, RING_F16>(acc, smem, wave, lane, la, lb, d_part >> 6);
+  }
+
+  float* const xn_s = reinterpret_cast<float*>(smem);   // 256 floats each
+  float* const yn_s = xn_s + 256;
+  float* const th_s = xn_s + 512;
+  float* const xs_s = xn_s + 768;     // -2 * 2^-ex
+  float* const xa_s = xn_s + 1024;    // A_i
+  float* const xb_s = xn_s + 1280;    // B_i
+  float* const ys_s = xn_s + 1536;    // 2^-ey
+  float* const yy_s = xn_s + 1792;    // |y_j|
+  float* const yr_s = xn_s + 2048;    // |ry_j|
+  if (threadIdx.x < 256) {
+    int r = m0 + (int)threadIdx.x;
+    if (r > p.m - 1) r = p.m - 1;
+    const float xn = p.xn[r];
+    const float4 a = p.xaux[r];
+    xn_s[threadIdx.x] = kh == 0 ? xn : 0.f;
+    xs_s[threadIdx.x] = -2.0f * a.x;
+    if (FILTER) {
+      const float nx = a.y, rx = a.z;
+      const float A = 2.0f * (rx + p.gamma * (nx + rx)), B = 2.0f * (nx + rx) * (1.0f + p.gamma);
+      const float ymx = __uint_as_float(p.ymax[0]), rmx = __uint_as_float(p.ymax[1]);
+      xa_s[threadIdx.x] = A;
+      xb_s[threadIdx.x] = B;
+      // sample k-th + the largest bound over the sample + the fp32 roundings of the two final distances
+      th_s[threadIdx.x] = p.thr[(long)r * p.thr_stride] + fmaf(A, ymx, B * rmx) + 1e-6f * (xn + ymx * ymx);
+    }
+  } else {
+    int c = n0 + (int)threadIdx.x - 256;
+    if (c > p.n - 1) c = p.n - 1;
+    const float yn = p.yn[(long)c * p.y_stride];
+    const float4 a = p.yaux[(long)c * p.y_stride];
+    yn_s[threadIdx.x - 256] = kh == 0 ? yn : 0.f;
+    ys_s[threadIdx.x - 256] = a.x;
+    yy_s[threadIdx.x - 256] = a.y;
+    yr_s[threadIdx.x - 256] = a.z;
+    if (p.ymax && kh == 0 && tm == 0) {  // one column of tiles covers every column of the launch once
+      const float my = wave_max(a.y), mr = wave_max(a.z);   // (non-negative: bit patterns order as integers)
+      if (lane == 0) {
+        atomicMax(p.ymax + (FILTER ? 2 : 0), __float_as_uint(my));
+        atomicMax(p.ymax + (FILTER ? 3 : 1), __float_as_uint(mr));
+      }
+    }
+  }
+  __syncthreads();
+  const int col0 = wn * 64 + (lane & 31), row0 = wm * 128 + 4 * (lane >> 5);
+  if constexpr (!FILTER) {
+    // (stores through one buffer descriptor per 32-row accumulator tile, scalar row offsets: pairwise_ring_kernel)
+    const float* const dbase = p.dist + (size_t)kh * p.part_stride + ((size_t)m0 + wm * 128) * p.ldd + n0;
+    const unsigned ldd4 = (unsigned)p.ldd * 4u;
+    const unsigned voff = (unsigned)(4 * (lane >> 5)) * ldd4 + (unsigned)col0 * 4u;
+    const int rows_left = p.m - m0 - row0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(dbase + (size_t)(32 * i) * p.ldd), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bool nok = n0 + col0 + 32 * j < p.n;
+        const float yn = yn_s[col0 + 32 * j], ys = ys_s[col0 + 32 * j];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rt = (r & 3) + 8 * (r >> 2), ro = 32 * i + rt;
+          const float dv = fmaf(acc[i][j][r] * ys, xs_s[row0 + ro], xn_s[row0 + ro] + yn);
+          if (nok && ro < rows_left)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dv), rs_d, (int)voff,
+                                                  (int)((unsigned)rt * ldd4 + 128u * j), 0);
+          if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  } else {
+    // per-lane survivor lists, then one round of atomics per tile (pairwise_ring_kernel, FILTER)
+    constexpr int LCAP = 8;
+    float* const l_val = reinterpret_cast<float*>(smem + 12288);
+    int* const l_idx = reinterpret_cast<int*>(smem + 12288 + LCAP * 512 * 4);
+    int* const l_row = reinterpret_cast<int*>(smem + 12288 + 2 * LCAP * 512 * 4);
+    const int rows_left = p.m - m0 - row0;
+    int nl = 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + col0 + 32 * j;
+      const bool nok = n < p.n;
+      const float yn = yn_s[col0 + 32 * j], ys = ys_s[col0 + 32 * j];
+      const float yy = yy_s[col0 + 32 * j], yr = yr_s[col0 + 32 * j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ro = 32 * i + (r & 3) + 8 * (r >> 2);
+          const float dv = fmaf(acc[i][j][r] * ys, xs_s[row0 + ro], xn_s[row0 + ro] + yn);
+          const float bound = th_s[row0 + ro] + fmaf(xa_s[row0 + ro], yy, xb_s[row0 + ro] * yr);
+          // !(dv > bound): a NaN on either side KEEPS the pair (the list then overflows into the exact path)
+          if (nok && ro < rows_left && !(dv > bound)) {
+            const int m = m0 + row0 + ro;
+            if (nl < LCAP) {
+              l_val[nl * 512 + threadIdx.x] = dv;
+              l_idx[nl * 512 + threadIdx.x] = p.index_base + n;
+              l_row[nl * 512 + threadIdx.x] = m;
+              ++nl;
+            } else {
+              const int pos = atomicAdd(p.cand_cnt + m, 1);
+              if (pos < p.cap) {
+                p.cand_val[(size_t)m * p.cap + pos] = dv;
+                p.cand_idx[(size_t)m * p.cap + pos] = p.index_base + n;
+              }
+            }
+          }
+        }
+    }
+    int e_row[LCAP], e_pos[LCAP];
+#pragma unroll
+    for (int e = 0; e < LCAP; ++e) {
+      e_row[e] = e < nl ? l_row[e * 512 + threadIdx.x] : 0;
+      e_pos[e] = p.cap;
+    }
+#pragma unroll
+    for (int e = 0; e < LCAP; ++e)
+      if (e < nl) e_pos[e] = atomicAdd(p.cand_cnt + e_row[e], 1);
+#pragma unroll
+    for (int e = 0; e < LCAP; ++e)
+      if (e < nl && e_pos[e] < p.cap) {
+        p.cand_val[(size_t)e_row[e] * p.cap + e_pos[e]] = l_val[e * 512 + threadIdx.x];
+        p.cand_idx[(size_t)e_row[e] * p.cap + e_pos[e]] = l_idx[e * 512 + threadIdx.x];
+      }
+  }
+}
+
+struct F16rRescoreParams {
+  const float* xsrc;      // [m][d] fp32 rows
+  const float* ysrc;      // [n][d] fp32 rows
+  const float* xn;
+  const float* yn;
+  const float4* xaux;
+  const float4* yaux;
+  const float* lval;      // [m][K2] D_h ascending ((+inf, -1) paddings)
+  const int32_t* lidx;    // [m][K2] global indices
+  const int* cnt;         // candidates the filter found per query
+  const unsigned* ymax;   // F16rParams::ymax ([2], [3]: the maxima over the whole gallery)
+  int m, d, k, K2, index_base;
+  float gamma;
+  float* out_val;         // [m][k]
+  int32_t* out_idx;
+  int* overflow;
+};
+
+constexpr int F16R_MAX_K2 = 1024;
+
+__device__ static inline double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned lo = __shfl_xor((unsigned)__double2loint(v), o, 64);
+    const unsigned hi = __shfl_xor((unsigned)__double2hiint(v), o, 64);
+    v += __hiloint2double((int)hi, (int)lo);
+  }
+  return v;
+}
+
+// one workgroup (4 waves) per query
+__global__ __launch_bounds__(256) void f16r_rescore_kernel(F16rRescoreParams p) {
+  __shared__ float s_val[F16R_MAX_K2];     // D_h, then D for members of the rescore set (+inf outside)
+  __shared__ float s_eps[F16R_MAX_K2];
+  __shared__ int s_idx[F16R_MAX_K2];
+  __shared__ unsigned s_epsT;
+  __shared__ int s_nfin;
+  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K2 = p.K2, k = p.k;
+  const float4 xa = p.xaux[q];
+  const float nx = xa.y, rx = xa.z, xn = p.xn[q];
+  const float A = 2.0f * (rx + p.gamma * (nx + rx)), B = 2.0f * (nx + rx) * (1.0f + p.gamma);
+  if (tid == 0) {
+    s_epsT = 0u;
+    s_nfin = 0;
+  }
+  __syncthreads();
+  for (int e = tid; e < K2; e += 256) {
+    const float v = p.lval[(size_t)q * K2 + e];
+    const int id = p.lidx[(size_t)q * K2 + e];
+    float eps = 0.f;
+    if (id >= 0) {
+      const float4 ya = p.yaux[id - p.index_base];
+      const float yn = p.yn[id - p.index_base];
+      eps = fmaf(A, ya.y, B * ya.z) + 1e-6f * (xn + yn);
+      if (!(eps >= 0.f)) eps = INFINITY;   // NaN: keep everything
+      if (e < k) atomicMax(&s_epsT, __float_as_uint(eps));
+    }
+    s_val[e] = v;
+    s_idx[e] = id;
+    s_eps[e] = eps;
+  }
+  __syncthreads();
+  // T = k-th smallest D_h (fewer than k candidates: everything is a member)
+  const float T = (k - 1 < K2 && s_idx[k - 1] >= 0) ? s_val[k - 1] : INFINITY;
+  const float epsT = __uint_as_float(s_epsT);
+  // Were members cut off?  The filter found more candidates than the K2 kept ones, and a candidate behind the last
+  // kept one (D_h >= the last kept D_h) could still be a member: its bound is at most the gallery-wide one.
+  if (tid == 0 && p.cnt[q] > K2 && p.overflow) {
+    const float ymx = __uint_as_float(p.ymax[2]), rmx = __uint_as_float(p.ymax[3]);
+    const float eps_any = fmaf(A, ymx, B * rmx) + 1e-6f * (xn + ymx * ymx);
+    if (!(s_val[K2 - 1] > T + epsT + eps_any)) atomicOr(p.overflow, 1);
+  }
+  __syncthreads();
+  // membership; D of the members (one wave per pair: fp64 accumulation over the resident fp32 rows)
+  const float* xr = p.xsrc + (size_t)q * p.d;
+  for (int e = wave; e < K2; e += 4) {
+    const int id = s_idx[e];                       // wave-uniform
+    const bool in = id >= 0 && !(s_val[e] > T + epsT + s_eps[e]);
+    if (!in) {
+      if (lane == 0) s_idx[e] = -1;
+      continue;
+    }
+    const float* yr = p.ysrc + (size_t)(id - p.index_base) * p.d;
+    double acc = 0.0;
+    for (int i = lane * 4; i < p.d; i += 256) {
+      const float4 a = *reinterpret_cast<const float4*>(xr + i);
+      const float4 b = *reinterpret_cast<const float4*>(yr + i);
+      acc = fma((double)a.x, (double)b.x, acc);
+      acc = fma((double)a.y, (double)b.y, acc);
+      acc = fma((double)a.z, (double)b.z, acc);
+      acc = fma((double)a.w, (double)b.w, acc);
+    }
+    acc = wave_sum_f64(acc);
+    if (lane == 0) {
+      const float yn = p.yn[id - p.index_base];
+      s_val[e] = (float)((double)(xn + yn) - 2.0 * acc);
+      atomicAdd(&s_nfin, 1);
+    }
+  }
+  __syncthreads();
+  // rank of every member among the members by (D, index): keys are unique (indices are)
+  for (int e = tid; e < K2; e += 256) {
+    const int id = s_idx[e];
+    if (id < 0) continue;
+    const unsigned long long key = ((unsigned long long)ordered_bits(s_val[e]) << 32) | (unsigned)id;
+    int rank = 0;
+    for (int f = 0; f < K2; ++f) {
+      const int idf = s_idx[f];
+      const unsigned long long kf = ((unsigned long long)ordered_bits(s_val[f]) << 32) | (unsigned)idf;
+      rank += (idf >= 0 && kf < key) ? 1 : 0;
+    }
+    if (rank < k) {
+      p.out_val[(size_t)q * k + rank] = s_val[e];
+      p.out_idx[(size_t)q * k + rank] = id;
+    }
+  }
+  for (int r = s_nfin + tid; r < k; r += 256) {   // fewer members than k (a gallery shorter than k): pad
+    p.out_val[(size_t)q * k + r] = INFINITY;
+    p.out_idx[(size_t)q * k + r] = -1;
+  }
+}
+
+}  // namespace oibl

@@ -70,6 +70,8 @@ constexpr unsigned RG_OOB = 0xF0000000u;  // voffset that is out of range for ev
 
 // operand arithmetic of an instantiation (template argument P; false / true of the older bool
 // parameter convert to RING_BF16 / RING_X3)
+constexpr int RING_F16 = -1;  // fp16 rows: the bf16 stream with v_mfma_f32_32x32x16_f16 (match.hip: the filter pass
+                              // of the fp16-filter + exact-rescore top-k; every `P >= ...` test below reads it as bf16)
 constexpr int RING_BF16 = 0;  // bf16 rows, 64 K per 128-byte K-tile, 8 MFMAs per phase
 constexpr int RING_X3 = 1;    // bf16x3 rows ([32 hi | 32 lo]), 32 K per K-tile, 12 MFMAs per phase
 constexpr int RING_MX = 2;    // f16mx rows (common.h), 32 K per K-tile, 4 f16 + 2 MX-fp6 MFMAs per phase;
@@ -284,9 +286,15 @@ __device__ static inline void ring_mainloop(f32x16_t (&acc)[4][2], char* smem, i
       __builtin_amdgcn_s_setprio(1);
     }
     auto mma = [&](int i2, int ka, int kb) __attribute__((always_inline)) {
-      acc[2 * h + i2][j] =
-          SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kb], fa[i2][ka], acc[2 * h + i2][j], 0, 0, 0)
-               : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i2][ka], fb[kb], acc[2 * h + i2][j], 0, 0, 0);
+      if constexpr (P == RING_F16) {
+        const f16x8_t a = __builtin_bit_cast(f16x8_t, fa[i2][ka]), b = __builtin_bit_cast(f16x8_t, fb[kb]);
+        acc[2 * h + i2][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, acc[2 * h + i2][j], 0, 0, 0)
+                                  : __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[2 * h + i2][j], 0, 0, 0);
+      } else {
+        acc[2 * h + i2][j] =
+            SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kb], fa[i2][ka], acc[2 * h + i2][j], 0, 0, 0)
+                 : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i2][ka], fb[kb], acc[2 * h + i2][j], 0, 0, 0);
+      }
     };
     if constexpr (P == RING_MX_NOMFMA) {
       asm volatile("" : "+v"(acc[2 * h][j]), "+v"(acc[2 * h + 1][j]));

@@ -356,11 +356,14 @@ class Evaluator(object):
                     "device_resident=False for the reference's host flow")
         # queries: prepared where they were extracted, exchanged in prepared form; gallery shard:
         # prepared once and resident
+        k = min(max(recall_topk) * (12 if nms else 1), len(gallery))
+        _check_prefix(k)
+        # an f16mx model's fp32 descriptors are matched by the fp16 filter + exact rescoring (fp32-exact lists,
+        # faster than f16mx on every pair): ops.topk_precision
+        prec = ops.topk_precision(prec, q_local.dtype if q_local.dtype == g_local.dtype else None, k)
         q_all = sharded.gather_prepared_queries(q_local, len(query), prec)
         start, _, n_valid = sharded.slice_bounds(len(gallery), rank, world)
         g_local = ops.PreparedRows(g_local[:n_valid].contiguous(), prec)
-        k = min(max(recall_topk) * (12 if nms else 1), len(gallery))
-        _check_prefix(k)
         if rank == 0:
             print("===> Start calculating pairwise distances")
         _, idx = sharded.sharded_topk(q_all, g_local, k, start, prec)

@@ -16,11 +16,13 @@ BF16 = 0
 F32 = 1
 BF16X3 = 2   # split bf16: (hi, lo) operand pairs, three MFMAs per product, fp32-class results
 F16MX = 3    # fp16 main term + MX-fp6 cross terms: 1e-4-class results at half the matrix time of bf16x3
+F16R = 4     # matching only (top-k entry points): fp16 filter pass + exact rescoring from the fp32 rows — fp32-exact
+             # lists at the cost of a 2-byte operand stream (csrc/match_f16r.h); not a backbone / matrix arithmetic
 # element containers: bf16x3 / f16mx activations and packed weights are opaque 4-byte elements (128-byte
 # groups of 32 elements, see x3_split / mx_split) carried in int32 tensors of the logical shape
 _DTYPES = {BF16: torch.bfloat16, F32: torch.float32, BF16X3: torch.int32, F16MX: torch.int32}
 _NAMES = {"bf16": BF16, "bfloat16": BF16, "fp32": F32, "f32": F32, "float32": F32,
-          "bf16x3": BF16X3, "x3": BF16X3, "f16mx": F16MX, "mx": F16MX}
+          "bf16x3": BF16X3, "x3": BF16X3, "f16mx": F16MX, "mx": F16MX, "f16r": F16R}
 
 
 def precision_code(p) -> int:
@@ -29,9 +31,20 @@ def precision_code(p) -> int:
             return _NAMES[p.lower()]
         except KeyError:
             raise ValueError(f"unknown precision {p!r} (use 'bf16', 'f16mx', 'bf16x3' or 'fp32')")
-    if p in (BF16, F32, BF16X3, F16MX):
+    if p in (BF16, F32, BF16X3, F16MX, F16R):
         return int(p)
     raise ValueError(f"unknown precision {p!r}")
+
+
+def topk_precision(precision, storage_dtype=torch.float32, k: int = 10) -> int:
+    """The arithmetic the fused distance + top-k of a model precision runs in: an f16mx model's descriptors are
+    matched in f16r — fp16 filter pass + exact rescoring: fp32-exact lists, and faster than contracting every
+    pair in f16mx — when they are stored as float32 (the rescoring reads the fp32 rows) and k fits its
+    candidate window; everything else as asked."""
+    p = precision_code(precision)
+    if p == F16MX and storage_dtype == torch.float32 and k <= 496:
+        return F16R
+    return p
 
 
 def head_precision(p) -> int:
@@ -581,6 +594,9 @@ def pairwise_sqdist(x: torch.Tensor, y: torch.Tensor, precision=F32,
     """dist[i][j] = |x_i|^2 + |y_j|^2 - 2 x_i.y_j for x [m][d], y [n][d] stored as float32, float16
     or bfloat16 (16-bit rows are widened exactly; see oibl_pairwise_sqdist_st)."""
     p = precision_code(precision)
+    if p == F16R:
+        raise ValueError("pairwise_sqdist: 'f16r' is a top-k arithmetic (filter + rescoring); a full matrix is "
+                         "computed in 'f16mx', 'bf16x3' or 'fp32'")
     dev = _need_cuda(x, y)
     if out is not None and (not out.is_cuda or out.dtype != torch.float32 or out.dim() != 2
                             or out.stride(1) != 1 or out.device != dev):
@@ -714,6 +730,14 @@ def sqdist_topk(x: torch.Tensor, y: torch.Tensor, k: int, index_base: int = 0, p
     dev = _need_cuda(x, y)
     if x.dim() != 2 or y.dim() != 2:
         raise ValueError("sqdist_topk expects [m][d] and [n][d]")
+    if p == F16R:
+        if x.dtype != torch.float32 or y.dtype != torch.float32:
+            raise ValueError("sqdist_topk: 'f16r' rescoring reads float32 rows (use 'f16mx' for 16-bit storage)")
+        if x.shape[0] == 0 or y.shape[0] == 0:
+            p = F32                                           # (nothing to prepare: the empty result below)
+        else:
+            return sqdist_topk_prepared(PreparedRows(x, F16R), PreparedRows(y, F16R), k, index_base=index_base,
+                                        exact=exact, defer_check=defer_check)
     xs, ys = storage_code(x), storage_code(y)
     if int(y.shape[1]) != int(x.shape[1]):
         raise ValueError("sqdist_topk: dimension mismatch")
@@ -780,6 +804,19 @@ class PreparedRows:
         self.precision, self.shape, self.device = p, (rows, d), dev
         self.norms = torch.empty((rows,), dtype=torch.float32, device=dev)
         self.operand = x
+        self.aux = None
+        if p == F16R:
+            # four parts: scaled fp16 rows (the filter pass), {2^-e, |x|, |residual|, 0} per row, the fp32 squared
+            # norms, and the fp32 rows themselves (read again by the rescoring)
+            if x.dtype != torch.float32:
+                raise ValueError("PreparedRows: 'f16r' needs float32 rows (the rescoring reads them)")
+            self._source = x
+            self.operand = torch.empty((rows, d), dtype=torch.float16, device=dev)
+            self.aux = torch.empty((rows, 4), dtype=torch.float32, device=dev)
+            if rows:
+                _lib.check(_lib.load().oibl_match_prepare_f16r(_ptr(x), rows, d, _ptr(self.norms), _ptr(self.aux),
+                                                               _ptr(self.operand), _stream(dev)), "match_prepare_f16r")
+            return
         if rows == 0:
             return
         lib = _lib.load()
@@ -795,6 +832,12 @@ class PreparedRows:
         """The operand as a [rows][bytes per row] uint8 matrix (a view): what travels when prepared
         queries are exchanged between ranks instead of fp32 rows."""
         rows = self.shape[0]
+        if self.precision == F16R:
+            # one row per query: [d fp16 | 4 fp32 aux | d fp32 source] — what a rank that extracted the query ships
+            d = self.shape[1]
+            return torch.cat([self.operand.view(torch.uint8).reshape(rows, 2 * d),
+                              self.aux.view(torch.uint8).reshape(rows, 16),
+                              self._source.view(torch.uint8).reshape(rows, 4 * d)], dim=1)
         per = self.shape[1] * (2 if self.precision == BF16 else 4)
         flat = self.operand.contiguous().view(torch.uint8).reshape(-1)
         return flat[: rows * per].view(rows, per)
@@ -807,9 +850,17 @@ class PreparedRows:
         self.precision = precision_code(precision)
         self.device = operand_rows.device
         self.shape = (int(operand_rows.shape[0]), int(d) + (-int(d)) % 64)
-        self.operand = operand_rows.contiguous()
         self.norms = norms.contiguous()
         self._source = None
+        self.aux = None
+        if self.precision == F16R:
+            rows, dd = self.shape
+            b = operand_rows
+            self.operand = b[:, : 2 * dd].contiguous().view(torch.float16).reshape(rows, dd)
+            self.aux = b[:, 2 * dd: 2 * dd + 16].contiguous().view(torch.float32).reshape(rows, 4)
+            self._source = b[:, 2 * dd + 16:].contiguous().view(torch.float32).reshape(rows, dd)
+            return self
+        self.operand = operand_rows.contiguous()
         return self
 
 
@@ -826,14 +877,25 @@ def sqdist_topk_prepared(x: "PreparedRows", y: "PreparedRows", k: int, index_bas
     if m == 0 or n == 0:
         return (ov, oi, flag) if defer_check else (ov, oi)
     lib = _lib.load()
-    ws = workspace(lib.oibl_sqdist_topk_prepared_workspace_bytes(m, n, d, k, p), dev, "sqdist_topk")
+    if p == F16R:
+        ws = workspace(lib.oibl_sqdist_topk_f16r_workspace_bytes(m, n, d, k), dev, "sqdist_topk")
 
-    def run(ex: int) -> None:
+        def run(ex: int) -> None:
+            _lib.check(lib.oibl_sqdist_topk_f16r(_ptr(x.operand), _ptr(x.aux), _ptr(x.norms), _ptr(x._source), m,
+                                                 _ptr(y.operand), _ptr(y.aux), _ptr(y.norms), _ptr(y._source), n,
+                                                 d, k, int(index_base), ex, _ptr(ov), _ptr(oi), _ptr(flag),
+                                                 _ptr(ws), ws.numel(), _stream(dev)), "sqdist_topk_f16r")
+    else:
+        ws = workspace(lib.oibl_sqdist_topk_prepared_workspace_bytes(m, n, d, k, p), dev, "sqdist_topk")
+
+    def run_generic(ex: int) -> None:
         _lib.check(lib.oibl_sqdist_topk_prepared(_ptr(x.operand), _ptr(x.norms), m, _ptr(y.operand),
                                                  _ptr(y.norms), n, d, k, int(index_base), p, ex, _ptr(ov),
                                                  _ptr(oi), _ptr(flag), _ptr(ws), ws.numel(), _stream(dev)),
                    "sqdist_topk_prepared")
 
+    if p != F16R:
+        run = run_generic
     if defer_check:
         run(1 if exact else 0)
         return ov, oi, flag

@@ -44,6 +44,17 @@ def main():
     if a.only in ("", "topk"):
         t = timed(lambda: ops.sqdist_topk(q, g, a.k, precision="bf16"), a.iters)
         rows.append(("sqdist_topk bf16 (fused)", t))
+    if a.only in ("", "prepared") or a.only.startswith("prepared:"):
+        # resident gallery + prepared queries (bench.py's matching step without the collectives), per arithmetic
+        for prec in (a.only.split(":")[1].split(",") if ":" in a.only else ["bf16", "f16mx", "f16r"]):
+            gp, qp = ops.PreparedRows(g, prec), ops.PreparedRows(q, prec)
+            t = timed(lambda: ops.sqdist_topk_prepared(qp, gp, a.k, defer_check=True), a.iters)
+            rows.append((f"sqdist_topk_prepared {prec}", t))
+            t = timed(lambda: ops.PreparedRows(q, prec), a.iters)
+            rows.append((f"  PreparedRows(queries) {prec}", t))
+            _, _, flag = ops.sqdist_topk_prepared(qp, gp, a.k, defer_check=True)
+            print(f"  [{prec}] overflow flag {int(flag.item())}")
+            del gp, qp
     if a.only in ("", "matrix"):
         t = timed(lambda: ops.pairwise_sqdist(q, g, "bf16", out=out), a.iters)
         rows.append(("pairwise_sqdist bf16 (ring, matrix written)", t))

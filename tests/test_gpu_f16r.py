@@ -1,0 +1,163 @@
+"""'f16r': fp16 filter pass + exact rescoring (csrc/match_f16r.h) — the fused distance +
+top-k whose lists are those of an fp32 matrix with correctly rounded dot products.  Checked here: the prepared
+parts against their definition (the residual bound is what the superset guarantee rests on), the lists against
+the fp64 oracle and against the fp32 mode, rows of any magnitude, the overflow -> exact-path protocol, sharded
+matching, and the reference's golden rankings / recalls."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from openibl_amd import ops, sharded, synth
+from oracle import matching as om
+
+pytestmark = pytest.mark.gpu
+
+
+def _fp64_topk(q, g, k):
+    d = (q.double() ** 2).sum(1)[:, None] + (g.double() ** 2).sum(1)[None] - 2.0 * q.double() @ g.double().t()
+    v, i = torch.sort(d, dim=1, stable=True)
+    return v[:, :k], i[:, :k], d
+
+
+def _assert_lists(name, q, g, v, i, k, tie=2e-6):
+    """(v, i) against fp64: values to fp32 rounding, indices equal except where fp64 calls a near-tie."""
+    wv, wi, d64 = _fp64_topk(q, g, k)
+    v, i = v.cpu(), i.cpu().long()
+    got64 = torch.gather(d64, 1, i)
+    assert (v.double() - got64).abs().max() <= 1e-6 * max(1.0, float(d64.abs().max())), name
+    diff = (i != wi)
+    worst = float((got64 - wv).abs()[diff].max()) if diff.any() else 0.0
+    print(f"{name}: {int(diff.sum())} of {i.numel()} entries differ from fp64, all within {worst:.2e}")
+    assert worst <= tie * max(1.0, float(wv.abs().max())), name
+    return int(diff.sum())
+
+
+def test_prepared_parts_are_what_the_bound_needs(dev):
+    x = synth.descriptors(37, 4096, seed=3)
+    x[5] *= 1e-4                        # any magnitude: the row scale is a power of two per row
+    x[6] *= 3e3
+    x[7] = 0.0
+    x[8, :100] *= 1e-7                  # elements far below the row's fp16 normals: dropped, kept in the residual
+    p = ops.PreparedRows(x.to(dev), "f16r")
+    ref = ops.PreparedRows(x.to(dev), "fp32")
+    assert torch.equal(p.norms, ref.norms)                      # the norms every mode uses, bit for bit
+    h, aux = p.operand.cpu().double(), p.aux.cpu().double()
+    isc, nx, rx = aux[:, 0], aux[:, 1], aux[:, 2]
+    assert torch.equal(torch.log2(isc[isc > 0]).round(), torch.log2(isc[isc > 0]))   # powers of two
+    big = h.abs().amax(1)
+    nz = big > 0
+    assert bool(((big[nz] >= 2.0 ** 14) & (big[nz] < 2.0 ** 15 + 1)).all())
+    resid = (x.double() - h * isc[:, None]).norm(dim=1)
+    assert bool((resid <= rx).all()) and bool((x.double().norm(dim=1) <= nx).all())   # rounded UP
+    assert bool((rx[nz] <= 2.0 ** -11 * nx[nz]).all())          # fp16: 11 significant bits
+    assert float(rx[7]) == 0.0 and float(nx[7]) == 0.0
+
+
+@pytest.mark.parametrize("m,n,d,k", [(512, 16384, 256, 10), (300, 20000, 4096, 10), (256, 16500, 512, 25),
+                                     (700, 9000, 128, 5)])
+def test_fused_lists_are_fp32_exact(dev, m, n, d, k):
+    q, g, gt, pids = synth.retrieval_problem(m, n, dim=d, seed=m + n, hard_fraction=0.5)
+    v, i, flag = ops.sqdist_topk(q.to(dev), g.to(dev), k, precision="f16r", defer_check=True)
+    assert int(flag.item()) == 0
+    n_diff = _assert_lists(f"f16r {m}x{n}x{d} k={k}", q, g, v, i, k)
+    v32, i32 = ops.sqdist_topk(q.to(dev), g.to(dev), k, precision="fp32")
+    n32 = _assert_lists(f"fp32 {m}x{n}x{d} k={k}", q, g, v32, i32, k)
+    assert n_diff <= n32 + 2          # at least as close to fp64 as the fp32 MFMA mode
+    assert (v - v32).abs().max() <= 2e-6 * max(1.0, float(v32.abs().max()))
+    # index_base and prepared operands: the same lists
+    gp = ops.PreparedRows(g.to(dev), "f16r")
+    v2, i2 = ops.sqdist_topk_prepared(ops.PreparedRows(q.to(dev), "f16r"), gp, k, index_base=1000)
+    assert torch.equal(v2, v) and torch.equal(i2, i + 1000)
+
+
+def test_small_and_ragged_problems_take_the_exact_path(dev):
+    for m, n, d, k in [(1, 1, 64, 1), (3, 129, 128, 10), (130, 67, 4096, 10), (5, 3000, 192, 7), (4, 6, 64, 10)]:
+        g = torch.Generator().manual_seed(m * 7 + n)
+        x, y = torch.randn((m, d), generator=g), torch.randn((n, d), generator=g)
+        v, i = ops.sqdist_topk(x.to(dev), y.to(dev), k, precision="f16r")
+        v32, i32 = ops.sqdist_topk(x.to(dev), y.to(dev), k, precision="fp32")
+        assert torch.equal(v, v32) and torch.equal(i, i32)        # (k > n: (+inf, -1) tails included)
+
+
+def test_rows_of_any_magnitude(dev):
+    """Unnormalised descriptors, rows 1e-3 .. 1e3 long, a zero row: per-row power-of-two scales keep the fp16
+    pass in range and the bound follows the row norms."""
+    m, n, d, k = 300, 17000, 256, 10
+    gen = torch.Generator().manual_seed(8)
+    q = torch.randn((m, d), generator=gen) * torch.logspace(-3, 3, m)[:, None]
+    g = torch.randn((n, d), generator=gen) * torch.logspace(-3, 3, n)[torch.randperm(n, generator=gen)][:, None]
+    g[77] = 0.0
+    v, i, flag = ops.sqdist_topk(q.to(dev), g.to(dev), k, precision="f16r", defer_check=True)
+    if int(flag.item()):                                            # (legitimate: then the exact repeat decides)
+        v, i = ops.sqdist_topk(q.to(dev), g.to(dev), k, precision="f16r", exact=True)
+    wv, wi, d64 = _fp64_topk(q, g, k)
+    got64 = torch.gather(d64, 1, i.cpu().long())
+    # relative to the size of the terms that are subtracted (|x|^2 + |y|^2)
+    scale = (q.double() ** 2).sum(1)[:, None] + torch.gather((g.double() ** 2).sum(1)[None].expand(m, -1), 1, wi)
+    assert float(((got64 - wv).abs() / scale).max()) <= 2e-6
+    assert float(((v.cpu().double() - got64).abs() / scale).max()) <= 1e-6
+
+
+def test_near_duplicate_gallery_overflows_into_the_exact_path(dev):
+    """More than K2 = 32 gallery rows within the error bound of the k-th distance: the rescore window cannot hold
+    them, the flag is raised, and the repeat on the exact path returns the fp32 mode's lists."""
+    m, n, d, k = 256, 16384, 256, 10
+    q, g, _, _ = synth.retrieval_problem(m, n, dim=d, seed=5)
+    dup = torch.nn.functional.normalize(g[:1] + 1e-6 * torch.randn(200, d), dim=1)
+    g[1000:1200] = dup                                              # 200 rows ~1e-6 apart
+    q[0] = g[1000]
+    v, i, flag = ops.sqdist_topk(q.to(dev), g.to(dev), k, precision="f16r", defer_check=True)
+    assert int(flag.item()) == 1
+    v, i = ops.sqdist_topk(q.to(dev), g.to(dev), k, precision="f16r")      # reads the flag, repeats exactly
+    v32, i32 = ops.sqdist_topk(q.to(dev), g.to(dev), k, precision="fp32")
+    assert torch.equal(i, i32) and torch.equal(v, v32)
+    # through sharded_topk (one rank): the same protocol
+    v2, i2 = sharded.sharded_topk(q.to(dev), g.to(dev), k, 0, "f16r")
+    assert torch.equal(i2, i32)
+
+
+@pytest.mark.parametrize("name", ["match_small", "match_nms"])
+def test_reference_rankings_and_recalls(name, dev):
+    """The reference's own outputs (tests/golden, written by oracle/make_golden.py from ibl/evaluators.py): these
+    problems are below the fused path's size, so f16r answers with the exact path — the API contract."""
+    g = load_golden(name)
+    q, gal, gt, pids = synth.retrieval_problem(
+        int(g["Q"]), int(g["G"]), dim=int(g["dim"]), seed=int(g["seed"]), views_per_place=int(g["views_per_place"]),
+        hard_fraction=float(g["hard_fraction"]), hard_noise_mult=float(g["hard_noise_mult"]))
+    v, i = ops.sqdist_topk(q.to(dev), gal.to(dev), 20, precision="f16r")
+    assert np.array_equal(i.cpu().numpy(), g["top20"])
+
+
+def test_sharded_f16r_equals_global(dev):
+    """8 shards on one GPU: per-shard f16r lists merged == the global f16r lists (values are exact distances, so
+    the merge cannot depend on the sharding), queries prepared once."""
+    Q, G, d, k, W = 512, 8 * 9000 + 13, 256, 10, 8
+    q, g, gt, pids = synth.retrieval_problem(Q, G, dim=d, seed=12, hard_fraction=0.5)
+    qd, gd = q.to(dev), g.to(dev)
+    gv, gi = ops.sqdist_topk(qd, gd, k, precision="f16r")
+    qp = ops.PreparedRows(qd, "f16r")
+    vs, is_ = [], []
+    for r in range(W):
+        start, per, n_valid = sharded.slice_bounds(G, r, W)
+        shard = ops.PreparedRows(gd[start:start + n_valid].contiguous(), "f16r")
+        v, i, flag = sharded.hip_local_topk(qp, shard, k, start, "f16r")
+        assert int(flag.item()) == 0
+        vs.append(v)
+        is_.append(i)
+    mv, mi = sharded.hip_merge_topk(torch.cat(vs, 1), torch.cat(is_, 1), k)
+    assert torch.equal(mi, gi) and torch.equal(mv, gv)
+    _assert_lists("f16r sharded", q, g, mv, mi, k)
+    # the exchanged form of prepared queries (what gather_prepared_queries ships) re-assembles to the same object
+    qp2 = ops.PreparedRows.from_parts(qp.operand_rows(), qp.norms, d, "f16r")
+    v2, i2 = ops.sqdist_topk_prepared(qp2, ops.PreparedRows(gd, "f16r"), k)
+    assert torch.equal(i2, gi) and torch.equal(v2, gv)
+
+
+def test_topk_precision_rule():
+    assert ops.topk_precision("f16mx") == ops.F16R
+    assert ops.topk_precision("f16mx", torch.float16) == ops.F16MX      # 16-bit storage: nothing exact to rescore from
+    assert ops.topk_precision("f16mx", torch.float32, 600) == ops.F16MX
+    assert ops.topk_precision("bf16x3") == ops.BF16X3 and ops.topk_precision("fp32") == ops.F32
+    with pytest.raises(ValueError):
+        ops.pairwise_sqdist(torch.zeros(2, 64), torch.zeros(2, 64), "f16r")

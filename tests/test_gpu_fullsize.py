@@ -43,7 +43,7 @@ def pitts30k():
     return q, g, gt, pids, rank, recalls
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16mx"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16mx", "f16r"])
 def test_pitts30k_shape_recall_equals_oracle(dev, pitts30k, precision):
     from openibl_amd.evaluators import recalls_from_topk
     q, g, gt, pids, want_rank, want_recalls = pitts30k
@@ -57,6 +57,12 @@ def test_pitts30k_shape_recall_equals_oracle(dev, pitts30k, precision):
     assert agree >= 0.9995 and worst < NEAR_TIE     # (fp32 itself: 9 of 68160 entries differ, all < 5e-7 apart in fp64)
     # the materialised matrix (pairwise_distance's return value) on a row block: same lists
     rows = slice(3000, 3512)
+    if precision == "f16r":      # a top-k arithmetic: its lists are those of the fp32 matrix up to fp32 near-ties
+        d = ops.pairwise_sqdist(q[rows].contiguous().to(dev), g.to(dev), "fp32")
+        _, i2 = ops.row_topk(d, 10)
+        n2, w2 = _near_tie_report(q[rows], g, i2.cpu().numpy(), got[rows])
+        assert n2 <= 8 and w2 < NEAR_TIE
+        return
     d = ops.pairwise_sqdist(q[rows].contiguous().to(dev), g.to(dev), precision)
     _, i2 = ops.row_topk(d, 10)
     assert torch.equal(i2, i[rows])
@@ -71,7 +77,7 @@ def pitts250k():
     return q, g, gt, rows, om.ranking(d)[:, :10]
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "f16mx"])
+@pytest.mark.parametrize("precision", ["bf16x3", "f16mx", "f16r"])
 def test_pitts250k_shape_eight_shards_equal_global_equal_oracle(dev, pitts250k, precision):
     q, g, gt, rows, want_block = pitts250k
     Q, G, W = q.shape[0], g.shape[0], 8
@@ -88,10 +94,13 @@ def test_pitts250k_shape_eight_shards_equal_global_equal_oracle(dev, pitts250k, 
         is_.append(i)
     mv, mi = sharded.hip_merge_topk(torch.cat(vs, 1), torch.cat(is_, 1), 10)
     assert torch.equal(mi, gi) and torch.equal(mv, gv)                       # merged == global fused
-    d = ops.pairwise_sqdist(qd[torch.from_numpy(rows).to(dev)].contiguous(), gd, precision)
-    bv, bi = ops.row_topk(d, 10)
     sel = torch.from_numpy(rows).to(dev)
-    assert torch.equal(bi, gi[sel]) and torch.equal(bv, gv[sel])             # == top-k of the matrix
+    if precision == "f16r":      # (no matrix in this arithmetic: its lists are checked against the oracle block below)
+        bi = gi[sel]
+    else:
+        d = ops.pairwise_sqdist(qd[sel].contiguous(), gd, precision)
+        bv, bi = ops.row_topk(d, 10)
+        assert torch.equal(bi, gi[sel]) and torch.equal(bv, gv[sel])         # == top-k of the matrix
     got = bi.cpu().numpy()
     agree = float((got == want_block).mean())
     n_diff, worst = _near_tie_report(q, g, got, want_block, rows=rows)
