@@ -2,6 +2,7 @@
 // shared MFMA core (gemm_core.h), bias + ReLU + 2x2 max-pool fused into the epilogue.
 // Reference behaviour: ibl/models/vgg.py:40-42 (layer list), :61-70 (forward).
 #include "conv_halo.h"
+#include "conv_halo4.h"
 #include "conv_ring.h"
 #include "gemm_core.h"
 
@@ -945,6 +946,45 @@ static int launch_conv_halo(const ConvParams& p, hipStream_t st) {
   return OIBL_OK;
 }
 
+// The 128-output-channel layers (conv2_1, conv2_2): conv_halo4.h — 256 pixels x 128 channels, 4 waves, two
+// workgroups per CU.  stagger (test hook): first-round workgroups of a CU's second slot start half a chunk late.
+template <bool POOL>
+static int launch_conv_halo4(const ConvParams& p, hipStream_t st, int stagger) {
+  HaloParams q = {};
+  q.in = p.in;
+  q.w = p.w;
+  q.bias = p.bias;
+  q.out = p.out;
+  q.in_bytes = (unsigned)((size_t)p.N * p.H * p.W * p.cin * 4);
+  q.w_bytes = (unsigned)((size_t)9 * p.cout * p.cin * 4);
+  q.N = p.N;
+  q.H = p.H;
+  q.W = p.W;
+  q.cin = p.cin;
+  q.cout = p.cout;
+  const int Hn = POOL ? (p.H / 2) * 2 : p.H, Wn = POOL ? (p.W / 2) * 2 : p.W;
+  halo_patch(Hn, Wn, &q.PH, &q.PW);
+  q.tiles_y = (Hn + q.PH - 1) / q.PH;
+  q.tiles_x = (Wn + q.PW - 1) / q.PW;
+  const long tiles_m = (long)p.N * q.tiles_y * q.tiles_x;
+  q.tiles_n = p.cout / H4_BN;
+  OIBL_REQUIRE(tiles_m * q.tiles_n <= 0x7fffffffL, "conv3x3 (halo4): grid out of range");
+  q.tiles_m = (int)tiles_m;
+  q.raster = (g_ring_raster & 255) | (stagger ? 256 : 0);
+  ring_magic_u31((unsigned)(q.tiles_y * q.tiles_x), &q.img_mul, &q.img_sh);
+  ring_magic_u31((unsigned)q.tiles_x, &q.tx_mul, &q.tx_sh);
+  ring_magic_u31((unsigned)(POOL ? q.PW / 2 : q.PW), &q.pw_mul, &q.pw_sh);
+  ring_magic_u31((unsigned)(q.PW + 2), &q.hp_mul, &q.hp_sh);
+  q.relu = p.relu;
+  q.out_f32 = p.out_f32;
+  q.range_flag = p.range_flag;
+  auto kern = conv3x3_halo4_kernel<POOL>;
+  OIBL_SET_MAX_LDS(kern, H4_LDS);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * q.tiles_n)), dim3(H4_THREADS), H4_LDS, st, q);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
+
 // ---- f16mx: row sub-ranges + split-K on the ring kernels ------------------------------------------
 // The ring tiles are 256 x 256 / 512 x 128 outputs and a workgroup owns a CU: a layer with T tiles runs
 // ceil(T / 256) rounds and the last one may be nearly empty — conv5_x at batch 32: 300 tiles = one full
@@ -967,10 +1007,19 @@ struct MxSplitPlan {
   long rows_part;   // GEMM rows of the split part
 };
 OIBL_HOOK(int, g_mx_splitk, 1);   // test hook: 0 = never split; 2 = split, reduced by conv_mx_splitk_reduce_kernel
+OIBL_HOOK(int, g_mx_variant, 0);  // test hook: kernel choice of the f16mx layers (launch_conv_mx)
+// the 128-output-channel layers run on conv_halo4.h (256-pixel tiles, two workgroups per CU): no ring rounds to balance
+static bool mx_halo4_layer(int cin, int cout) {
+  return (g_mx_variant == 0 || g_mx_variant == 3 || g_mx_variant == 9) && cout == 128 && cin % 64 == 0;
+}
 static MxSplitPlan mx_split_plan(long m_plain, int cin, int cout, int pool, int korder, int wm) {
   MxSplitPlan pl = {};
   pl.wm = wm;
   if (wm == 0 || m_plain <= 0) return pl;   // no ring tiling for this layer (Cout = 64: the stem's conv1_2)
+  if (mx_halo4_layer(cin, cout)) {          // one pass, whatever the batch
+    pl.tm_main = (int)((m_plain + wm * 128 - 1) / (wm * 128));
+    return pl;
+  }
   const int bm = wm * 128, tiles_n = cout / (wm == 2 ? 256 : 128);
   const long tm = (m_plain + bm - 1) / bm;
   const long T = tm * tiles_n;
@@ -1170,7 +1219,6 @@ __global__ __launch_bounds__(256) void conv_mx_splitk_reduce8_kernel(
 // 0.58x the LDS-DMA bytes, +5 % on conv3_x, -5 % on conv4_x / conv5_x since the ring's K cursor left its
 // LOAD segments (profiles/r03_*): kept as the tested alternative; 2 = ring kernels with the LDS-DMA issue
 // inside COMPUTE (RING_MX); 4..8 = timing experiments (wrong results) / stamps.
-OIBL_HOOK(int, g_mx_variant, 0);
 static int launch_conv_mx_split(const ConvParams& p, int pool, const MxSplitPlan& pl, hipStream_t st) {
   // 1. the full rounds, unsplit, straight into the output (never pooled: see mx_split_plan)
   int rc;
@@ -1243,6 +1291,10 @@ static int launch_conv_mx(const ConvParams& p, int pool, hipStream_t st) {
   const bool halo_ok = rv == 2 && ((p.cin >> 5) & 1) == 0;
   if (halo_ok && (g_mx_variant == 3 || (g_mx_variant == 0 && p.cout == 256)))
     return pool ? launch_conv_halo<true>(p, st) : launch_conv_halo<false>(p, st);
+  // the 4-wave halo kernel (conv_halo4.h) for the 128-output-channel layers (rv == 4: conv2_1 / conv2_2): a third
+  // of the ring's L2 -> LDS bytes per K-tile.  Hook: 1 = ring, 9 = halo4 with the first-round stagger, 10 = ring.
+  if (rv == 4 && mx_halo4_layer(p.cin, p.cout))
+    return pool ? launch_conv_halo4<true>(p, st, g_mx_variant == 9) : launch_conv_halo4<false>(p, st, g_mx_variant == 9);
   if (g_mx_variant == 2) {
     if (rv == 2) return pool ? launch_conv_ring<2, true, RING_MX>(p, st) : launch_conv_ring<2, false, RING_MX>(p, st);
     if (rv == 4) return pool ? launch_conv_ring<4, true, RING_MX>(p, st) : launch_conv_ring<4, false, RING_MX>(p, st);

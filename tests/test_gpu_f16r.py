@@ -20,12 +20,14 @@ def _fp64_topk(q, g, k):
     return v[:, :k], i[:, :k], d
 
 
-def _assert_lists(name, q, g, v, i, k, tie=2e-6):
-    """(v, i) against fp64: values to fp32 rounding, indices equal except where fp64 calls a near-tie."""
+def _assert_lists(name, q, g, v, i, k, tie=2e-6, val_tol=1e-6):
+    """(v, i) against fp64: values to fp32 rounding (val_tol: the fp32 MFMA mode itself carries ~d 2^-24 of
+    accumulation error, 4.7e-6 seen at d = 4096), indices equal except where fp64 calls a near-tie."""
     wv, wi, d64 = _fp64_topk(q, g, k)
     v, i = v.cpu(), i.cpu().long()
     got64 = torch.gather(d64, 1, i)
-    assert (v.double() - got64).abs().max() <= 1e-6 * max(1.0, float(d64.abs().max())), name
+    verr = float((v.double() - got64).abs().max())
+    assert verr <= val_tol * max(1.0, float(d64.abs().max())), (name, verr)
     diff = (i != wi)
     worst = float((got64 - wv).abs()[diff].max()) if diff.any() else 0.0
     print(f"{name}: {int(diff.sum())} of {i.numel()} entries differ from fp64, all within {worst:.2e}")
@@ -62,9 +64,9 @@ def test_fused_lists_are_fp32_exact(dev, m, n, d, k):
     assert int(flag.item()) == 0
     n_diff = _assert_lists(f"f16r {m}x{n}x{d} k={k}", q, g, v, i, k)
     v32, i32 = ops.sqdist_topk(q.to(dev), g.to(dev), k, precision="fp32")
-    n32 = _assert_lists(f"fp32 {m}x{n}x{d} k={k}", q, g, v32, i32, k)
+    n32 = _assert_lists(f"fp32 {m}x{n}x{d} k={k}", q, g, v32, i32, k, tie=1e-5, val_tol=1e-5)
     assert n_diff <= n32 + 2          # at least as close to fp64 as the fp32 MFMA mode
-    assert (v - v32).abs().max() <= 2e-6 * max(1.0, float(v32.abs().max()))
+    assert (v - v32).abs().max() <= 1e-5 * max(1.0, float(v32.abs().max()))
     # index_base and prepared operands: the same lists
     gp = ops.PreparedRows(g.to(dev), "f16r")
     v2, i2 = ops.sqdist_topk_prepared(ops.PreparedRows(q.to(dev), "f16r"), gp, k, index_base=1000)
@@ -161,3 +163,21 @@ def test_topk_precision_rule():
     assert ops.topk_precision("bf16x3") == ops.BF16X3 and ops.topk_precision("fp32") == ops.F32
     with pytest.raises(ValueError):
         ops.pairwise_sqdist(torch.zeros(2, 64), torch.zeros(2, 64), "f16r")
+
+
+def test_two_lane_blocks_equal_one_call(dev):
+    """Query sets from 4096 rows on are matched in row blocks alternating between two streams (ops._f16r_two_lanes):
+    same lists, same flag protocol."""
+    m, n, d, k = 4096 + 300, 16384, 128, 10
+    q, g, _, _ = synth.retrieval_problem(m, n, dim=d, seed=77, hard_fraction=0.5)
+    qp, gp = ops.PreparedRows(q.to(dev), "f16r"), ops.PreparedRows(g.to(dev), "f16r")
+    v2, i2, f2 = ops.sqdist_topk_prepared(qp, gp, k, index_base=5, defer_check=True)
+    ops.F16R_LANES = False
+    try:
+        v1, i1, f1 = ops.sqdist_topk_prepared(qp, gp, k, index_base=5, defer_check=True)
+    finally:
+        ops.F16R_LANES = True
+    torch.cuda.synchronize()
+    assert int(f1.item()) == 0 and int(f2.item()) == 0
+    assert torch.equal(v1, v2) and torch.equal(i1, i2)
+    _assert_lists("f16r two lanes", q, g, v2, i2 - 5, k)

@@ -89,6 +89,9 @@ def mx_variant(request):
     (1, 60, 80, 256, 512, True, True),    # conv4_3-like: 12 x 20 patches, pooled
     (2, 31, 45, 128, 256, True, True),    # odd sizes: patches cut by both borders, pooling floors
     (1, 120, 160, 128, 256, True, False),  # conv3_1 shape: 8 x 32 patches
+    (2, 240, 320, 64, 128, True, False),   # conv2_1 shape: 4-wave halo kernel (conv_halo4.h), 8 x 32 patches, 2 chunks
+    (1, 240, 320, 128, 128, True, True),   # conv2_2 shape: pooled, 4 chunks (three single-buffered halo reloads)
+    (1, 50, 34, 64, 128, False, False),    # 4-wave halo kernel: patches cut by both borders, no ReLU
 ])
 def test_conv3x3_mx(dev, N, H, W, cin, cout, relu, pool, mx_variant):
     x, w, b = _case(N, H, W, cin, cout, seed=H * 1000 + cin)
@@ -332,6 +335,34 @@ def test_conv_mx_repeatable_under_load(dev):
             torch.cuda.synchronize()
         finally:
             lib.debug_hooks().oibl_debug_set_mx_variant(0)
+
+
+def test_conv_mx_halo4_repeatable_under_load(dev):
+    """The 4-wave halo kernel of the 128-output-channel layers (conv_halo4.h): its single halo buffer is reloaded
+    between chunks behind a drained queue — the same bits launch after launch, also while a second stream loads the
+    memory system, pooled and unpooled, and its output agrees with the ring kernel's to the arithmetic's accuracy."""
+    from openibl_amd import lib
+    g = torch.Generator(device=dev).manual_seed(6)
+    big = torch.randn((4096, 4096), device=dev)
+    side = torch.cuda.Stream()
+    for cin, pool in ((64, False), (128, True)):
+        xf = torch.relu(torch.randn((4, 240, 320, cin), generator=g, device=dev)) * 3.0
+        w = torch.randn((128, cin, 3, 3), generator=g, device=dev) * 0.05
+        b = torch.randn((128,), generator=g, device=dev) * 0.1
+        x, wp = ops.mx_split(xf), ops.pack_conv3x3(w, "f16mx")
+        ref = ops.conv3x3_nhwc(x, wp, b, True, pool, "f16mx")          # default dispatch: conv_halo4.h
+        for _ in range(25):
+            with torch.cuda.stream(side):
+                big @ big
+            assert torch.equal(ops.conv3x3_nhwc(x, wp, b, True, pool, "f16mx"), ref)
+        torch.cuda.synchronize()
+        lib.debug_hooks().oibl_debug_set_mx_variant(1)
+        try:
+            ring = ops.conv3x3_nhwc(x, wp, b, True, pool, "f16mx")
+        finally:
+            lib.debug_hooks().oibl_debug_set_mx_variant(0)
+        d = float((ops.mx_join(ring) - ops.mx_join(ref)).norm() / ops.mx_join(ring).norm())
+        assert d < 3e-5, d
 
 
 def test_small_batch_threshold_is_a_knob_and_off_by_default(dev, state_dict):
