@@ -970,7 +970,12 @@ static int launch_conv_halo4(const ConvParams& p, hipStream_t st, int stagger) {
   q.tiles_n = p.cout / H4_BN;
   OIBL_REQUIRE(tiles_m * q.tiles_n <= 0x7fffffffL, "conv3x3 (halo4): grid out of range");
   q.tiles_m = (int)tiles_m;
-  q.raster = (g_ring_raster & 255) | (stagger ? 256 : 0);
+  // first-round de-phasing of a CU's two workgroups (conv_halo4.h): half a tile — its 9 Cin / 32 K-tiles plus an
+  // epilogue worth ~14 more, ~900 cycles each — in sleeps of 8128 cycles (conv2_1: 2, conv2_2: 3)
+  int sleeps = ((9 * (p.cin / 32) + 14) * 450 + 4064) / 8128;
+  if (sleeps < 1) sleeps = 1;
+  if (sleeps > 15) sleeps = 15;
+  q.raster = (g_ring_raster & 255) | ((stagger & 15) << 8) | (sleeps << 12);
   ring_magic_u31((unsigned)(q.tiles_y * q.tiles_x), &q.img_mul, &q.img_sh);
   ring_magic_u31((unsigned)q.tiles_x, &q.tx_mul, &q.tx_sh);
   ring_magic_u31((unsigned)(POOL ? q.PW / 2 : q.PW), &q.pw_mul, &q.pw_sh);
@@ -1010,7 +1015,7 @@ OIBL_HOOK(int, g_mx_splitk, 1);   // test hook: 0 = never split; 2 = split, redu
 OIBL_HOOK(int, g_mx_variant, 0);  // test hook: kernel choice of the f16mx layers (launch_conv_mx)
 // the 128-output-channel layers run on conv_halo4.h (256-pixel tiles, two workgroups per CU): no ring rounds to balance
 static bool mx_halo4_layer(int cin, int cout) {
-  return (g_mx_variant == 0 || g_mx_variant == 3 || g_mx_variant == 9) && cout == 128 && cin % 64 == 0;
+  return (g_mx_variant == 0 || g_mx_variant == 3 || (g_mx_variant >= 9 && g_mx_variant <= 12)) && cout == 128 && cin % 64 == 0;
 }
 static MxSplitPlan mx_split_plan(long m_plain, int cin, int cout, int pool, int korder, int wm) {
   MxSplitPlan pl = {};
@@ -1293,8 +1298,11 @@ static int launch_conv_mx(const ConvParams& p, int pool, hipStream_t st) {
     return pool ? launch_conv_halo<true>(p, st) : launch_conv_halo<false>(p, st);
   // the 4-wave halo kernel (conv_halo4.h) for the 128-output-channel layers (rv == 4: conv2_1 / conv2_2): a third
   // of the ring's L2 -> LDS bytes per K-tile.  Hook: 1 = ring, 9 = halo4 with the first-round stagger, 10 = ring.
-  if (rv == 4 && mx_halo4_layer(p.cin, p.cout))
-    return pool ? launch_conv_halo4<true>(p, st, g_mx_variant == 9) : launch_conv_halo4<false>(p, st, g_mx_variant == 9);
+  if (rv == 4 && mx_halo4_layer(p.cin, p.cout)) {
+    // hook 9 / 10 / 11 / 12: de-phasing by TG_ID (the default) / two block-index guesses / off
+    const int stag = g_mx_variant == 12 ? 0 : g_mx_variant == 10 ? 2 : g_mx_variant == 11 ? 3 : 1;
+    return pool ? launch_conv_halo4<true>(p, st, stag) : launch_conv_halo4<false>(p, st, stag);
+  }
   if (g_mx_variant == 2) {
     if (rv == 2) return pool ? launch_conv_ring<2, true, RING_MX>(p, st) : launch_conv_ring<2, false, RING_MX>(p, st);
     if (rv == 4) return pool ? launch_conv_ring<4, true, RING_MX>(p, st) : launch_conv_ring<4, false, RING_MX>(p, st);

@@ -237,11 +237,23 @@ __global__ __launch_bounds__(H4_THREADS, 2) void conv3x3_halo4_kernel(HaloParams
     }
   }
 
-  // Experiment (test hook through HaloParams::raster bit 8): workgroups that land in a CU's second slot in the first
-  // round start half a chunk late, so that the two workgroups of a CU reload their halos at different times
-  if ((p.raster & 256) && (((blockIdx.x >> 3) >> 5) & 1)) {
+  // De-phasing the two workgroups of a CU.  Every tile of a layer takes the same time, so two workgroups that start
+  // together stay together: both in their K loops (the matrix pipe shared), then both in their epilogues (~100
+  // VALU instructions per stored line, the matrix pipe idle) — measured: 44k cycles of a conv2_1 round outside the
+  // K loops, 2x the ring kernel's.  A first-round workgroup in the CU's ODD workgroup slot (HW_ID.TG_ID) therefore
+  // starts half a tile late, once; the offset then persists from round to round, and one workgroup's epilogue runs
+  // under the other's matrix work.  HaloParams::raster bits 8-11: 0 = off, 1 = TG_ID, 2 / 3 = test variants that
+  // guess the slot from the block index; bits 12-15: sleeps of 8128 cycles.
+  {
+    const int mode = (p.raster >> 8) & 15, sleeps = (p.raster >> 12) & 15;
+    bool late = false;
+    if (mode == 1) late = blockIdx.x < 512u && ((__builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4) & 1) != 0);
+    else if (mode == 2) late = blockIdx.x < 512u && ((((blockIdx.x >> 3) >> 5) & 1) != 0);
+    else if (mode == 3) late = blockIdx.x < 512u && (((blockIdx.x >> 3) & 1) != 0);
+    if (late) {
 #pragma unroll 1
-    for (int s = 0; s < 28; ++s) __builtin_amdgcn_s_sleep(127);
+      for (int s_ = 0; s_ < sleeps; ++s_) __builtin_amdgcn_s_sleep(127);
+    }
   }
 
   using I0 = std::integral_constant<int, 0>;

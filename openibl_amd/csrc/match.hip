@@ -1499,32 +1499,27 @@ int oibl_sqdist_topk_f16r(const void* xh, const float* xaux, const float* xn, co
   q.index_base = index_base;
   rc = launch_pairwise_f16r<true>(q, st);
   if (rc) return rc;
-  // 3. the K2 smallest filter distances of every list, ascending (a list beyond its capacity raises *overflow)
+  // 3. the members of every query's rescore set (a list beyond the window / capacity, or more than K2 members,
+  //    raises *overflow)
   float* lval = (float*)(wsb + f.off_lval);
   int32_t* lidx = (int32_t*)(wsb + f.off_lidx);
-  launch_row_topk(q.cand_val, q.cand_idx, m, t.cap, (size_t)t.cap, f.K2, 0, lval, lidx, cnt, (int*)overflow, st);
+  hipLaunchKernelGGL(f16r_select_kernel<32>, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, q.cand_val, q.cand_idx, cnt,
+                     m, t.cap, k, f.K2, xn, (const float4*)xaux, ymax, q.gamma, lval, lidx, (int*)overflow);
   OIBL_LAUNCH_CHECK();
-  // 4. exact distances of the rescore set, final selection
+  // 4. exact distances of the members, final selection
   F16rRescoreParams r = {};
   r.xsrc = xsrc;
   r.ysrc = ysrc;
   r.xn = xn;
   r.yn = yn;
-  r.xaux = (const float4*)xaux;
-  r.yaux = (const float4*)yaux;
-  r.lval = lval;
   r.lidx = lidx;
-  r.cnt = cnt;
-  r.ymax = ymax;
   r.m = m;
   r.d = d;
   r.k = k;
   r.K2 = f.K2;
   r.index_base = index_base;
-  r.gamma = q.gamma;
   r.out_val = out_val;
   r.out_idx = out_idx;
-  r.overflow = (int*)overflow;
   hipLaunchKernelGGL(f16r_rescore_kernel, dim3((unsigned)m), dim3(256), 0, st, r);
   OIBL_LAUNCH_CHECK();
   return OIBL_OK;

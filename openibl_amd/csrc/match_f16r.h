@@ -23,10 +23,11 @@
 //             smallest TRUE distance of the whole gallery is <= thr_i + max_s eps(i, s), so every member of the
 //             true top-k has D_h <= thr_i + max_s eps(i, s) + eps(i, j): that is the filter's test (two fma per
 //             pair in the epilogue).  Survivors go to per-query candidate lists, as in the other modes.
-//   select    the K2 (32 for k <= 16) smallest D_h of every list, ascending (row_topk).  With T = the k-th of
-//             them, a member of the true top-k has D_h <= T + max_{e < k} eps_e + eps(i, j): the RESCORE SET,
-//             typically k + 2..5 entries.  If entry K2 - 1 is still inside it and the list was longer, the set
-//             may be truncated: *overflow is raised and the caller repeats on the exact fp32 path.
+//   select    one wave per query holds its candidate list in registers: k rounds of minimum extraction give T =
+//             the k-th smallest D_h, and a member of the true top-k has D_h <= T + max_{e < k} eps_e + eps(i, j)
+//             <= T + 2 eps_any (eps_any: the bound with the gallery-wide maxima of |y|, |ry|): the RESCORE SET,
+//             typically k + 2..5 entries, compacted by ballot.  More than K2 (32 for k <= 16) members, or a list
+//             beyond the register window: *overflow is raised and the caller repeats on the exact fp32 path.
 //   rescore   for the set only: x.y from the resident fp32 rows, accumulated in fp64 (one wave per pair, a 16 KB
 //             contiguous gather per gallery row), D = fl32((|x|^2 + |y|^2) - 2 x.y) with the fp32 norms every
 //             mode uses; the k smallest (D, index) leave, lowest index first on ties.
@@ -296,25 +297,86 @@ __global__ __launch_bounds__(512) void pairwise_f16r_kernel(F16rParams p) {
   }
 }
 
+// ---- selection: which candidates can belong to the true top-k ------------------------------------------------
+// One wave per query, its candidate list (<= 64 NQ entries) in registers as (ordered value bits << 32 | index) keys:
+// k rounds of wave-minimum extraction give T = the k-th smallest filter distance; a candidate is a MEMBER of the
+// rescore set iff D_h <= T + 2 eps_any, eps_any = the pair bound with the gallery-wide maxima of |y| and |ry| (>=
+// the bound of every pair of this query: both the k-th TRUE distance and the candidate's own move by at most that).
+// Members are compacted (ballot prefix, any order) into lval / lidx [m][K2], padded with (+inf, -1).  A list longer
+// than the register window or the candidate capacity, or more than K2 members: *overflow (exact path).
+constexpr int F16R_MAX_K2 = 1024;
+
+template <int NQ>
+__global__ __launch_bounds__(256) void f16r_select_kernel(const float* __restrict__ cand_val,
+                                                          const int32_t* __restrict__ cand_idx,
+                                                          const int* __restrict__ cnt, int m, int cap, int k, int K2,
+                                                          const float* __restrict__ xn, const float4* __restrict__ xaux,
+                                                          const unsigned* __restrict__ ymax, float gamma,
+                                                          float* __restrict__ lval, int32_t* __restrict__ lidx,
+                                                          int* __restrict__ overflow) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= m) return;   // wave-uniform
+  int n = cnt[row];
+  const int window = cap < 64 * NQ ? cap : 64 * NQ;
+  if (n > window) {
+    if (lane == 0 && overflow) atomicOr(overflow, 1);
+    n = window;
+  }
+  const float* vr = cand_val + (size_t)row * cap;
+  const int32_t* ir = cand_idx + (size_t)row * cap;
+  unsigned long long mine[NQ], keep[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int j = lane + 64 * q;
+    mine[q] = TOPK_INF;
+    if (j < n) mine[q] = ((unsigned long long)ordered_bits(vr[j]) << 32) | (unsigned)ir[j];
+    keep[q] = mine[q];
+  }
+  unsigned long long w = TOPK_INF;
+  for (int r = 0; r < k; ++r) w = wave_extract_min(mine, lane);   // the k-th smallest key (TOPK_INF: fewer than k)
+  const float T = w == TOPK_INF ? INFINITY : from_ordered_bits((uint32_t)(w >> 32));
+  const float4 xa = xaux[row];
+  const float nx = xa.y, rx = xa.z, xnr = xn[row];
+  const float A = 2.0f * (rx + gamma * (nx + rx)), B = 2.0f * (nx + rx) * (1.0f + gamma);
+  const float ymx = __uint_as_float(ymax[2]), rmx = __uint_as_float(ymax[3]);
+  const float eps_any = fmaf(A, ymx, B * rmx) + 1e-6f * (xnr + ymx * ymx);
+  const float bound = T + 2.0f * eps_any;
+  int count = 0;
+  float* lv = lval + (size_t)row * K2;
+  int32_t* li = lidx + (size_t)row * K2;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const float v = from_ordered_bits((uint32_t)(keep[q] >> 32));
+    const bool in = keep[q] != TOPK_INF && !(v > bound);          // (NaN on either side: keep)
+    const unsigned long long mask = __ballot(in);
+    const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
+    if (in && pos < K2) {
+      lv[pos] = v;
+      li[pos] = (int32_t)(uint32_t)(keep[q] & 0xffffffffu);
+    }
+    count += __popcll(mask);
+  }
+  if (count > K2) {
+    if (lane == 0 && overflow) atomicOr(overflow, 1);
+    count = K2;
+  }
+  for (int e = count + lane; e < K2; e += 64) {
+    lv[e] = INFINITY;
+    li[e] = -1;
+  }
+}
+
 struct F16rRescoreParams {
   const float* xsrc;      // [m][d] fp32 rows
   const float* ysrc;      // [n][d] fp32 rows
   const float* xn;
   const float* yn;
-  const float4* xaux;
-  const float4* yaux;
-  const float* lval;      // [m][K2] D_h ascending ((+inf, -1) paddings)
-  const int32_t* lidx;    // [m][K2] global indices
-  const int* cnt;         // candidates the filter found per query
-  const unsigned* ymax;   // F16rParams::ymax ([2], [3]: the maxima over the whole gallery)
+  const int32_t* lidx;    // [m][K2] members of the rescore set (global indices; -1 = padding), any order
   int m, d, k, K2, index_base;
-  float gamma;
   float* out_val;         // [m][k]
   int32_t* out_idx;
-  int* overflow;
 };
-
-constexpr int F16R_MAX_K2 = 1024;
 
 __device__ static inline double wave_sum_f64(double v) {
 #pragma unroll
@@ -326,59 +388,22 @@ __device__ static inline double wave_sum_f64(double v) {
   return v;
 }
 
-// one workgroup (4 waves) per query
+// one workgroup (4 waves) per query: D of every member (one wave per pair: fp64 accumulation over the resident fp32
+// rows), then the k smallest (D, index)
 __global__ __launch_bounds__(256) void f16r_rescore_kernel(F16rRescoreParams p) {
-  __shared__ float s_val[F16R_MAX_K2];     // D_h, then D for members of the rescore set (+inf outside)
-  __shared__ float s_eps[F16R_MAX_K2];
+  __shared__ float s_val[F16R_MAX_K2];
   __shared__ int s_idx[F16R_MAX_K2];
-  __shared__ unsigned s_epsT;
-  __shared__ int s_nfin;
+  __shared__ int s_nmem;
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K2 = p.K2, k = p.k;
-  const float4 xa = p.xaux[q];
-  const float nx = xa.y, rx = xa.z, xn = p.xn[q];
-  const float A = 2.0f * (rx + p.gamma * (nx + rx)), B = 2.0f * (nx + rx) * (1.0f + p.gamma);
-  if (tid == 0) {
-    s_epsT = 0u;
-    s_nfin = 0;
-  }
+  if (tid == 0) s_nmem = 0;
+  for (int e = tid; e < K2; e += 256) s_idx[e] = p.lidx[(size_t)q * K2 + e];
   __syncthreads();
-  for (int e = tid; e < K2; e += 256) {
-    const float v = p.lval[(size_t)q * K2 + e];
-    const int id = p.lidx[(size_t)q * K2 + e];
-    float eps = 0.f;
-    if (id >= 0) {
-      const float4 ya = p.yaux[id - p.index_base];
-      const float yn = p.yn[id - p.index_base];
-      eps = fmaf(A, ya.y, B * ya.z) + 1e-6f * (xn + yn);
-      if (!(eps >= 0.f)) eps = INFINITY;   // NaN: keep everything
-      if (e < k) atomicMax(&s_epsT, __float_as_uint(eps));
-    }
-    s_val[e] = v;
-    s_idx[e] = id;
-    s_eps[e] = eps;
-  }
-  __syncthreads();
-  // T = k-th smallest D_h (fewer than k candidates: everything is a member)
-  const float T = (k - 1 < K2 && s_idx[k - 1] >= 0) ? s_val[k - 1] : INFINITY;
-  const float epsT = __uint_as_float(s_epsT);
-  // Were members cut off?  The filter found more candidates than the K2 kept ones, and a candidate behind the last
-  // kept one (D_h >= the last kept D_h) could still be a member: its bound is at most the gallery-wide one.
-  if (tid == 0 && p.cnt[q] > K2 && p.overflow) {
-    const float ymx = __uint_as_float(p.ymax[2]), rmx = __uint_as_float(p.ymax[3]);
-    const float eps_any = fmaf(A, ymx, B * rmx) + 1e-6f * (xn + ymx * ymx);
-    if (!(s_val[K2 - 1] > T + epsT + eps_any)) atomicOr(p.overflow, 1);
-  }
-  __syncthreads();
-  // membership; D of the members (one wave per pair: fp64 accumulation over the resident fp32 rows)
+  const float xn = p.xn[q];
   const float* xr = p.xsrc + (size_t)q * p.d;
   for (int e = wave; e < K2; e += 4) {
     const int id = s_idx[e];                       // wave-uniform
-    const bool in = id >= 0 && !(s_val[e] > T + epsT + s_eps[e]);
-    if (!in) {
-      if (lane == 0) s_idx[e] = -1;
-      continue;
-    }
+    if (id < 0) continue;
     const float* yr = p.ysrc + (size_t)(id - p.index_base) * p.d;
     double acc = 0.0;
     for (int i = lane * 4; i < p.d; i += 256) {
@@ -393,7 +418,7 @@ __global__ __launch_bounds__(256) void f16r_rescore_kernel(F16rRescoreParams p) 
     if (lane == 0) {
       const float yn = p.yn[id - p.index_base];
       s_val[e] = (float)((double)(xn + yn) - 2.0 * acc);
-      atomicAdd(&s_nfin, 1);
+      atomicAdd(&s_nmem, 1);
     }
   }
   __syncthreads();
@@ -413,7 +438,7 @@ __global__ __launch_bounds__(256) void f16r_rescore_kernel(F16rRescoreParams p) 
       p.out_idx[(size_t)q * k + rank] = id;
     }
   }
-  for (int r = s_nfin + tid; r < k; r += 256) {   // fewer members than k (a gallery shorter than k): pad
+  for (int r = s_nmem + tid; r < k; r += 256) {   // fewer members than k (a gallery shorter than k): pad
     p.out_val[(size_t)q * k + r] = INFINITY;
     p.out_idx[(size_t)q * k + r] = -1;
   }

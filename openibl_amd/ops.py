@@ -877,9 +877,6 @@ def sqdist_topk_prepared(x: "PreparedRows", y: "PreparedRows", k: int, index_bas
     if m == 0 or n == 0:
         return (ov, oi, flag) if defer_check else (ov, oi)
     lib = _lib.load()
-    if p == F16R and defer_check and not exact and m >= F16R_LANE_MIN_ROWS and F16R_LANES and \
-            not torch.cuda.is_current_stream_capturing():
-        return _f16r_two_lanes(x, y, k, index_base, ov, oi, flag)
     if p == F16R:
         ws = workspace(lib.oibl_sqdist_topk_f16r_workspace_bytes(m, n, d, k), dev, "sqdist_topk")
 
@@ -907,50 +904,6 @@ def sqdist_topk_prepared(x: "PreparedRows", y: "PreparedRows", k: int, index_bas
         if ex == 1 or int(flag.item()) == 0:
             break
     return ov, oi
-
-
-F16R_LANES = True           # diagnostic switch: False = one call on the caller's stream
-F16R_LANE_MIN_ROWS = 4096   # query sets from this size on are matched in row blocks alternating between two streams
-_F16R_LANE_POOL = {}
-
-
-def _f16r_two_lanes(x: "PreparedRows", y: "PreparedRows", k: int, index_base: int, ov, oi, flag):
-    """The f16r step of a large query set, in row blocks on two streams.  A block is filter pass (matrix cores:
-    ~90 % of it) -> selection -> rescoring (HBM gathers of fp32 rows): with the blocks alternating between two
-    lanes the short HBM-bound tail of block b runs under the filter pass of block b + 1, and the partial last
-    round of one filter launch is back-filled by the next (the same effect as the two lanes of extract.py).
-    Same lists as one call (every query row is independent; the sample that sets a row's threshold is the same
-    strided gallery sample).  Each lane has its own workspace (ops.workspace is keyed by stream)."""
-    dev = x.device
-    (m, d), n = x.shape, y.shape[0]
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
-    if key not in _F16R_LANE_POOL:      # created once: streams created at different times may share a hardware queue
-        _F16R_LANE_POOL[key] = [torch.cuda.Stream(device=dev) for _ in range(2)]
-    lanes = _F16R_LANE_POOL[key]
-    nb = 4 if m >= 8192 else 2
-    step = -(-(-(-m // nb)) // 256) * 256                 # block rows: a multiple of the 256-row tile
-    bounds = [(lo, min(lo + step, m)) for lo in range(0, m, step)]
-    flags = torch.zeros(len(bounds), dtype=torch.int32, device=dev)
-    main = torch.cuda.current_stream(dev)
-    lib = _lib.load()
-    for lane in lanes:
-        lane.wait_stream(main)
-    for b, (lo, hi) in enumerate(bounds):
-        lane = lanes[b % 2]
-        with torch.cuda.stream(lane):
-            rows = hi - lo
-            ws = workspace(lib.oibl_sqdist_topk_f16r_workspace_bytes(rows, n, d, k), dev, "sqdist_topk")
-            _lib.check(lib.oibl_sqdist_topk_f16r(
-                x.operand[lo:hi].data_ptr(), x.aux[lo:hi].data_ptr(), x.norms[lo:hi].data_ptr(),
-                x._source[lo:hi].data_ptr(), rows, _ptr(y.operand), _ptr(y.aux), _ptr(y.norms), _ptr(y._source), n,
-                d, k, int(index_base), 0, ov[lo:hi].data_ptr(), oi[lo:hi].data_ptr(), flags[b:b + 1].data_ptr(),
-                _ptr(ws), ws.numel(), lane.cuda_stream), "sqdist_topk_f16r")
-    for lane in lanes:
-        main.wait_stream(lane)
-        for t in (ov, oi, flags, x.operand, x.aux, x.norms, x._source, y.operand, y.aux, y.norms, y._source):
-            t.record_stream(lane)
-    torch.amax(flags, dim=0, keepdim=True, out=flag)
-    return ov, oi, flag
 
 
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, regstage: bool = False) -> torch.Tensor:

@@ -141,3 +141,57 @@ def test_device_resident_flow_refuses_a_loader_it_cannot_index(group, state_dict
     bad = torch.utils.data.DataLoader(gset, batch_size=4, sampler=DistributedSliceSampler(gset), drop_last=True)
     with pytest.raises(ValueError, match="DistributedSliceSampler"):
         Evaluator(model).evaluate(ql, query + gallery, query, gallery, gt, gallery_loader=bad)
+
+
+@pytest.mark.parametrize("precision", ["f16mx", "bf16x3"])
+def test_images_to_recall_at_480x640_in_the_headline_arithmetic(group, state_dict, dev, precision):
+    """images -> Recall@1/5/10 through `Evaluator.evaluate` (ibl/evaluators.py:176-201) in the
+    1e-4 arithmetics at the benchmark resolution: 74 planted 480x640 images (24 queries, 50 gallery), batches of
+    32 with ragged last batches, DistributedSliceSampler, the device-resident flow (f16mx: top-k by the fp16
+    filter + exact rescoring) and the reference's host flow (full matrix), with and without spatial NMS — all equal
+    to the oracle's recalls on its own fp32 descriptors, and the gathered descriptors themselves within 1e-4."""
+    import hubconf
+    from ibl.evaluators import Evaluator, extract_features
+    from ibl.utils.data.sampler import DistributedSliceSampler
+    model = hubconf.vgg16_netvlad()
+    model.load_state_dict(state_dict)
+    model = model.to(dev).eval().set_precision(precision)
+    nq, ng = 24, 50
+    base = synth.images(ng // 2, 480, 640, seed=61)
+    gen = torch.Generator().manual_seed(62)
+    # gallery: two views per place (the second a noisy copy); queries: noisier copies of a view, half of them hard
+    gal = torch.empty((ng, 3, 480, 640))
+    for j in range(ng):
+        gal[j] = base[j // 2] + (0.0 if j % 2 == 0 else 12.0) * torch.randn((3, 480, 640), generator=gen)
+    qry = torch.empty((nq, 3, 480, 640))
+    for i in range(nq):
+        qry[i] = gal[(2 * i + 1) % ng] + (10.0 if i % 2 else 45.0) * torch.randn((3, 480, 640), generator=gen)
+    imgs = torch.cat([qry, gal])
+    query = [(f"q{i}.png", 1000 + i, 0.0, 0.0) for i in range(nq)]
+    gallery = [(f"g{j}.png", j // 2, 0.0, 0.0) for j in range(ng)]
+    gt = [[(2 * i + 1) % ng] for i in range(nq)]
+    qset, gset = _Records(qry, query), _Records(gal, gallery)
+
+    def loader(ds):
+        return torch.utils.data.DataLoader(ds, batch_size=32, num_workers=0, shuffle=False,
+                                           sampler=DistributedSliceSampler(ds))
+
+    with torch.no_grad():
+        desc = torch.cat([od.extract_cnn_feature(imgs[i:i + 8], state_dict) for i in range(0, nq + ng, 8)])
+    pids = [g[1] for g in gallery]
+    d = om.pairwise_distance(desc[:nq], desc[nq:]).numpy()
+    want, want_nms = om.evaluate_all(d, gt, pids), om.evaluate_all(d, gt, pids, nms=True)
+    ev = Evaluator(model)
+    r_dev = ev.evaluate(loader(qset), query + gallery, query, gallery, gt, gallery_loader=loader(gset))
+    r_host = ev.evaluate(loader(qset), query + gallery, query, gallery, gt, gallery_loader=loader(gset),
+                         device_resident=False)
+    r_nms = ev.evaluate(loader(qset), query + gallery, query, gallery, gt, gallery_loader=loader(gset), nms=True)
+    print(precision, "recalls", r_dev, r_host, want, "nms", r_nms, want_nms)
+    assert np.array_equal(r_dev, want) and np.array_equal(r_host, want) and np.array_equal(r_nms, want_nms)
+    assert 0.3 < want[0] and want[2] <= 1.0
+    feats = extract_features(model, loader(gset), gallery, gpu=dev.index)
+    got = torch.stack([feats[g[0]] for g in gallery]).double()
+    err = ((got - desc[nq:].double()).abs().amax(1) / desc[nq:].double().abs().amax(1)).max().item()
+    print(f"{precision}: gathered gallery descriptors, worst image max|diff| / max|want| = {err:.2e}")
+    assert err <= 1e-4
+    assert model.base_model.range_fallbacks == 0

@@ -164,20 +164,3 @@ def test_topk_precision_rule():
     with pytest.raises(ValueError):
         ops.pairwise_sqdist(torch.zeros(2, 64), torch.zeros(2, 64), "f16r")
 
-
-def test_two_lane_blocks_equal_one_call(dev):
-    """Query sets from 4096 rows on are matched in row blocks alternating between two streams (ops._f16r_two_lanes):
-    same lists, same flag protocol."""
-    m, n, d, k = 4096 + 300, 16384, 128, 10
-    q, g, _, _ = synth.retrieval_problem(m, n, dim=d, seed=77, hard_fraction=0.5)
-    qp, gp = ops.PreparedRows(q.to(dev), "f16r"), ops.PreparedRows(g.to(dev), "f16r")
-    v2, i2, f2 = ops.sqdist_topk_prepared(qp, gp, k, index_base=5, defer_check=True)
-    ops.F16R_LANES = False
-    try:
-        v1, i1, f1 = ops.sqdist_topk_prepared(qp, gp, k, index_base=5, defer_check=True)
-    finally:
-        ops.F16R_LANES = True
-    torch.cuda.synchronize()
-    assert int(f1.item()) == 0 and int(f2.item()) == 0
-    assert torch.equal(v1, v2) and torch.equal(i1, i2)
-    _assert_lists("f16r two lanes", q, g, v2, i2 - 5, k)

@@ -173,6 +173,42 @@ def test_configs1_batch32_trained_like_weights(dev, precision):
     assert_desc(f"trained-like weights, batch 32, {precision} (conv1_2 peak {peak:.3g})", got, want, TOL_DESC)
 
 
+def test_configs1_batch32_calibrated_activation_range(dev):
+    """BASELINE configs[1] on weights whose per-layer activation maxima are calibrated to what
+    fixed-point studies report for the trained VGG16 on 0-255-scale pixels (synth.backbone_state_calibrated: up to
+    2.8e4 behind conv3_3 on the calibration batch, heavy-tailed channel gains) — the fallback RATE of the f16mx
+    range guard at the benchmark batch, and the descriptors of every image inside 1e-4 whether or not a batch is
+    re-run.  The device maxima of the test batch are reported per layer (bf16x3 feature maps)."""
+    sd = synth.backbone_state_calibrated(0)
+    sd.update(synth.netvlad_state(0))
+    sd.update(synth.pca_state(0))
+    n_batches, fallbacks, runs = 3, 0, {}
+    model = _model(sd, dev, "f16mx")
+    worst = 0.0
+    for k in range(n_batches):
+        x = synth.images(32, 480, 640, seed=700 + k)
+        with torch.no_grad():
+            want = torch.cat([od.embednetpca(x[i:i + 8], sd) for i in range(0, 32, 8)])
+        before = model.base_model.range_fallbacks
+        got = model(x.to(dev))
+        fallbacks += model.base_model.range_fallbacks - before
+        assert_desc(f"calibrated activations, batch {k}, f16mx (+ guard)", got, want, TOL_DESC)
+        if k == 0:   # where the batch's activations peak (device, bf16x3 maps of 8 images: layer by layer)
+            ws, bs = model.base_model._packed(dev, "bf16x3")
+            cur = ops.conv1_1_nchw(x[:8].to(dev), ws[0], bs[0], "bf16x3")
+            peaks = [float(ops.x3_join(cur).max())]
+            for li in range(1, 13):
+                cin, cout, relu, pool = ops.VGG16_CFG[li]
+                cur = ops.conv3x3_nhwc(cur, ws[li], bs[li], bool(relu), bool(pool), "bf16x3")
+                peaks.append(float(ops.x3_join(cur).abs().max()))
+            print("per-layer maxima of 8 test images: " + " ".join(f"{p:.3g}" for p in peaks))
+            worst = max(peaks)
+    runs = dict(model.base_model.precision_runs)
+    print(f"calibrated activations: {fallbacks} of {n_batches} batches of 32 re-run in bf16x3 "
+          f"(largest activation seen {worst:.3g}; fp16 max 65504); precision_runs {runs}")
+    assert worst > 2e4            # the calibration did reach the band the test is about
+
+
 def test_matching_marks_out_of_range_rows(dev):
     """The distance kernels' f16mx operands: a descriptor row with an element beyond fp16 gets the norm +inf,
     so every distance to it is +inf (never a finite wrong number); all other rows are untouched."""

@@ -44,12 +44,18 @@ def test_split_layers_against_fp64_and_the_one_pass_kernel(dev, N, H, W, cin, co
     xd = ops.mx_split(ops.nchw_f32_to_nhwc(x.to(dev), "fp32"))
     wp, bd = ops.pack_conv3x3(w.to(dev), "f16mx"), b.to(dev)
     run = lambda: ops.conv3x3_nhwc(xd, wp, bd, relu, pool, "f16mx")   # noqa: E731
+    if cout == 128:
+        # the 128-output-channel layers run on the 4-wave halo kernel (conv_halo4.h) in one pass by default; their
+        # 512 x 128 ring tiling and its split-K remainder stay in the library behind the hook, and stay tested
+        lib.debug_hooks().oibl_debug_set_mx_variant(1)
     assert lib.load().oibl_conv3x3_workspace_bytes(N, H, W, cin, cout, int(pool), ops.F16MX) > 0   # the plan splits
     y = run()
     got = ops.nhwc_to_nchw_f32(ops.mx_join(y)).cpu()
     assert_rel_l2(f"split-K f16mx {N}x{H}x{W} {cin}->{cout}", got, want, TOL_LAYER)
     assert torch.equal(run(), y) and torch.equal(run(), y)          # fixed-order reduction: the same bits every time
     h = lib.debug_hooks()
+    if cout == 128:
+        h.oibl_debug_set_mx_variant(1)
     h.oibl_debug_set_mx_splitk(2)                                    # the one-thread-per-line reduction: same bits
     try:
         assert torch.equal(ops.conv3x3_nhwc(xd, wp, bd, relu, pool, "f16mx"), y)
