@@ -346,9 +346,11 @@ def time_matching(c, precision, Q, G, msteps=10):
     gp = ops.PreparedRows(g, mp)
     qs, qper, _ = sharded.slice_bounds(Q, c.rank, c.world)
     q_local = q[(qs + torch.arange(qper, device=dev)) % Q].contiguous() if c.world > 1 else q   # (wrapped slice)
-    blocks = 2 if c.world > 1 else 1
+    blocks = 4 if c.world > 1 else 1
 
     def step():
+        if c.world > 1:     # both exchanges in sub-blocks under the matrix work (sharded.sharded_topk_pipelined)
+            return sharded.sharded_topk_pipelined(q_local, Q, gp, 10, start, mp, blocks=blocks)
         qp = sharded.gather_prepared_queries(q_local, Q, mp)
         return sharded.sharded_topk(qp, gp, 10, start, mp, blocks=blocks)
     for _ in range(3):
@@ -419,9 +421,10 @@ def time_matching(c, precision, Q, G, msteps=10):
             "ms_per_step": float(mt.item()) / msteps * 1e3, "scaling": "strong",
             "tflops": round(pairs * 8192 / 1e12, 2), "roofline": roof, "correctness": check,
             "config": {"workload": f"{Q} queries x {G} gallery x 4096-d squared-L2 + top-10, gallery sharded "
-                                   f"{c.world}-way and resident as prepared operands; per step: every rank prepares "
-                                   f"its Q/{c.world} queries, all_gather of the prepared queries, local top-k in "
-                                   f"{blocks} query block(s), top-k all_gather + merge",
+                                   f"{c.world}-way and resident as prepared operands; per step: the Q/{c.world} queries "
+                                   f"of every rank travel in {blocks} sub-block(s) (all_gather under the previous "
+                                   f"sub-block's matrix work), local top-k per sub-block, top-k all_gather + merge under "
+                                   f"the next one",
                        "precision": mp, "model_precision": precision,
                        "arithmetic": {"f16r": "fp16 filter pass (v_mfma_f32_32x32x16_f16, per-row power-of-two scales) "
                                               "with a rigorous per-pair error bound + fp64-accumulated rescoring of the "

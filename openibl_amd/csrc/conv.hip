@@ -983,6 +983,7 @@ static int launch_conv_halo4(const ConvParams& p, hipStream_t st, int stagger) {
   q.relu = p.relu;
   q.out_f32 = p.out_f32;
   q.range_flag = p.range_flag;
+  q.prof = g_prof_buf;
   auto kern = conv3x3_halo4_kernel<POOL>;
   OIBL_SET_MAX_LDS(kern, H4_LDS);
   hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_m * q.tiles_n)), dim3(H4_THREADS), H4_LDS, st, q);
@@ -1015,6 +1016,7 @@ OIBL_HOOK(int, g_mx_splitk, 1);   // test hook: 0 = never split; 2 = split, redu
 OIBL_HOOK(int, g_mx_variant, 0);  // test hook: kernel choice of the f16mx layers (launch_conv_mx)
 // the 128-output-channel layers run on conv_halo4.h (256-pixel tiles, two workgroups per CU): no ring rounds to balance
 static bool mx_halo4_layer(int cin, int cout) {
+  if (g_mx_variant == 13) return cout % 128 == 0 && cin % 64 == 0;   // experiment: every layer on conv_halo4.h
   return (g_mx_variant == 0 || g_mx_variant == 3 || (g_mx_variant >= 9 && g_mx_variant <= 12)) && cout == 128 && cin % 64 == 0;
 }
 static MxSplitPlan mx_split_plan(long m_plain, int cin, int cout, int pool, int korder, int wm) {
@@ -1298,9 +1300,10 @@ static int launch_conv_mx(const ConvParams& p, int pool, hipStream_t st) {
     return pool ? launch_conv_halo<true>(p, st) : launch_conv_halo<false>(p, st);
   // the 4-wave halo kernel (conv_halo4.h) for the 128-output-channel layers (rv == 4: conv2_1 / conv2_2): a third
   // of the ring's L2 -> LDS bytes per K-tile.  Hook: 1 = ring, 9 = halo4 with the first-round stagger, 10 = ring.
-  if (rv == 4 && mx_halo4_layer(p.cin, p.cout)) {
-    // hook 9 / 10 / 11 / 12: de-phasing by TG_ID (the default) / two block-index guesses / off
-    const int stag = g_mx_variant == 12 ? 0 : g_mx_variant == 10 ? 2 : g_mx_variant == 11 ? 3 : 1;
+  if ((rv == 4 || (g_mx_variant == 13 && rv == 2)) && mx_halo4_layer(p.cin, p.cout)) {
+    // hook 9 / 10 / 11: de-phasing of a CU's two workgroups by TG_ID / two block-index guesses (default and 12: off —
+    // measured: no effect, profiles/r05_*_precbench)
+    const int stag = g_mx_variant == 9 ? 1 : g_mx_variant == 10 ? 2 : g_mx_variant == 11 ? 3 : 0;
     return pool ? launch_conv_halo4<true>(p, st, stag) : launch_conv_halo4<false>(p, st, stag);
   }
   if (g_mx_variant == 2) {

@@ -67,6 +67,7 @@ struct HaloParams {
   unsigned hp_mul, hp_sh;    // divide by PW + 2: halo position -> (hy, hx)
   int relu, out_f32;
   unsigned* range_flag;      // raised when an output is beyond fp16 (common.h, mx_raise_range_flag); may be null
+  unsigned long long* prof;  // test hook (debug library, conv_halo4.h): per-workgroup stamps, tests/gpu_halo4_phase.py
 };
 
 // one phase's matrix work on two 32x32 accumulator tiles (ring_core.h, compute)

@@ -57,6 +57,18 @@ __global__ __launch_bounds__(H4_THREADS, 2) void conv3x3_halo4_kernel(HaloParams
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
+#ifdef OIBL_DEBUG_HOOKS   // (debug library only: conv_ring.h, wgprof)
+  const bool wgprof = p.prof != nullptr && wave == 0 && lane == 0;
+#else
+  constexpr bool wgprof = false;
+#endif
+  if (wgprof) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    p.prof[64 + 4 * (size_t)blockIdx.x] = __builtin_amdgcn_s_memtime();
+    p.prof[64 + 4 * (size_t)blockIdx.x + 1] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+  }
   int tm, tn;
   xcd_tile(blockIdx.x, (unsigned)p.tiles_m, (unsigned)p.tiles_n, p.raster & 255, tm, tn);
   const unsigned img = ring_div_u31((unsigned)tm, p.img_mul, p.img_sh);
@@ -330,6 +342,7 @@ __global__ __launch_bounds__(H4_THREADS, 2) void conv3x3_halo4_kernel(HaloParams
 #undef H4_IC
   wait_vmcnt<0>();  // (sink writes of the last dummies)
   __syncthreads();
+  if (wgprof) p.prof[64 + 4 * (size_t)blockIdx.x + 3] = __builtin_amdgcn_s_memtime();
 
   // ---- epilogue: conv_halo.h's — fp32 staging with the chunk swizzle, one thread per (row, 32-channel group) packs
   //      its f16mx line in place, full lines out — for 128 channels and 256 threads
@@ -428,6 +441,7 @@ __global__ __launch_bounds__(H4_THREADS, 2) void conv3x3_halo4_kernel(HaloParams
     }
     if (pass + 1 < PASSES) __syncthreads();
   }
+  if (wgprof) p.prof[64 + 4 * (size_t)blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
 }
 
 }  // namespace oibl

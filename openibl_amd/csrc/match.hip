@@ -1385,7 +1385,7 @@ static F16rPlan f16r_plan(int m, int n, int d, int k) {
   F16rPlan f = {};
   f.t = topk_plan(m, n, d, k, OIBL_BF16, 0);   // 2-byte operand rows: the bf16 plan's sample / capacity / legality
   f.K2 = f16r_k2(k);
-  f.fused = f.t.fused && f.K2 <= F16R_MAX_K2 && f.K2 <= f.t.cap;
+  f.fused = f.t.fused && k <= SEL_MAX_K && f.K2 <= F16R_MAX_K2 && f.K2 <= f.t.cap;   // (k: the selection's register rounds)
   size_t o = f.t.total;
   f.off_lval = o;
   o += align_up((size_t)m * f.K2 * sizeof(float), 256);
@@ -1503,8 +1503,13 @@ int oibl_sqdist_topk_f16r(const void* xh, const float* xaux, const float* xn, co
   //    raises *overflow)
   float* lval = (float*)(wsb + f.off_lval);
   int32_t* lidx = (int32_t*)(wsb + f.off_lidx);
-  hipLaunchKernelGGL(f16r_select_kernel<32>, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, q.cand_val, q.cand_idx, cnt,
-                     m, t.cap, k, f.K2, xn, (const float4*)xaux, ymax, q.gamma, lval, lidx, (int*)overflow);
+  hipLaunchKernelGGL((f16r_select_kernel<32, false>), dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, q.cand_val,
+                     q.cand_idx, cnt, m, t.cap, k, f.K2, 2048, xn, (const float4*)xaux, ymax, q.gamma, lval, lidx,
+                     (int*)overflow);
+  OIBL_LAUNCH_CHECK();
+  // (the rare lists beyond 2048 entries: one workgroup per such query; every other workgroup returns at once)
+  hipLaunchKernelGGL((f16r_select_kernel<32, true>), dim3((unsigned)m), dim3(256), 0, st, q.cand_val, q.cand_idx, cnt,
+                     m, t.cap, k, f.K2, 2048, xn, (const float4*)xaux, ymax, q.gamma, lval, lidx, (int*)overflow);
   OIBL_LAUNCH_CHECK();
   // 4. exact distances of the members, final selection
   F16rRescoreParams r = {};

@@ -306,35 +306,65 @@ __global__ __launch_bounds__(512) void pairwise_f16r_kernel(F16rParams p) {
 // than the register window or the candidate capacity, or more than K2 members: *overflow (exact path).
 constexpr int F16R_MAX_K2 = 1024;
 
-template <int NQ>
+// WG = false: one wave per query (four per workgroup), lists up to 64 NQ entries — longer ones are left to the
+// WG = true launch, one 256-thread workgroup per query, lists up to 256 NQ entries (the candidate capacity).  With
+// ~800 expected candidates and the k-th order statistic's gamma tail, a list beyond 2048 entries happens about once
+// per 8192 queries: the second launch finds its handful of rows by their counts and returns at once everywhere else.
+template <int NQ, bool WG>
 __global__ __launch_bounds__(256) void f16r_select_kernel(const float* __restrict__ cand_val,
                                                           const int32_t* __restrict__ cand_idx,
                                                           const int* __restrict__ cnt, int m, int cap, int k, int K2,
+                                                          int short_rows,
                                                           const float* __restrict__ xn, const float4* __restrict__ xaux,
                                                           const unsigned* __restrict__ ymax, float gamma,
                                                           float* __restrict__ lval, int32_t* __restrict__ lidx,
                                                           int* __restrict__ overflow) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= m) return;   // wave-uniform
+  __shared__ unsigned long long wsel[4 * SEL_MAX_K];   // WG: the k smallest keys of every wave
+  __shared__ int s_count;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tid = WG ? (int)threadIdx.x : lane, nthr = WG ? 256 : 64;
+  const int row = WG ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+  if (row >= m) return;   // (WG: workgroup-uniform; else wave-uniform)
   int n = cnt[row];
-  const int window = cap < 64 * NQ ? cap : 64 * NQ;
+  if (WG ? n <= short_rows : n > short_rows) return;     // the other launch's row
+  const int window = cap < nthr * NQ ? cap : nthr * NQ;
   if (n > window) {
-    if (lane == 0 && overflow) atomicOr(overflow, 1);
+    if (tid == 0 && overflow) atomicOr(overflow, 1);
     n = window;
   }
   const float* vr = cand_val + (size_t)row * cap;
   const int32_t* ir = cand_idx + (size_t)row * cap;
-  unsigned long long mine[NQ], keep[NQ];
+  unsigned long long mine[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    const int j = lane + 64 * q;
+    const int j = tid + nthr * q;
     mine[q] = TOPK_INF;
     if (j < n) mine[q] = ((unsigned long long)ordered_bits(vr[j]) << 32) | (unsigned)ir[j];
-    keep[q] = mine[q];
   }
-  unsigned long long w = TOPK_INF;
-  for (int r = 0; r < k; ++r) w = wave_extract_min(mine, lane);   // the k-th smallest key (TOPK_INF: fewer than k)
+  // the wave's k smallest keys leave `mine` one by one; lane r keeps the r-th (k <= SEL_MAX_K <= 64)
+  unsigned long long res = TOPK_INF, w = TOPK_INF;
+  for (int r = 0; r < k; ++r) {
+    w = wave_extract_min(mine, lane);
+    if (lane == r) res = w;
+  }
+  if constexpr (WG) {
+    if (tid == 0) s_count = 0;
+    if (lane < k) wsel[wave * SEL_MAX_K + lane] = res;
+    __syncthreads();
+    if (wave == 0) {       // the k-th smallest of the 4 k survivors (<= 128 keys: two per lane)
+      unsigned long long two[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int e = lane + 64 * h;
+        two[h] = e < 4 * k ? wsel[(e / k) * SEL_MAX_K + (e % k)] : TOPK_INF;
+      }
+      unsigned long long t_ = TOPK_INF;
+      for (int r = 0; r < k; ++r) t_ = wave_extract_min(two, lane);
+      if (lane == 0) wsel[0] = t_;   // (wave 0's own entries were read into `two` / `res` above)
+    }
+    __syncthreads();
+    w = wsel[0];
+  }
   const float T = w == TOPK_INF ? INFINITY : from_ordered_bits((uint32_t)(w >> 32));
   const float4 xa = xaux[row];
   const float nx = xa.y, rx = xa.z, xnr = xn[row];
@@ -342,26 +372,41 @@ __global__ __launch_bounds__(256) void f16r_select_kernel(const float* __restric
   const float ymx = __uint_as_float(ymax[2]), rmx = __uint_as_float(ymax[3]);
   const float eps_any = fmaf(A, ymx, B * rmx) + 1e-6f * (xnr + ymx * ymx);
   const float bound = T + 2.0f * eps_any;
-  int count = 0;
   float* lv = lval + (size_t)row * K2;
   int32_t* li = lidx + (size_t)row * K2;
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const float v = from_ordered_bits((uint32_t)(keep[q] >> 32));
-    const bool in = keep[q] != TOPK_INF && !(v > bound);          // (NaN on either side: keep)
+  // members: the extracted keys (lane r's `res`) and what is left in `mine`, if not beyond the bound
+  int count = 0;
+  auto emit = [&](unsigned long long key) __attribute__((always_inline)) {
+    const float v = from_ordered_bits((uint32_t)(key >> 32));
+    const bool in = key != TOPK_INF && !(v > bound);              // (NaN on either side: keep)
     const unsigned long long mask = __ballot(in);
-    const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
+    int pos;
+    if constexpr (WG) {
+      int base = 0;
+      if (lane == 0 && mask) base = atomicAdd(&s_count, __popcll(mask));
+      base = __shfl(base, 0, 64);
+      pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+    } else {
+      pos = count + __popcll(mask & ((1ull << lane) - 1ull));
+      count += __popcll(mask);
+    }
     if (in && pos < K2) {
       lv[pos] = v;
-      li[pos] = (int32_t)(uint32_t)(keep[q] & 0xffffffffu);
+      li[pos] = (int32_t)(uint32_t)(key & 0xffffffffu);
     }
-    count += __popcll(mask);
+  };
+  emit(res);
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) emit(mine[q]);
+  if constexpr (WG) {
+    __syncthreads();
+    count = s_count;
   }
   if (count > K2) {
-    if (lane == 0 && overflow) atomicOr(overflow, 1);
+    if (tid == 0 && overflow) atomicOr(overflow, 1);
     count = K2;
   }
-  for (int e = count + lane; e < K2; e += 64) {
+  for (int e = count + tid; e < K2; e += nthr) {
     lv[e] = INFINITY;
     li[e] = -1;
   }

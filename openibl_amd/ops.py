@@ -39,10 +39,11 @@ def precision_code(p) -> int:
 def topk_precision(precision, storage_dtype=torch.float32, k: int = 10) -> int:
     """The arithmetic the fused distance + top-k of a model precision runs in: an f16mx model's descriptors are
     matched in f16r — fp16 filter pass + exact rescoring: fp32-exact lists, and faster than contracting every
-    pair in f16mx — when they are stored as float32 (the rescoring reads the fp32 rows) and k fits its
-    candidate window; everything else as asked."""
+    pair in f16mx — when they are stored as float32 (the rescoring reads the fp32 rows) and k fits the register
+    rounds of its selection (k <= 32: Recall@1/5/10; the 120 of spatial NMS stay in f16mx); everything else as
+    asked."""
     p = precision_code(precision)
-    if p == F16MX and storage_dtype == torch.float32 and k <= 496:
+    if p == F16MX and storage_dtype == torch.float32 and k <= 32:
         return F16R
     return p
 

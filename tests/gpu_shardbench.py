@@ -31,40 +31,56 @@ def timed(fn, iters=10, warm=3):
 worlds = [int(w) for w in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1, 2, 4, 8]
 prec = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 base = None
-print(f"precision {prec}; the gallery shard is resident (ops.PreparedRows); per step every rank prepares the Q / W "
-      f"queries it extracted, the two collectives of sharded.py (prepared queries; per-block top-k lists) are "
-      f"EMULATED by device copies of the gathered sizes (one GPU here: no xGMI latency in these numbers), the local "
-      f"top-k runs in 2 query blocks with the exchange + merge of block b on a second stream (bench.py's schedule)")
-q_all = ops.PreparedRows(q, prec)
+print(f"precision {prec}; the gallery shard is resident (ops.PreparedRows); per step the Q / W queries of every rank "
+      f"travel in 4 sub-blocks — the all_gather of sub-block b + 1 and the list exchange + merge of sub-block b on a "
+      f"second stream under the matrix work (sharded.sharded_topk_pipelined, bench.py's schedule) — both collectives "
+      f"EMULATED by device copies of the gathered sizes (one GPU here: no xGMI time in these numbers)")
+BLOCKS = 4
 side = torch.cuda.Stream()
 main = torch.cuda.current_stream()
-half = Q // 2
-q_blocks = [ops.PreparedRows.from_parts(q_all.operand_rows()[lo:lo + half], q_all.norms[lo:lo + half], D, prec)
-            for lo in (0, half)]
 for world in worlds:
     n = G // world
     shard = ops.PreparedRows(gal[:n].contiguous(), prec)
-    q_mine = q[: Q // world].contiguous()
-    rows_src = q_all.operand_rows()
-    rows_dst = torch.empty_like(rows_src)
-    lists_src = torch.randn((world, half + 1, 2 * K), device=dev)
+    qper = Q // world
+    q_mine = q[:qper].contiguous()
+    sub = qper // BLOCKS if world > 1 else qper
+    rows_travel = prec in ("f16r", "fp32")
+    # what one sub-block's all_gather delivers: world * sub rows (fp32 rows, or prepared operand rows + norms)
+    q_sub = q[: world * sub].contiguous()
+    p_sub = ops.PreparedRows(q_sub, prec)
+    gathered_src = q_sub if rows_travel else p_sub.operand_rows().contiguous()
+    gathered_dst = torch.empty_like(gathered_src)
+    lists_src = torch.randn((world, world * sub + 1, 2 * K), device=dev)
     lists_dst = torch.empty_like(lists_src)
-    vals = torch.randn((half, world * K), device=dev)
-    idx = torch.randint(0, G, (half, world * K), device=dev, dtype=torch.int32)
+    vals = torch.randn((world * sub, world * K), device=dev)
+    idx = torch.randint(0, G, (world * sub, world * K), device=dev, dtype=torch.int32)
 
     def step():
-        ops.PreparedRows(q_mine, prec)                     # this rank's share of the queries
-        if world > 1:
-            rows_dst.copy_(rows_src)                       # all_gather of the prepared queries (gathered size)
-        for qb in q_blocks if world > 1 else [q_all]:
-            out = ops.sqdist_topk_prepared(qb, shard, K, defer_check=True)      # as sharded.py
-            if world > 1:
-                side.wait_stream(main)
+        if world == 1:
+            return ops.sqdist_topk_prepared(ops.PreparedRows(q_mine, prec), shard, K, defer_check=True)
+        side.wait_stream(main)
+        evs = []
+        for b in range(BLOCKS):                         # sharded.sharded_topk_pipelined with device copies as collectives
+            if b == 0:
                 with torch.cuda.stream(side):
-                    lists_dst.copy_(lists_src)             # all_gather of this block's lists (gathered size)
-                    ops.row_topk(vals, K, idx_in=idx)      # k-way merge
-        if world > 1:
-            main.wait_stream(side)
+                    if not rows_travel:
+                        ops.PreparedRows(q_mine[:sub], prec)
+                    gathered_dst.copy_(gathered_src)    # all_gather of sub-block 0 (gathered size)
+                    e0 = torch.cuda.Event(); e0.record(side); evs.append(e0)
+            if b + 1 < BLOCKS:
+                with torch.cuda.stream(side):
+                    if not rows_travel:
+                        ops.PreparedRows(q_mine[:sub], prec)
+                    gathered_dst.copy_(gathered_src)    # sub-block b + 1 travels under sub-block b's matrix work
+                    e = torch.cuda.Event(); e.record(side); evs.append(e)
+            main.wait_event(evs[b])
+            qb = ops.PreparedRows(q_sub, prec) if rows_travel else p_sub
+            out = ops.sqdist_topk_prepared(qb, shard, K, defer_check=True)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                lists_dst.copy_(lists_src)              # all_gather of this sub-block's lists (gathered size)
+                ops.row_topk(vals, K, idx_in=idx)       # k-way merge
+        main.wait_stream(side)
         return out
     t = timed(step)
     base = base or t

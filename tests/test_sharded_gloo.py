@@ -158,6 +158,23 @@ def _worker(rank, world, port, G, ret):
                                       local_topk_fn=_first_block_overflows, merge_fn=_oracle_merge)
         ok_topk = ok_topk and _first_block_overflows.calls == [(False, 8), (False, 8), (False, 8), (True, 8)] and \
             bool(np.array_equal(i8.numpy(), wi) and np.allclose(v8.numpy(), wv))
+        # both exchanges pipelined under the matrix work (sharded_topk_pipelined): the local query slice travels
+        # in sub-blocks — as prepared parts, or as fp32 rows prepared after the gather (f16r / fp32) — same lists
+        for nb in (1, 2, 3, 7):
+            v9, i9 = sharded.sharded_topk_pipelined(q_loc, Qn, g[start:start + n_valid], 10, start, blocks=nb,
+                                                    local_topk_fn=_prepared_local_topk, merge_fn=_oracle_merge,
+                                                    prepare_fn=_CpuPrepared)
+            v10, i10 = sharded.sharded_topk_pipelined(q_loc, Qn, g[start:start + n_valid], 10, start, blocks=nb,
+                                                      local_topk_fn=_oracle_local_topk, merge_fn=_oracle_merge,
+                                                      prepare_fn=lambda x: x, rows_travel=True)
+            ok_topk = ok_topk and bool(np.array_equal(i9.numpy(), wi) and np.array_equal(i10.numpy(), wi)
+                                       and np.allclose(v9.numpy(), wv) and np.allclose(v10.numpy(), wv))
+        _first_block_overflows.calls = []
+        v11, i11 = sharded.sharded_topk_pipelined(q_loc, Qn, g[start:start + n_valid], 10, start, blocks=3,
+                                                  local_topk_fn=_first_block_overflows, merge_fn=_oracle_merge,
+                                                  prepare_fn=lambda x: x, rows_travel=True)
+        ok_topk = ok_topk and bool(np.array_equal(i11.numpy(), wi)) and \
+            [c_[0] for c_ in _first_block_overflows.calls] == [False, False, False, True]
         rec = evaluators.recalls_from_topk(idx.numpy(), gt)
         ok_rec = bool(np.array_equal(rec, om.evaluate_all(d, gt, pids)))
 
@@ -245,6 +262,12 @@ def _worker8(rank, world, port, ret):
                                     local_topk_fn=_first_block_overflows, merge_fn=_oracle_merge)
         ok = ok and bool(np.array_equal(i.numpy(), wi)) and \
             _first_block_overflows.calls == [(False, 10), (False, 10), (False, 10), (True, 10)]
+        # the pipelined form: every rank's 4 local queries travel in 1 / 2 / 4 sub-blocks (the last slice wraps)
+        for nb in (1, 2, 4):
+            v, i = sharded.sharded_topk_pipelined(q_loc, Q, g[start:start + n_valid], k, start, blocks=nb,
+                                                  local_topk_fn=_prepared_local_topk, merge_fn=_oracle_merge,
+                                                  prepare_fn=_CpuPrepared)
+            ok = ok and bool(np.array_equal(i.numpy(), wi) and np.allclose(v.numpy(), wv))
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
