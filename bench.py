@@ -346,7 +346,7 @@ def time_matching(c, precision, Q, G, msteps=10):
     gp = ops.PreparedRows(g, mp)
     qs, qper, _ = sharded.slice_bounds(Q, c.rank, c.world)
     q_local = q[(qs + torch.arange(qper, device=dev)) % Q].contiguous() if c.world > 1 else q   # (wrapped slice)
-    blocks = 4 if c.world > 1 else 1
+    blocks = 2 if c.world > 1 else 1
 
     def step():
         if c.world > 1:     # both exchanges in sub-blocks under the matrix work (sharded.sharded_topk_pipelined)

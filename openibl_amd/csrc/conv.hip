@@ -947,9 +947,9 @@ static int launch_conv_halo(const ConvParams& p, hipStream_t st) {
 }
 
 // The 128-output-channel layers (conv2_1, conv2_2): conv_halo4.h — 256 pixels x 128 channels, 4 waves, two
-// workgroups per CU.  stagger (test hook): first-round workgroups of a CU's second slot start half a chunk late.
+// workgroups per CU.
 template <bool POOL>
-static int launch_conv_halo4(const ConvParams& p, hipStream_t st, int stagger) {
+static int launch_conv_halo4(const ConvParams& p, hipStream_t st) {
   HaloParams q = {};
   q.in = p.in;
   q.w = p.w;
@@ -970,12 +970,7 @@ static int launch_conv_halo4(const ConvParams& p, hipStream_t st, int stagger) {
   q.tiles_n = p.cout / H4_BN;
   OIBL_REQUIRE(tiles_m * q.tiles_n <= 0x7fffffffL, "conv3x3 (halo4): grid out of range");
   q.tiles_m = (int)tiles_m;
-  // first-round de-phasing of a CU's two workgroups (conv_halo4.h): half a tile — its 9 Cin / 32 K-tiles plus an
-  // epilogue worth ~14 more, ~900 cycles each — in sleeps of 8128 cycles (conv2_1: 2, conv2_2: 3)
-  int sleeps = ((9 * (p.cin / 32) + 14) * 450 + 4064) / 8128;
-  if (sleeps < 1) sleeps = 1;
-  if (sleeps > 15) sleeps = 15;
-  q.raster = (g_ring_raster & 255) | ((stagger & 15) << 8) | (sleeps << 12);
+  q.raster = g_ring_raster & 255;
   ring_magic_u31((unsigned)(q.tiles_y * q.tiles_x), &q.img_mul, &q.img_sh);
   ring_magic_u31((unsigned)q.tiles_x, &q.tx_mul, &q.tx_sh);
   ring_magic_u31((unsigned)(POOL ? q.PW / 2 : q.PW), &q.pw_mul, &q.pw_sh);
@@ -1017,7 +1012,7 @@ OIBL_HOOK(int, g_mx_variant, 0);  // test hook: kernel choice of the f16mx layer
 // the 128-output-channel layers run on conv_halo4.h (256-pixel tiles, two workgroups per CU): no ring rounds to balance
 static bool mx_halo4_layer(int cin, int cout) {
   if (g_mx_variant == 13) return cout % 128 == 0 && cin % 64 == 0;   // experiment: every layer on conv_halo4.h
-  return (g_mx_variant == 0 || g_mx_variant == 3 || (g_mx_variant >= 9 && g_mx_variant <= 12)) && cout == 128 && cin % 64 == 0;
+  return (g_mx_variant == 0 || g_mx_variant == 3) && cout == 128 && cin % 64 == 0;
 }
 static MxSplitPlan mx_split_plan(long m_plain, int cin, int cout, int pool, int korder, int wm) {
   MxSplitPlan pl = {};
@@ -1299,13 +1294,10 @@ static int launch_conv_mx(const ConvParams& p, int pool, hipStream_t st) {
   if (halo_ok && (g_mx_variant == 3 || (g_mx_variant == 0 && p.cout == 256)))
     return pool ? launch_conv_halo<true>(p, st) : launch_conv_halo<false>(p, st);
   // the 4-wave halo kernel (conv_halo4.h) for the 128-output-channel layers (rv == 4: conv2_1 / conv2_2): a third
-  // of the ring's L2 -> LDS bytes per K-tile.  Hook: 1 = ring, 9 = halo4 with the first-round stagger, 10 = ring.
-  if ((rv == 4 || (g_mx_variant == 13 && rv == 2)) && mx_halo4_layer(p.cin, p.cout)) {
-    // hook 9 / 10 / 11: de-phasing of a CU's two workgroups by TG_ID / two block-index guesses (default and 12: off —
-    // measured: no effect, profiles/r05_*_precbench)
-    const int stag = g_mx_variant == 9 ? 1 : g_mx_variant == 10 ? 2 : g_mx_variant == 11 ? 3 : 0;
-    return pool ? launch_conv_halo4<true>(p, st, stag) : launch_conv_halo4<false>(p, st, stag);
-  }
+  // of the ring's L2 -> LDS bytes per K-tile.  Hook: 1 = ring kernels; 13 = EVERY layer on it (experiment: conv3_x
+  // ties with the 8-wave halo kernel, conv4_x / conv5_x lose 12-16 %, profiles/r05_*_timing.txt).
+  if ((rv == 4 || (g_mx_variant == 13 && rv == 2)) && mx_halo4_layer(p.cin, p.cout))
+    return pool ? launch_conv_halo4<true>(p, st) : launch_conv_halo4<false>(p, st);
   if (g_mx_variant == 2) {
     if (rv == 2) return pool ? launch_conv_ring<2, true, RING_MX>(p, st) : launch_conv_ring<2, false, RING_MX>(p, st);
     if (rv == 4) return pool ? launch_conv_ring<4, true, RING_MX>(p, st) : launch_conv_ring<4, false, RING_MX>(p, st);

@@ -13,9 +13,16 @@
 //     fragment reads of A and 2 of B per 8 accumulator tiles), ONE per SIMD, 79 KB of LDS: TWO workgroups share
 //     a CU, each wave with the 256 registers it has in the 8-wave kernels.  The second workgroup is what the
 //     second stagger group is in ring_core.h — a wave with operands in registers while the other one loads —
-//     without any coupling: no barrier between the two, and the 16 KB single-buffered halo reload of one
+//     without any coupling: no barrier between the two, and the single-buffered halo reload of one
 //     workgroup (every 9 K-tiles; it needs a drained queue: conv_halo.h, "fully out-of-range LDS-DMA
-//     instructions do not retire in order") runs under the other one's matrix work.
+//     instructions do not retire in order") runs under the other one's matrix work.  Measured with per-workgroup
+//     stamps (tests/gpu_halo4_phase.py, profiles/r05_*): the two workgroups of a CU de-phase by themselves within
+//     the first tile — 95-100 % of every epilogue lies inside the other workgroup's K loop — so no start-up
+//     stagger is needed (three variants of one were tried: no effect).  What the design does NOT reach is the
+//     8-wave kernels' matrix-pipe occupancy inside the K loop: 2260-2660 cycles per K-tile and workgroup with two
+//     resident (57-68 % of 2 x 768) against 1660-1740 per 256 x 256 K-tile (88-92 %) — two UNCOORDINATED waves per
+//     SIMD do not alternate load and compute segments the way the barrier-staggered groups of ring_core.h do.  Net:
+//     conv2_1 0.76 -> 0.71 ms, conv2_2 1.10 -> 1.03 ms at batch 32 (the halved L2 -> LDS traffic pays for it).
 //   * with one wave per SIMD and no stagger discipline the weights need TWO barriers per K-tile, not four / eight.
 //
 // Schedule of K-tile t = tap `tap` of chunk cc (weights: two K-tile buffers of B0 | B1, 64 rows x 128 B each):
@@ -246,25 +253,6 @@ __global__ __launch_bounds__(H4_THREADS, 2) void conv3x3_halo4_kernel(HaloParams
           acc[i][j][4 * g + 3] = b.w;
         }
       }
-    }
-  }
-
-  // De-phasing the two workgroups of a CU.  Every tile of a layer takes the same time, so two workgroups that start
-  // together stay together: both in their K loops (the matrix pipe shared), then both in their epilogues (~100
-  // VALU instructions per stored line, the matrix pipe idle) — measured: 44k cycles of a conv2_1 round outside the
-  // K loops, 2x the ring kernel's.  A first-round workgroup in the CU's ODD workgroup slot (HW_ID.TG_ID) therefore
-  // starts half a tile late, once; the offset then persists from round to round, and one workgroup's epilogue runs
-  // under the other's matrix work.  HaloParams::raster bits 8-11: 0 = off, 1 = TG_ID, 2 / 3 = test variants that
-  // guess the slot from the block index; bits 12-15: sleeps of 8128 cycles.
-  {
-    const int mode = (p.raster >> 8) & 15, sleeps = (p.raster >> 12) & 15;
-    bool late = false;
-    if (mode == 1) late = blockIdx.x < 512u && ((__builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4) & 1) != 0);
-    else if (mode == 2) late = blockIdx.x < 512u && ((((blockIdx.x >> 3) >> 5) & 1) != 0);
-    else if (mode == 3) late = blockIdx.x < 512u && (((blockIdx.x >> 3) & 1) != 0);
-    if (late) {
-#pragma unroll 1
-      for (int s_ = 0; s_ < sleeps; ++s_) __builtin_amdgcn_s_sleep(127);
     }
   }
 

@@ -14,16 +14,14 @@ LAYERS = [  # (cin, cout, H, W, relu, pool)
     (64, 128, 240, 320, 1, 0), (128, 128, 240, 320, 1, 1), (128, 256, 120, 160, 1, 0), (256, 256, 120, 160, 1, 0),
     (256, 256, 120, 160, 1, 1), (256, 512, 60, 80, 1, 0), (512, 512, 60, 80, 1, 0),
     (512, 512, 60, 80, 1, 1), (512, 512, 30, 40, 1, 0), (512, 512, 30, 40, 0, 0)]
-PRECS = ("bf16", "bf16x3", "f16mx", "f16mx-ring", "f16mx-halo", "f16mx-late", "f16mx-s10", "f16mx-s11", "f16mx-s12", "f16mx-s13")
+PRECS = ("bf16", "bf16x3", "f16mx", "f16mx-ring", "f16mx-halo", "f16mx-late", "f16mx-s13")
 
 
 def sel(p):
     from openibl_amd import lib
     # 0: default dispatch, 1: ring kernels only, 3: halo kernel wherever it applies, 2: ring kernels with the
     # LDS-DMA issue inside the COMPUTE segments
-    # 13: EVERY layer on the 4-wave halo kernel (experiment)
-    # 10 / 11 / 12: the 4-wave halo kernel of conv2_x (conv_halo4.h) de-phased by two block-index guesses / not at all
-    # (default: by the CU's workgroup slot)
+    # 13: EVERY layer on the 4-wave halo kernel of conv2_x (conv_halo4.h; experiment)
     lib.debug_hooks().oibl_debug_set_mx_variant(3 if p.endswith("halo") else 1 if p.endswith("ring") else
                                                 2 if p.endswith("late") else int(p[-2:]) if p[-3] == "s" else 0)
 
@@ -44,7 +42,7 @@ def main():
         w = torch.randn((cout, cin, 3, 3), generator=g, device=dev) * (2.0 / (9 * cin)) ** 0.5
         b = torch.randn((cout,), generator=g, device=dev) * 0.1
         xs = {"bf16": xf.to(torch.bfloat16), "bf16x3": ops.x3_split(xf), "f16mx": ops.mx_split(xf)}
-        xs["f16mx-halo"] = xs["f16mx-ring"] = xs["f16mx-late"] = xs["f16mx-s10"] = xs["f16mx-s11"] = xs["f16mx-s12"] = xs["f16mx-s13"] = xs["f16mx"]
+        xs["f16mx-halo"] = xs["f16mx-ring"] = xs["f16mx-late"] = xs["f16mx-s13"] = xs["f16mx"]
         wp = {p: ops.pack_conv3x3(w, p.split("-")[0]) for p in PRECS}
         times = {p: [] for p in PRECS}
         outs = {}

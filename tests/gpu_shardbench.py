@@ -31,11 +31,11 @@ def timed(fn, iters=10, warm=3):
 worlds = [int(w) for w in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1, 2, 4, 8]
 prec = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 base = None
+BLOCKS = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 print(f"precision {prec}; the gallery shard is resident (ops.PreparedRows); per step the Q / W queries of every rank "
-      f"travel in 4 sub-blocks — the all_gather of sub-block b + 1 and the list exchange + merge of sub-block b on a "
+      f"travel in {BLOCKS} sub-blocks — the all_gather of sub-block b + 1 and the list exchange + merge of sub-block b on a "
       f"second stream under the matrix work (sharded.sharded_topk_pipelined, bench.py's schedule) — both collectives "
       f"EMULATED by device copies of the gathered sizes (one GPU here: no xGMI time in these numbers)")
-BLOCKS = 4
 side = torch.cuda.Stream()
 main = torch.cuda.current_stream()
 for world in worlds:

@@ -69,7 +69,7 @@ def main():
                     "over gloo (not a performance number)\n"
                     + "\n".join(l[:600] for l in (d / "bench_2ranks_shared.json").read_text().splitlines()
                                 if l.startswith("{")) + "\n\n")
-        for n in ("gpu.txt", "precbench.log", "bar1_ab.log", "stem_mx.log", "mx_stamps.log", "mx_probe.log", "timing_bf16x3.log", "timing_bf16.log", "timing_bf16x3_raster1.log",
+        for n in ("gpu.txt", "precbench.log", "matchbench.log", "halo4_phase.log", "bar1_ab.log", "stem_mx.log", "mx_stamps.log", "mx_probe.log", "timing_bf16x3.log", "timing_bf16.log", "timing_bf16x3_raster1.log",
                   "timing_bf16_raster1.log", "timing_fp32.log", "pcie.log", "convbench.log", "shardbench.log"):
             if (d / n).exists():
                 f.write(f"==== {n}\n" + (d / n).read_text() + "\n")
@@ -93,7 +93,7 @@ def main():
             ("prof_stats_f16mx", f"{tag}_kernel_stats_f16mx.md", f"python bench.py --precision f16mx --steps 40 --warmup 5 {skip}"),
             ("prof_stats_bf16x3", f"{tag}_kernel_stats_bf16x3.md", f"python bench.py --precision bf16x3 --steps 40 --warmup 5 {skip}"),
             ("prof_stats_bf16", f"{tag}_kernel_stats_bf16.md", f"python bench.py --precision bf16 --steps 40 --warmup 5 {skip}"),
-            ("prof_match", f"{tag}_kernel_stats_matching.md", "python bench.py --steps 2 --warmup 1 --skip-cpu-baseline --skip-api (with matching, both modes)")):
+            ("prof_match", f"{tag}_kernel_stats_matching.md", "python tests/gpu_matchbench.py --only prepared:f16r,bf16 --iters 3 (8192 x 81920 x 4096-d + top-10, resident prepared operands)")):
         p = d / sub / "bench_kernel_stats.csv"
         if p.exists():
             lines = [f"# {tag}: rocprofv3 --kernel-trace --stats -- {title}", "", a.note, ""] + kernel_stats(p)
@@ -107,6 +107,32 @@ def main():
             ent = traffic_table(fp, wp, prof, tag, prec)
             if ent:
                 digest[prec or "bf16"] = ent
+    # the matching step (tests/gpu_matchbench.py --only prepared:f16r,bf16): bytes per launch of the filter kernels
+    fp, wp = d / "prof_fetch_match" / "bench_counter_collection.csv", d / "prof_write_match" / "bench_counter_collection.csv"
+    if fp.exists() and wp.exists():
+        fe, wr = counter_avg(fp, "FETCH_SIZE"), counter_avg(wp, "WRITE_SIZE")
+        lines = [f"# {tag}: HBM traffic per launch of the matching step's kernels, 8192 x 81920 x 4096-d (rocprofv3 --pmc "
+                 "FETCH_SIZE / --pmc WRITE_SIZE, separate passes over tests/gpu_matchbench.py --only prepared:f16r,bf16)", "",
+                 "FETCH_SIZE doubled per MI355X_MICROARCH.md; MB = 1e6 bytes.  Algorithmic operand bytes of one step: "
+                 "(8192 + 81920) rows x 4096 x 2 B = 738 MB read once (+ 8192 x ~14 x 16 KB = 1.9 GB of fp32 rows gathered by "
+                 "the f16r rescoring).", "",
+                 "| kernel | launches | fetch MB (raw) | fetch MB (corrected) | write MB | avg us | corrected GB/s |",
+                 "|---|---|---|---|---|---|---|"]
+        for k, (n, v, t) in sorted(fe.items(), key=lambda kv: -kv[1][2]):
+            if n == 0 or "at::native" in k or "rocclr" in k:
+                continue
+            f_raw = v / n * 1024 / 1e6
+            w = wr.get(k, [1, 0.0, 1])
+            w_mb = w[1] / max(w[0], 1) * 1024 / 1e6
+            us = t / n / 1e3
+            lines.append(f"| `{short(k)}` | {n} | {f_raw:.1f} | {2 * f_raw:.1f} | {w_mb:.1f} | {us:.1f} | "
+                         f"{(2 * f_raw + w_mb) / us * 1e3:.0f} |")
+            for key, pat in (("matching_f16r", "pairwise_f16r_kernel<true"), ("matching_bf16", "pairwise_ring_kernel<true, 0")):
+                if pat in k:
+                    digest[key] = {"source": f"profiles/{tag}_hbm_traffic_matching.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                             "separate passes; FETCH doubled per MI355X_MICROARCH.md; the filter kernel)",
+                                   "bytes_per_launch": (2 * f_raw + w_mb) * 1e6}
+        (prof / f"{tag}_hbm_traffic_matching.md").write_text("\n".join(lines) + "\n")
     if digest:
         import json
         latest = prof / "hbm_traffic_latest.json"
