@@ -266,11 +266,245 @@ __global__ __launch_bounds__(256) void netvlad_apply_kernel(const float* __restr
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The FUSED NetVLAD layer (fp32 feature map: the head of the fp32 / bf16x3 / f16mx arithmetics) — north_star's
+// "soft-assignment softmax, residual accumulation and intra-/L2-norm as a fused kernel with coalesced reads of the
+// H x W x 512 feature map" (ibl/models/netvlad.py:44-61, 100-102), two launches instead of five, the map read ONCE:
+//
+//   netvlad_fused_kernel     one workgroup per (image, slab of pixels).  Per chunk of 32 pixels: the chunk's 32 x
+//                            512 values go to LDS with coalesced 16-byte loads (64.5 KB, rows 4 floats apart in the
+//                            banks); 1 / |x_p| from LDS; logits = x . w^T on v_mfma_f32_32x32x2_f32 — every wave
+//                            contracts its 128 channels, the four partial [32 x 64] tiles are added through LDS —
+//                            scaled by 1 / |x_p|; softmax over the 64 clusters; aggregation
+//                            sum_p a[p][k] / |x_p| * x[p][c] on the same instruction from the same LDS chunk, 64
+//                            clusters x 128 channels of accumulators per wave (128 VGPRs), kept across the slab's
+//                            chunks; at the end acc - (sum_p a[p][k]) centroids[k][c] -> parts[slab][n][k][c].
+//   netvlad_finalize_kernel  one workgroup per image: adds the slabs in slab order, intra-normalises the 64 cluster
+//                            rows, L2-normalises the 32768-vector (netvlad.py:100-102), writes raw and / or
+//                            normalised outputs.
+// Slab = 160 pixels (N >= 5: 8 slabs of a 30 x 40 map, 256 workgroups at batch 32) or 32 pixels (N <= 4: the chip
+// would idle otherwise) — chosen by N ALONE within each range, so a row's result does not depend on its batch mates
+// within a range.  Exact fp32 throughout; against the five-launch path (hook) the sums differ by association only.
+constexpr int NVF_XP = 516;          // floats per LDS row of the chunk: 16-byte aligned, +4 banks per pixel
+constexpr int NVF_LP = 65;           // pitch of the [32][64] logit / assignment tiles
+constexpr int NVF_LDS = (32 * NVF_XP + 4 * 32 * NVF_LP + 2 * 32 * NVF_LP + 32 + 64) * 4;
+
+__global__ __launch_bounds__(256) void netvlad_fused_kernel(const float* __restrict__ feat, const float* __restrict__ w,
+                                                            const float* __restrict__ centroids,
+                                                            float* __restrict__ parts, int P, int slab_px,
+                                                            int normalize) {
+  constexpr int C = 512;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* const x_s = reinterpret_cast<float*>(smem);             // [32][NVF_XP]
+  float* const lp_s = x_s + 32 * NVF_XP;                          // [4 waves][32][NVF_LP] partial logits
+  float* const a_s = lp_s + 4 * 32 * NVF_LP;                      // [32][NVF_LP] a[p][k]
+  float* const a2_s = a_s + 32 * NVF_LP;                          // [32][NVF_LP] a[p][k] / |x_p|
+  float* const inv_s = a2_s + 32 * NVF_LP;                        // [32]
+  float* const cs_s = inv_s + 32;                                 // [64] sum_p a[p][k] of the slab
+  const int n = blockIdx.x, slab = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int p_lo = slab * slab_px;
+  int p_hi = p_lo + slab_px;
+  if (p_hi > P) p_hi = P;
+  const float* fimg = feat + (size_t)n * P * C;
+
+  f32x16_t acc[2][4];          // [cluster tile][channel tile of this wave's 128 channels]
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[kt][ct][r] = 0.f;
+  float colsum = 0.f;          // threads 0..63
+
+  for (int p0 = p_lo; p0 < p_hi; p0 += 32) {
+    // ---- the chunk -> LDS (a pixel beyond the slab reads as zeros: it then gets a = 0 below)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int idx = (int)threadIdx.x + 256 * q;          // float4 index inside the chunk
+      const int px = idx >> 7, c4 = (idx & 127) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p0 + px < p_hi) v = *reinterpret_cast<const float4*>(fimg + (size_t)(p0 + px) * C + c4);
+      *reinterpret_cast<float4*>(x_s + px * NVF_XP + c4) = v;
+    }
+    __syncthreads();
+    // ---- 1 / |x_p|: eight threads per pixel, interleaved float4s
+    {
+      const int px = (int)threadIdx.x >> 3, sub = (int)threadIdx.x & 7;
+      float ss = 0.f;
+      if (normalize) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const float4 v = *reinterpret_cast<const float4*>(x_s + px * NVF_XP + 4 * (sub + 8 * j));
+          ss = fmaf(v.x, v.x, ss);
+          ss = fmaf(v.y, v.y, ss);
+          ss = fmaf(v.z, v.z, ss);
+          ss = fmaf(v.w, v.w, ss);
+        }
+        ss += __shfl_xor(ss, 1, 64);
+        ss += __shfl_xor(ss, 2, 64);
+        ss += __shfl_xor(ss, 4, 64);
+      }
+      if (sub == 0) inv_s[px] = normalize ? 1.0f / fmaxf(sqrtf(ss), 1e-12f) : 1.0f;
+    }
+    // ---- partial logits of this wave's 128 channels: [32 pixels] x [64 clusters]
+    {
+      f32x16_t lg[2];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lg[ct][r] = 0.f;
+      const float* xa = x_s + l31 * NVF_XP + 128 * wave + 4 * kh;
+      const float* wb0 = w + (size_t)l31 * C + 128 * wave + 4 * kh;
+      const float* wb1 = wb0 + (size_t)32 * C;
+#pragma unroll 4
+      for (int j = 0; j < 16; ++j) {
+        const float4 a = *reinterpret_cast<const float4*>(xa + 8 * j);
+        const float4 b0 = *reinterpret_cast<const float4*>(wb0 + 8 * j);
+        const float4 b1 = *reinterpret_cast<const float4*>(wb1 + 8 * j);
+        lg[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, lg[0], 0, 0, 0);
+        lg[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, lg[1], 0, 0, 0);
+        lg[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, lg[0], 0, 0, 0);
+        lg[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, lg[1], 0, 0, 0);
+        lg[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, lg[0], 0, 0, 0);
+        lg[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, lg[1], 0, 0, 0);
+        lg[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, lg[0], 0, 0, 0);
+        lg[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, lg[1], 0, 0, 0);
+      }
+      float* lw = lp_s + wave * 32 * NVF_LP;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lw[acc_row(r, lane) * NVF_LP + 32 * ct + l31] = lg[ct][r];
+    }
+    __syncthreads();
+    // ---- softmax over the 64 clusters: eight threads per pixel, eight clusters each
+    {
+      const int px = (int)threadIdx.x >> 3, sub = (int)threadIdx.x & 7;
+      const float iv = inv_s[px];
+      float l[8], mx = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int o = px * NVF_LP + sub * 8 + k;
+        l[k] = (lp_s[o] + lp_s[32 * NVF_LP + o] + lp_s[2 * 32 * NVF_LP + o] + lp_s[3 * 32 * NVF_LP + o]) * iv;
+        mx = fmaxf(mx, l[k]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+      float ssum = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        l[k] = expf(l[k] - mx);
+        ssum += l[k];
+      }
+      ssum += __shfl_xor(ssum, 1, 64);
+      ssum += __shfl_xor(ssum, 2, 64);
+      ssum += __shfl_xor(ssum, 4, 64);
+      const float is = (p0 + px < p_hi) ? 1.0f / ssum : 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float a = l[k] * is;
+        a_s[px * NVF_LP + sub * 8 + k] = a;
+        a2_s[px * NVF_LP + sub * 8 + k] = a * iv;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+#pragma unroll
+      for (int p = 0; p < 32; ++p) colsum += a_s[p * NVF_LP + threadIdx.x];
+    }
+    // ---- aggregation: acc[k][c] += sum_p (a[p][k] / |x_p|) x[p][c]
+#pragma unroll 2
+    for (int s2 = 0; s2 < 16; ++s2) {
+      const int p = 2 * s2 + kh;
+      const float av0 = a2_s[p * NVF_LP + l31], av1 = a2_s[p * NVF_LP + 32 + l31];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const float bv = x_s[p * NVF_XP + 128 * wave + 32 * ct + l31];
+        acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv, acc[0][ct], 0, 0, 0);
+        acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv, acc[1][ct], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 64) cs_s[threadIdx.x] = colsum;
+  __syncthreads();
+  float* out = parts + ((size_t)slab * gridDim.x + n) * 64 * C;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const int ch = 128 * wave + 32 * ct + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = 32 * kt + acc_row(r, lane);
+        out[(size_t)k * C + ch] = acc[kt][ct][r] - cs_s[k] * centroids[(size_t)k * C + ch];
+      }
+    }
+}
+
+// one workgroup per image: wave v owns cluster rows 16 v .. 16 v + 15, a lane eight elements of a row
+__global__ __launch_bounds__(256) void netvlad_finalize_kernel(const float* __restrict__ parts, int slabs, int N,
+                                                               float* __restrict__ raw, float* __restrict__ out) {
+  constexpr int C = 512;
+  __shared__ float s_part[4];
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float v[16][8], iv[16];
+  float tot = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int k = 16 * wave + i;
+    const size_t off = ((size_t)n * 64 + k) * C + lane * 8;
+    float4 a = *reinterpret_cast<const float4*>(parts + off), b = *reinterpret_cast<const float4*>(parts + off + 4);
+    for (int z = 1; z < slabs; ++z) {      // fixed order
+      const float* pz = parts + (size_t)z * N * 64 * C + off;
+      const float4 a2 = *reinterpret_cast<const float4*>(pz), b2 = *reinterpret_cast<const float4*>(pz + 4);
+      a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
+      b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
+    }
+    v[i][0] = a.x; v[i][1] = a.y; v[i][2] = a.z; v[i][3] = a.w;
+    v[i][4] = b.x; v[i][5] = b.y; v[i][6] = b.z; v[i][7] = b.w;
+    if (raw) {
+      *reinterpret_cast<float4*>(raw + off) = a;
+      *reinterpret_cast<float4*>(raw + off + 4) = b;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s = fmaf(v[i][e], v[i][e], s);
+    s = wave_sum(s);
+    iv[i] = 1.0f / fmaxf(sqrtf(s), 1e-12f);                 // F.normalize(vlad, dim=2)
+    float s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float t = v[i][e] * iv[i];
+      s2 = fmaf(t, t, s2);
+    }
+    tot += wave_sum(s2);
+  }
+  if (!out) return;
+  if (lane == 0) s_part[wave] = tot;
+  __syncthreads();
+  const float ginv = 1.0f / fmaxf(sqrtf(s_part[0] + s_part[1] + s_part[2] + s_part[3]), 1e-12f);   // dim=1 of the flat vector
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const size_t off = ((size_t)n * 64 + 16 * wave + i) * C + lane * 8;
+    const float sc = iv[i] * ginv;
+    *reinterpret_cast<float4*>(out + off) = make_float4(v[i][0] * sc, v[i][1] * sc, v[i][2] * sc, v[i][3] * sc);
+    *reinterpret_cast<float4*>(out + off + 4) = make_float4(v[i][4] * sc, v[i][5] * sc, v[i][6] * sc, v[i][7] * sc);
+  }
+}
+
 }  // namespace oibl
 
 using namespace oibl;
 
-OIBL_HOOK(int, g_nv_slabs, 1);   // test hook: 0 = never split the aggregation over the pixels
+OIBL_HOOK(int, g_nv_slabs, 1);   // test hook: 1 = default (fp32 maps: the fused kernel; bf16 maps: five launches, the
+                                 // aggregation split over the pixels for few images), 0 = five launches, never split,
+                                 // 2 = five launches with the pixel split for fp32 maps too
 
 extern "C" {
 
@@ -293,10 +527,15 @@ static size_t nv_off_parts(int N, int P, int K, int C) {
   return nv_off_stats(N, P, K, C) + align_up((size_t)N * K * 2 * sizeof(float), 256);
 }
 
+// the fused kernel's slabs: 160 pixels for N >= 5, 32 for fewer images (by N alone within each range)
+static int nvf_slab_px(int N) { return N >= 5 ? 160 : 32; }
+static int nvf_slabs(int N, int P) { return (P + nvf_slab_px(N) - 1) / nvf_slab_px(N); }
+
 size_t oibl_netvlad_workspace_bytes(int N, int P, int K, int C) {
   if (N <= 0 || P <= 0 || K <= 0 || C <= 0) return 0;
-  const int slabs = nv_pixel_slabs(N, P);
-  return nv_off_parts(N, P, K, C) + (slabs > 1 ? align_up((size_t)slabs * N * K * C * sizeof(float), 256) : 0);
+  int slabs = nv_pixel_slabs(N, P);
+  if (nvf_slabs(N, P) > slabs) slabs = nvf_slabs(N, P);
+  return nv_off_parts(N, P, K, C) + align_up((size_t)slabs * N * K * C * sizeof(float), 256);
 }
 
 int oibl_netvlad_forward(const void* feat, int N, int P, int K, int C, int precision,
@@ -324,6 +563,19 @@ int oibl_netvlad_forward(const void* feat, int N, int P, int K, int C, int preci
   float* raw = vlad_raw ? vlad_raw : (float*)(wsb + nv_off_raw(N, P));
   void* w_t = wsb + nv_off_w(N, P, K, C);
   const long rows = (long)N * P;
+  if (precision == OIBL_F32 && g_nv_slabs == 1 && C == 512 && (uintptr_t)assign_w % 16 == 0) {
+    // the fused layer: two launches, the map read once (netvlad_fused_kernel)
+    const int spx = nvf_slab_px(N), ns = nvf_slabs(N, P);
+    float* parts = (float*)(wsb + nv_off_parts(N, P, K, C));
+    OIBL_SET_MAX_LDS(netvlad_fused_kernel, NVF_LDS);
+    hipLaunchKernelGGL(netvlad_fused_kernel, dim3((unsigned)N, (unsigned)ns), dim3(256), NVF_LDS, st, (const float*)feat,
+                       assign_w, centroids, parts, P, spx, normalize_input);
+    OIBL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(netvlad_finalize_kernel, dim3((unsigned)N), dim3(256), 0, st, (const float*)parts, ns, N, vlad_raw,
+                       vlad_norm);
+    OIBL_LAUNCH_CHECK();
+    return OIBL_OK;
+  }
   // few images: the aggregation is split over the pixels (only when the normalised output is wanted: the
   // kernel that normalises is the one that adds the slabs)
   const int slabs = (vlad_norm && g_nv_slabs) ? nv_pixel_slabs(N, P) : 1;
@@ -382,7 +634,7 @@ int oibl_netvlad_forward(const void* feat, int N, int P, int K, int C, int preci
 
 #ifdef OIBL_DEBUG_HOOKS
 int oibl_debug_set_netvlad_slabs(int on) {
-  g_nv_slabs = on ? 1 : 0;
+  g_nv_slabs = on < 0 ? 0 : (on > 2 ? 2 : on);
   return OIBL_OK;
 }
 #endif

@@ -221,7 +221,8 @@ def test_hot_kernels_stay_inside_their_register_budgets():
     for name, u in usage.items():
         scratch, vgprs = u.get("ScratchSize", 0), u.get("VGPRs", 0) + u.get("AGPRs", 0)
         if any(k in name for k in ("conv3x3_ring_kernel", "pairwise_ring_kernel", "vgg_stem_kernel",
-                                   "conv3x3_halo_kernel", "pca_small_kernel")):
+                                   "conv3x3_halo_kernel", "conv3x3_halo4_kernel", "pairwise_f16r_kernel",
+                                   "pca_small_kernel")):
             assert scratch == 0 and vgprs <= 256, (name, u)
             seen.add(re.sub(r"I.*", "", name))
         elif "vgg_stem_x3_kernel" in name:
@@ -262,6 +263,12 @@ def test_hot_kernels_hold_exactly_their_matrix_instructions():
             assert t["bytes"] < 64 * 1024, (name, t)          # the instruction cache two CUs share
             ring += 1
     assert ring >= 40
+    # the 4-wave halo kernel of the 128-output-channel layers: 18 K-tiles x 4 phases x 6, one body; the fp16 filter
+    # pass of the f16r top-k: the bf16 ring loop (16 phases x 8) per stagger-group body
+    halo4 = {n: t for n, t in text.items() if "conv3x3_halo4_kernel" in n and not n.endswith(".kd")}
+    assert len(halo4) == 2 and all(t["mfma"] == 432 and t["bytes"] < 64 * 1024 for t in halo4.values()), halo4
+    f16r = {n: t for n, t in text.items() if "pairwise_f16r_kernel" in n and not n.endswith(".kd")}
+    assert len(f16r) == 4 and all(t["mfma"] == (256 if re.search(r"ELb1EEE", n) else 128) for n, t in f16r.items()), f16r
     halo = {n: t for n, t in text.items() if "conv3x3_halo_kernel" in n and not n.endswith(".kd")}
     assert halo and all(t["mfma"] == (864 if re.search(r"ELb1EEE", n) else 432) for n, t in halo.items()), halo
     stems = {n: t["mfma"] for n, t in text.items() if "vgg_stem" in n and not n.endswith(".kd")}
