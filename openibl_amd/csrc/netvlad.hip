@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void netvlad_apply_kernel(const float* __restr
 // ---------------------------------------------------------------------------------------------
 // The FUSED NetVLAD layer (fp32 feature map: the head of the fp32 / bf16x3 / f16mx arithmetics) — north_star's
 // "soft-assignment softmax, residual accumulation and intra-/L2-norm as a fused kernel with coalesced reads of the
-// H x W x 512 feature map" (ibl/models/netvlad.py:44-61, 100-102), two launches instead of five, the map read ONCE:
+// H x W x 512 feature map" (ibl/models/netvlad.py:44-61, 100-102), three launches instead of five, the map read ONCE:
 //
 //   netvlad_fused_kernel     one workgroup per (image, slab of pixels).  Per chunk of 32 pixels: the chunk's 32 x
 //                            512 values go to LDS with coalesced 16-byte loads (64.5 KB, rows 4 floats apart in the
@@ -280,12 +280,16 @@ __global__ __launch_bounds__(256) void netvlad_apply_kernel(const float* __restr
 //                            sum_p a[p][k] / |x_p| * x[p][c] on the same instruction from the same LDS chunk, 64
 //                            clusters x 128 channels of accumulators per wave (128 VGPRs), kept across the slab's
 //                            chunks; at the end acc - (sum_p a[p][k]) centroids[k][c] -> parts[slab][n][k][c].
-//   netvlad_finalize_kernel  one workgroup per image: adds the slabs in slab order, intra-normalises the 64 cluster
-//                            rows, L2-normalises the 32768-vector (netvlad.py:100-102), writes raw and / or
-//                            normalised outputs.
-// Slab = 160 pixels (N >= 5: 8 slabs of a 30 x 40 map, 256 workgroups at batch 32) or 32 pixels (N <= 4: the chip
-// would idle otherwise) — chosen by N ALONE within each range, so a row's result does not depend on its batch mates
-// within a range.  Exact fp32 throughout; against the five-launch path (hook) the sums differ by association only.
+//                            The assignment weights of a wave's channels live in 128 registers for the whole slab,
+//                            the next chunk is prefetched into registers under the current one's matrix work.
+//   netvlad_rowstats_kernel  adds the slabs in slab order, one wave per (image, cluster) row, + the row statistics;
+//   netvlad_apply_kernel     intra-norm + L2 over the 32768-vector (netvlad.py:100-102) — the two normalising
+//                            launches of the five-launch path (a single-workgroup-per-image finalize was tried:
+//                            132 us at batch 32 against 112 for five launches — its serial slab sums — and dropped).
+// Three launches, the map read ONCE (five launches: three times).  Slab = 160 pixels: 8 slabs of a 30 x 40 map, 256
+// workgroups at batch 32.  Batches of up to four images keep the five-launch path with its 4-slab aggregation (51 us
+// for one image; the fused kernel's 38 one-chunk workgroups + a 38-slab sum were slower).  Exact fp32 throughout;
+// against the five-launch path the sums differ by association only.
 constexpr int NVF_XP = 516;          // floats per LDS row of the chunk: 16-byte aligned, +4 banks per pixel
 constexpr int NVF_LP = 65;           // pitch of the [32][64] logit / assignment tiles
 constexpr int NVF_LDS = (32 * NVF_XP + 4 * 32 * NVF_LP + 2 * 32 * NVF_LP + 32 + 64) * 4;
@@ -319,18 +323,39 @@ __global__ __launch_bounds__(256) void netvlad_fused_kernel(const float* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[kt][ct][r] = 0.f;
   float colsum = 0.f;          // threads 0..63
-
-  for (int p0 = p_lo; p0 < p_hi; p0 += 32) {
-    // ---- the chunk -> LDS (a pixel beyond the slab reads as zeros: it then gets a = 0 below)
+  // the assignment weights of this wave's 128 channels stay in registers for the whole slab (128 VGPRs: the kernel
+  // runs one wave per SIMD): lane (cluster l31 / 32 + l31, k half kh) holds w[cluster][128 wave + 8 j + 4 kh ..+3]
+  float4 wr[2][16];
+  {
+    const float* wb = w + (size_t)l31 * C + 128 * wave + 4 * kh;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      wr[0][j] = *reinterpret_cast<const float4*>(wb + 8 * j);
+      wr[1][j] = *reinterpret_cast<const float4*>(wb + (size_t)32 * C + 8 * j);
+    }
+  }
+  // register prefetch of the NEXT chunk (one workgroup per CU has nothing else to hide the load latency behind)
+  float4 pf[16];
+  auto prefetch = [&](int p0) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int idx = (int)threadIdx.x + 256 * q;          // float4 index inside the chunk
       const int px = idx >> 7, c4 = (idx & 127) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p0 + px < p_hi) v = *reinterpret_cast<const float4*>(fimg + (size_t)(p0 + px) * C + c4);
-      *reinterpret_cast<float4*>(x_s + px * NVF_XP + c4) = v;
+      pf[q] = make_float4(0.f, 0.f, 0.f, 0.f);             // a pixel beyond the slab reads as zeros (a = 0 below)
+      if (p0 + px < p_hi) pf[q] = *reinterpret_cast<const float4*>(fimg + (size_t)(p0 + px) * C + c4);
+    }
+  };
+  prefetch(p_lo);
+
+  for (int p0 = p_lo; p0 < p_hi; p0 += 32) {
+    // ---- the chunk -> LDS
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int idx = (int)threadIdx.x + 256 * q;
+      *reinterpret_cast<float4*>(x_s + (idx >> 7) * NVF_XP + (idx & 127) * 4) = pf[q];
     }
     __syncthreads();
+    if (p0 + 32 < p_hi) prefetch(p0 + 32);
     // ---- 1 / |x_p|: eight threads per pixel, interleaved float4s
     {
       const int px = (int)threadIdx.x >> 3, sub = (int)threadIdx.x & 7;
@@ -358,13 +383,10 @@ __global__ __launch_bounds__(256) void netvlad_fused_kernel(const float* __restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) lg[ct][r] = 0.f;
       const float* xa = x_s + l31 * NVF_XP + 128 * wave + 4 * kh;
-      const float* wb0 = w + (size_t)l31 * C + 128 * wave + 4 * kh;
-      const float* wb1 = wb0 + (size_t)32 * C;
-#pragma unroll 4
+#pragma unroll
       for (int j = 0; j < 16; ++j) {
         const float4 a = *reinterpret_cast<const float4*>(xa + 8 * j);
-        const float4 b0 = *reinterpret_cast<const float4*>(wb0 + 8 * j);
-        const float4 b1 = *reinterpret_cast<const float4*>(wb1 + 8 * j);
+        const float4 b0 = wr[0][j], b1 = wr[1][j];
         lg[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, lg[0], 0, 0, 0);
         lg[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, lg[1], 0, 0, 0);
         lg[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, lg[0], 0, 0, 0);
@@ -447,57 +469,6 @@ __global__ __launch_bounds__(256) void netvlad_fused_kernel(const float* __restr
     }
 }
 
-// one workgroup per image: wave v owns cluster rows 16 v .. 16 v + 15, a lane eight elements of a row
-__global__ __launch_bounds__(256) void netvlad_finalize_kernel(const float* __restrict__ parts, int slabs, int N,
-                                                               float* __restrict__ raw, float* __restrict__ out) {
-  constexpr int C = 512;
-  __shared__ float s_part[4];
-  const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float v[16][8], iv[16];
-  float tot = 0.f;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int k = 16 * wave + i;
-    const size_t off = ((size_t)n * 64 + k) * C + lane * 8;
-    float4 a = *reinterpret_cast<const float4*>(parts + off), b = *reinterpret_cast<const float4*>(parts + off + 4);
-    for (int z = 1; z < slabs; ++z) {      // fixed order
-      const float* pz = parts + (size_t)z * N * 64 * C + off;
-      const float4 a2 = *reinterpret_cast<const float4*>(pz), b2 = *reinterpret_cast<const float4*>(pz + 4);
-      a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
-      b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
-    }
-    v[i][0] = a.x; v[i][1] = a.y; v[i][2] = a.z; v[i][3] = a.w;
-    v[i][4] = b.x; v[i][5] = b.y; v[i][6] = b.z; v[i][7] = b.w;
-    if (raw) {
-      *reinterpret_cast<float4*>(raw + off) = a;
-      *reinterpret_cast<float4*>(raw + off + 4) = b;
-    }
-    float s = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s = fmaf(v[i][e], v[i][e], s);
-    s = wave_sum(s);
-    iv[i] = 1.0f / fmaxf(sqrtf(s), 1e-12f);                 // F.normalize(vlad, dim=2)
-    float s2 = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float t = v[i][e] * iv[i];
-      s2 = fmaf(t, t, s2);
-    }
-    tot += wave_sum(s2);
-  }
-  if (!out) return;
-  if (lane == 0) s_part[wave] = tot;
-  __syncthreads();
-  const float ginv = 1.0f / fmaxf(sqrtf(s_part[0] + s_part[1] + s_part[2] + s_part[3]), 1e-12f);   // dim=1 of the flat vector
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const size_t off = ((size_t)n * 64 + 16 * wave + i) * C + lane * 8;
-    const float sc = iv[i] * ginv;
-    *reinterpret_cast<float4*>(out + off) = make_float4(v[i][0] * sc, v[i][1] * sc, v[i][2] * sc, v[i][3] * sc);
-    *reinterpret_cast<float4*>(out + off + 4) = make_float4(v[i][4] * sc, v[i][5] * sc, v[i][6] * sc, v[i][7] * sc);
-  }
-}
-
 }  // namespace oibl
 
 using namespace oibl;
@@ -527,14 +498,14 @@ static size_t nv_off_parts(int N, int P, int K, int C) {
   return nv_off_stats(N, P, K, C) + align_up((size_t)N * K * 2 * sizeof(float), 256);
 }
 
-// the fused kernel's slabs: 160 pixels for N >= 5, 32 for fewer images (by N alone within each range)
-static int nvf_slab_px(int N) { return N >= 5 ? 160 : 32; }
-static int nvf_slabs(int N, int P) { return (P + nvf_slab_px(N) - 1) / nvf_slab_px(N); }
+// the fused kernel's slabs: 160 pixels; it serves batches of five images and more
+constexpr int NVF_SLAB_PX = 160, NVF_MIN_N = 5;
+static int nvf_slabs(int P) { return (P + NVF_SLAB_PX - 1) / NVF_SLAB_PX; }
 
 size_t oibl_netvlad_workspace_bytes(int N, int P, int K, int C) {
   if (N <= 0 || P <= 0 || K <= 0 || C <= 0) return 0;
   int slabs = nv_pixel_slabs(N, P);
-  if (nvf_slabs(N, P) > slabs) slabs = nvf_slabs(N, P);
+  if (N >= NVF_MIN_N && nvf_slabs(P) > slabs) slabs = nvf_slabs(P);
   return nv_off_parts(N, P, K, C) + align_up((size_t)slabs * N * K * C * sizeof(float), 256);
 }
 
@@ -563,17 +534,24 @@ int oibl_netvlad_forward(const void* feat, int N, int P, int K, int C, int preci
   float* raw = vlad_raw ? vlad_raw : (float*)(wsb + nv_off_raw(N, P));
   void* w_t = wsb + nv_off_w(N, P, K, C);
   const long rows = (long)N * P;
-  if (precision == OIBL_F32 && g_nv_slabs == 1 && C == 512 && (uintptr_t)assign_w % 16 == 0) {
-    // the fused layer: two launches, the map read once (netvlad_fused_kernel)
-    const int spx = nvf_slab_px(N), ns = nvf_slabs(N, P);
-    float* parts = (float*)(wsb + nv_off_parts(N, P, K, C));
+  if (precision == OIBL_F32 && g_nv_slabs == 1 && C == 512 && N >= NVF_MIN_N && (uintptr_t)assign_w % 16 == 0) {
+    // the fused layer: the map read once (netvlad_fused_kernel), then the slab sum + the two normalising launches
+    const int ns = nvf_slabs(P);
+    float* parts = ns > 1 ? (float*)(wsb + nv_off_parts(N, P, K, C)) : raw;   // (one slab: it IS the raw output)
     OIBL_SET_MAX_LDS(netvlad_fused_kernel, NVF_LDS);
     hipLaunchKernelGGL(netvlad_fused_kernel, dim3((unsigned)N, (unsigned)ns), dim3(256), NVF_LDS, st, (const float*)feat,
-                       assign_w, centroids, parts, P, spx, normalize_input);
+                       assign_w, centroids, parts, P, NVF_SLAB_PX, normalize_input);
     OIBL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(netvlad_finalize_kernel, dim3((unsigned)N), dim3(256), 0, st, (const float*)parts, ns, N, vlad_raw,
-                       vlad_norm);
+    float* stats = (float*)(wsb + nv_off_stats(N, P, K, C));
+    const long vrows = (long)N * K;
+    const unsigned fgrid = (unsigned)((vrows + 3) / 4);
+    hipLaunchKernelGGL(netvlad_rowstats_kernel, dim3(fgrid), dim3(256), 0, st, raw, (const float*)parts, ns, stats,
+                       vrows, C);
     OIBL_LAUNCH_CHECK();
+    if (vlad_norm) {
+      hipLaunchKernelGGL(netvlad_apply_kernel, dim3(fgrid), dim3(256), 0, st, raw, stats, vlad_norm, vrows, K, C);
+      OIBL_LAUNCH_CHECK();
+    }
     return OIBL_OK;
   }
   // few images: the aggregation is split over the pixels (only when the normalised output is wanted: the

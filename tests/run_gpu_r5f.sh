@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, call E: the fused NetVLAD layer (parity + timing)
 cd "$(dirname "$0")/.."
-R=$(pwd); OUT=$R/gpurun_out/r5e; mkdir -p $OUT
+R=$(pwd); OUT=$R/gpurun_out/r5f; mkdir -p $OUT
 export PYTHONDONTWRITEBYTECODE=1
 timeout 900 python -m pytest tests/test_gpu_netvlad_pca.py tests/test_gpu_descriptor.py tests/test_gpu_api.py -q --tb=short --timeout 600 -p no:cacheprovider > $OUT/pytest.log 2>&1
 echo "pytest exit $?" | tee -a $OUT/pytest.log
