@@ -287,9 +287,10 @@ __global__ __launch_bounds__(256) void netvlad_apply_kernel(const float* __restr
 //                            launches of the five-launch path (a single-workgroup-per-image finalize was tried:
 //                            132 us at batch 32 against 112 for five launches — its serial slab sums — and dropped).
 // Three launches, the map read ONCE (five launches: three times).  Slab = 160 pixels: 8 slabs of a 30 x 40 map, 256
-// workgroups at batch 32.  Batches of up to four images keep the five-launch path with its 4-slab aggregation (51 us
-// for one image; the fused kernel's 38 one-chunk workgroups + a 38-slab sum were slower).  Exact fp32 throughout;
-// against the five-launch path the sums differ by association only.
+// workgroups at batch 32: 97 us against 112 (the kernel's phases — norms, logits, softmax, aggregation — are
+// serialised by workgroup barriers with one workgroup per CU: ~45 % of its time is on the matrix pipe).  Batches
+// below 16 images keep the five-launch path (79 against 86 us at batch 8; 51 us for one image with its 4-slab
+// aggregation).  Exact fp32 throughout; against the five-launch path the sums differ by association only.
 constexpr int NVF_XP = 516;          // floats per LDS row of the chunk: 16-byte aligned, +4 banks per pixel
 constexpr int NVF_LP = 65;           // pitch of the [32][64] logit / assignment tiles
 constexpr int NVF_LDS = (32 * NVF_XP + 4 * 32 * NVF_LP + 2 * 32 * NVF_LP + 32 + 64) * 4;
@@ -498,8 +499,9 @@ static size_t nv_off_parts(int N, int P, int K, int C) {
   return nv_off_stats(N, P, K, C) + align_up((size_t)N * K * 2 * sizeof(float), 256);
 }
 
-// the fused kernel's slabs: 160 pixels; it serves batches of five images and more
-constexpr int NVF_SLAB_PX = 160, NVF_MIN_N = 5;
+// the fused kernel's slabs: 160 pixels; it serves batches of 16 images and more (8 slabs of a 30 x 40 map: from 128
+// workgroups on; measured 97 against 112 us for five launches at batch 32, 86 against 79 at batch 8)
+constexpr int NVF_SLAB_PX = 160, NVF_MIN_N = 16;
 static int nvf_slabs(int P) { return (P + NVF_SLAB_PX - 1) / NVF_SLAB_PX; }
 
 size_t oibl_netvlad_workspace_bytes(int N, int P, int K, int C) {

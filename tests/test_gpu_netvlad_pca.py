@@ -109,10 +109,7 @@ def test_netvlad_pixel_slabs_for_few_images(dev, precision):
     assert_rel_l2("slabs vs whole, raw", outs[4][0].cpu(), whole[4][0].cpu(), 2e-6)
     assert_rel_l2("slabs vs whole, normalised", outs[4][1].cpu(), whole[4][1].cpu(), 2e-6)
     assert not torch.equal(outs[4][0], whole[4][0])
-    if precision == "bf16":      # five images: the same unsplit kernels either way
-        assert torch.equal(outs[5][0], whole[5][0]) and torch.equal(outs[5][1], whole[5][1])
-    else:                        # fp32 maps of five images take the fused layer (next test)
-        assert_rel_l2("fused vs whole, N=5", outs[5][1].cpu(), whole[5][1].cpu(), 3e-6)
+    assert torch.equal(outs[5][0], whole[5][0]) and torch.equal(outs[5][1], whole[5][1])   # (five images: unsplit)
     for n in (1, 2):
         assert torch.equal(outs[n][0], outs[4][0][:n]) and torch.equal(outs[n][1], outs[4][1][:n])
     only_norm = ops.netvlad(feat[:2].contiguous(), cw, cent, True, want_raw=False, want_norm=True)[1]
@@ -123,7 +120,7 @@ def test_netvlad_pixel_slabs_for_few_images(dev, precision):
 
 @pytest.mark.parametrize("normalize_input", [True, False])
 def test_netvlad_fused_kernel_against_the_five_launch_path(dev, normalize_input):
-    """fp32 feature maps of five images and more take the fused layer (netvlad_fused_kernel: norm + soft-assignment +
+    """fp32 feature maps of 16 images and more take the fused layer (netvlad_fused_kernel: norm + soft-assignment +
     softmax + aggregation in one kernel, the map read once; then the slab sum and the two normalising launches).
     Against the five-launch path it replaces (hooks 0 / 2) the sums differ by association only; a row's result does
     not depend on its batch mates; raw-only and normalised-only calls give the same bits as the call that asks for
@@ -132,26 +129,26 @@ def test_netvlad_fused_kernel_against_the_five_launch_path(dev, normalize_input)
     sd = synth.netvlad_state(0)
     cw, cent = sd["net_vlad.conv.weight"].reshape(64, 512).contiguous().to(dev), sd["net_vlad.centroids"].to(dev)
     for (h, w_) in ((30, 37), (9, 11)):                                              # P = 1110: ragged last slab; P = 99: one slab
-        f = _feat(9, h, w_, seed=12 + h)
+        f = _feat(20, h, w_, seed=12 + h)
         if not normalize_input:
             f = f * 0.05
         feat = ops.nchw_f32_to_nhwc(f.to(dev), "fp32")
         outs = {n: ops.netvlad(feat[:n].contiguous(), cw, cent, normalize_input, want_raw=True, want_norm=True)
-                for n in (5, 7, 9)}
+                for n in (16, 18, 20)}
         for hook in (0, 2):
             lib.debug_hooks().oibl_debug_set_netvlad_slabs(hook)
             try:
-                old = ops.netvlad(feat[:7].contiguous(), cw, cent, normalize_input, want_raw=True, want_norm=True)
+                old = ops.netvlad(feat[:18].contiguous(), cw, cent, normalize_input, want_raw=True, want_norm=True)
             finally:
                 lib.debug_hooks().oibl_debug_set_netvlad_slabs(1)
-            assert_rel_l2(f"fused vs five launches (hook {hook}), raw", outs[7][0].cpu(), old[0].cpu(), 3e-6)
-            assert_rel_l2(f"fused vs five launches (hook {hook}), normalised", outs[7][1].cpu(), old[1].cpu(), 3e-6)
-            assert not torch.equal(outs[7][0], old[0])                                # (the hook did select the other path)
-        assert torch.equal(outs[5][0], outs[9][0][:5]) and torch.equal(outs[5][1], outs[9][1][:5])
-        assert torch.equal(outs[7][0], outs[9][0][:7]) and torch.equal(outs[7][1], outs[9][1][:7])
-        only_norm = ops.netvlad(feat[:5].contiguous(), cw, cent, normalize_input, want_raw=False, want_norm=True)[1]
-        only_raw = ops.netvlad(feat[:5].contiguous(), cw, cent, normalize_input, want_raw=True, want_norm=False)[0]
-        assert torch.equal(only_norm, outs[5][1]) and torch.equal(only_raw, outs[5][0])
+            assert_rel_l2(f"fused vs five launches (hook {hook}), raw", outs[18][0].cpu(), old[0].cpu(), 3e-6)
+            assert_rel_l2(f"fused vs five launches (hook {hook}), normalised", outs[18][1].cpu(), old[1].cpu(), 3e-6)
+            assert not torch.equal(outs[18][0], old[0])                               # (the hook did select the other path)
+        assert torch.equal(outs[16][0], outs[20][0][:16]) and torch.equal(outs[16][1], outs[20][1][:16])
+        assert torch.equal(outs[18][0], outs[20][0][:18]) and torch.equal(outs[18][1], outs[20][1][:18])
+        only_norm = ops.netvlad(feat[:16].contiguous(), cw, cent, normalize_input, want_raw=False, want_norm=True)[1]
+        only_raw = ops.netvlad(feat[:16].contiguous(), cw, cent, normalize_input, want_raw=True, want_norm=False)[0]
+        assert torch.equal(only_norm, outs[16][1]) and torch.equal(only_raw, outs[16][0])
         want = od.netvlad(f.double(), sd["net_vlad.conv.weight"].double(), sd["net_vlad.centroids"].double(), normalize_input)
-        assert_rel_l2("fused raw vs the fp64 oracle", outs[9][0].cpu(), want, 5e-6)
-        assert_rel_l2("fused normalised vs the fp64 oracle", outs[9][1].cpu(), od.normalize_vlad(want), 5e-6)
+        assert_rel_l2("fused raw vs the fp64 oracle", outs[20][0].cpu(), want, 5e-6)
+        assert_rel_l2("fused normalised vs the fp64 oracle", outs[20][1].cpu(), od.normalize_vlad(want), 5e-6)
