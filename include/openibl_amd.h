@@ -381,6 +381,33 @@ int oibl_sqdist_topk_prepared(const void* xo, const float* xn, int m, const void
  *       run fp32 distance tiles + oibl_row_topk on the fp32 rows (what OIBL_F32 runs).                      */
 int oibl_match_prepare_f16r(const float* x, int rows, int d, float* norms, float* aux, void* rows_f16,
                             void* stream);
+/* The two stages of oibl_sqdist_topk_f16r on their own — for a caller that puts something between them: gallery-
+ * sharded matching exchanges the FILTER lists first, takes the threshold from all shards' lists, and lets every rank
+ * rescore only its members of the GLOBAL rescore set (openibl_amd/sharded.py: the rescoring work then divides by the
+ * number of ranks instead of being repeated on each).
+ *   oibl_f16r_members(k)        member slots per query: K2 = 32 (k <= 16), 2k + 32 otherwise
+ *   oibl_f16r_fused(m, n, d, k) 1 when the problem takes the fused path (else only oibl_sqdist_topk_f16r serves it)
+ *   oibl_f16r_filter_select     stage 1 -> lval / lidx [m][K2]: filter distances and global indices of the candidates
+ *       that can belong to the top-k of this gallery (any order; (+inf, -1) paddings); ymax_out (device, 2 floats, may
+ *       be NULL): the gallery's largest |y| and largest fp16 residual norm — the pair bound of a query row i towards
+ *       ANY row of it is eps_i = A_i ymax[0] + B_i ymax[1] + 1e-6 (|x_i|^2 + ymax[0]^2), A_i = 2 (r_i + g (n_i +
+ *       r_i)), B_i = 2 (n_i + r_i)(1 + g), (n_i, r_i) = aux[i][1], aux[i][2], g = d 2^-24.  Workspace as
+ *       oibl_sqdist_topk_f16r.
+ *   oibl_f16r_rescore           stage 2: exact distances of the members listed in lidx [m][K2] (-1 = none), the k
+ *       smallest (distance, index) per query, (+inf, -1) beyond the member count.                              */
+int oibl_f16r_members(int k);
+int oibl_f16r_fused(int m, int n, int d, int k);
+int oibl_f16r_filter_select(const void* xh, const float* xaux, const float* xn, int m, const void* yh,
+                            const float* yaux, const float* yn, int n, int d, int k, int index_base, float* lval,
+                            int32_t* lidx, float* ymax_out, int32_t* overflow, void* ws, size_t ws_bytes,
+                            void* stream);
+int oibl_f16r_rescore(const float* xsrc, const float* xn, int m, const float* ysrc, const float* yn, int d, int k,
+                      int index_base, const int32_t* lidx, float* out_val, int32_t* out_idx, void* stream);
+/* Between the stages, sharded: thr [m] (device) = the k-th smallest filter distance over the lists of ALL shards,
+ * ymax_all [shards][2] (device) = every shard's ymax_out; entries of lidx [m][K2] whose lval exceeds thr + 2 eps (eps
+ * from the maxima over all shards) are set to -1. */
+int oibl_f16r_keep_members(const float* lval, int32_t* lidx, int m, int k, const float* thr, const float* xn,
+                           const float* xaux, const float* ymax_all, int shards, int d, void* stream);
 size_t oibl_sqdist_topk_f16r_workspace_bytes(int m, int n, int d, int k);
 int oibl_sqdist_topk_f16r(const void* xh, const float* xaux, const float* xn, const float* xsrc, int m,
                           const void* yh, const float* yaux, const float* yn, const float* ysrc, int n, int d,

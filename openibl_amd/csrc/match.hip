@@ -1425,31 +1425,37 @@ static int launch_pairwise_f16r(F16rParams& p, hipStream_t st, int ksplit = 1) {
 }
 }  // extern "C++"
 
-int oibl_sqdist_topk_f16r(const void* xh, const float* xaux, const float* xn, const float* xsrc, int m,
-                          const void* yh, const float* yaux, const float* yn, const float* ysrc, int n, int d,
-                          int k, int index_base, int exact, float* out_val, int32_t* out_idx, int32_t* overflow,
-                          void* ws, size_t ws_bytes, void* stream) {
-  OIBL_REQUIRE(xh && xaux && xn && xsrc && yh && yaux && yn && ysrc && out_val && out_idx && ws,
-               "sqdist_topk_f16r: null pointer");
+// K2 of a k (the member slots per query) and whether (m, n, d, k) takes the fused path — what a caller that runs the
+// two stages itself (sharded matching: the rescoring behind the exchange of the filter lists) has to know
+int oibl_f16r_members(int k) { return k >= 1 ? f16r_k2(k) : 0; }
+int oibl_f16r_fused(int m, int n, int d, int k) {
+  if (m <= 0 || n <= 0 || d <= 0 || d % 64 != 0 || k <= 0) return 0;
+  return f16r_plan(m, n, d, k).fused ? 1 : 0;
+}
+
+// stage 1: thresholds, filter pass, selection -> lval / lidx [m][K2]: the candidates that can belong to the top-k of
+// THIS gallery (filter distances + global indices, any order, (+inf, -1) paddings); ymax_out [2] (device, may be
+// NULL) = the largest |y| and |y - yh 2^-e| of the gallery (what the pair bound of a wider selection needs)
+int oibl_f16r_filter_select(const void* xh, const float* xaux, const float* xn, int m, const void* yh,
+                            const float* yaux, const float* yn, int n, int d, int k, int index_base, float* lval,
+                            int32_t* lidx, float* ymax_out, int32_t* overflow, void* ws, size_t ws_bytes,
+                            void* stream) {
+  OIBL_REQUIRE(xh && xaux && xn && yh && yaux && yn && lval && lidx && ws, "f16r_filter_select: null pointer");
   int rc = topk_args_ok(m, n, d, k, index_base, OIBL_F32);
   if (rc) return rc;
   OIBL_REQUIRE((uintptr_t)ws % 256 == 0 && (uintptr_t)xh % 16 == 0 && (uintptr_t)yh % 16 == 0 &&
-                   (uintptr_t)xsrc % 16 == 0 && (uintptr_t)ysrc % 16 == 0 && (uintptr_t)xaux % 16 == 0 &&
-                   (uintptr_t)yaux % 16 == 0,
-               "sqdist_topk_f16r: workspace must be 256-byte, rows and aux 16-byte aligned");
+                   (uintptr_t)xaux % 16 == 0 && (uintptr_t)yaux % 16 == 0,
+               "f16r_filter_select: workspace must be 256-byte, rows and aux 16-byte aligned");
   const F16rPlan f = f16r_plan(m, n, d, k);
+  OIBL_REQUIRE(f.fused, "f16r_filter_select: (m=%d, n=%d, d=%d, k=%d) does not take the fused path (oibl_f16r_fused)", m, n,
+               d, k);
   if (ws_bytes < f.total) {
-    set_error("sqdist_topk_f16r: workspace %zu < required %zu bytes", ws_bytes, f.total);
+    set_error("f16r_filter_select: workspace %zu < required %zu bytes", ws_bytes, f.total);
     return OIBL_E_WORKSPACE;
   }
   char* wsb = (char*)ws;
   hipStream_t st = (hipStream_t)stream;
   const TopkPlan& t = f.t;
-  if (!f.fused || exact) {
-    // the exact path: fp32 distance tiles of the resident fp32 rows + row_topk (what OIBL_F32 runs)
-    return sqdist_topk_core(xsrc, xn, m, ysrc, yn, n, d, k, index_base, OIBL_F32, 1, out_val, out_idx, overflow, wsb,
-                            t, st);
-  }
   if (overflow) OIBL_HIP_CHECK(hipMemsetAsync(overflow, 0, sizeof(int32_t), st));
   float* sample = (float*)(wsb + t.off_sample);
   float* sval = (float*)(wsb + t.off_sval);
@@ -1501,8 +1507,6 @@ int oibl_sqdist_topk_f16r(const void* xh, const float* xaux, const float* xn, co
   if (rc) return rc;
   // 3. the members of every query's rescore set (a list beyond the window / capacity, or more than K2 members,
   //    raises *overflow)
-  float* lval = (float*)(wsb + f.off_lval);
-  int32_t* lidx = (int32_t*)(wsb + f.off_lidx);
   hipLaunchKernelGGL((f16r_select_kernel<32, false>), dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, q.cand_val,
                      q.cand_idx, cnt, m, t.cap, k, f.K2, 2048, xn, (const float4*)xaux, ymax, q.gamma, lval, lidx,
                      (int*)overflow);
@@ -1511,7 +1515,18 @@ int oibl_sqdist_topk_f16r(const void* xh, const float* xaux, const float* xn, co
   hipLaunchKernelGGL((f16r_select_kernel<32, true>), dim3((unsigned)m), dim3(256), 0, st, q.cand_val, q.cand_idx, cnt,
                      m, t.cap, k, f.K2, 2048, xn, (const float4*)xaux, ymax, q.gamma, lval, lidx, (int*)overflow);
   OIBL_LAUNCH_CHECK();
-  // 4. exact distances of the members, final selection
+  if (ymax_out) OIBL_HIP_CHECK(hipMemcpyAsync(ymax_out, ymax + 2, 8, hipMemcpyDeviceToDevice, st));
+  return OIBL_OK;
+}
+
+// stage 2: exact distances (fp64-accumulated, from the fp32 rows) of the listed members lidx [m][K2] (global indices
+// of THIS gallery, -1 = no member), the k smallest (distance, index) per query
+int oibl_f16r_rescore(const float* xsrc, const float* xn, int m, const float* ysrc, const float* yn, int d, int k,
+                      int index_base, const int32_t* lidx, float* out_val, int32_t* out_idx, void* stream) {
+  OIBL_REQUIRE(xsrc && xn && ysrc && yn && lidx && out_val && out_idx, "f16r_rescore: null pointer");
+  OIBL_REQUIRE(m > 0 && d > 0 && d % 4 == 0 && k >= 1 && f16r_k2(k) <= F16R_MAX_K2, "f16r_rescore: bad shape m=%d d=%d k=%d", m,
+               d, k);
+  OIBL_REQUIRE((uintptr_t)xsrc % 16 == 0 && (uintptr_t)ysrc % 16 == 0, "f16r_rescore: rows must be 16-byte aligned");
   F16rRescoreParams r = {};
   r.xsrc = xsrc;
   r.ysrc = ysrc;
@@ -1521,13 +1536,54 @@ int oibl_sqdist_topk_f16r(const void* xh, const float* xaux, const float* xn, co
   r.m = m;
   r.d = d;
   r.k = k;
-  r.K2 = f.K2;
+  r.K2 = f16r_k2(k);
   r.index_base = index_base;
   r.out_val = out_val;
   r.out_idx = out_idx;
-  hipLaunchKernelGGL(f16r_rescore_kernel, dim3((unsigned)m), dim3(256), 0, st, r);
+  hipLaunchKernelGGL(f16r_rescore_kernel, dim3((unsigned)m), dim3(256), 0, (hipStream_t)stream, r);
   OIBL_LAUNCH_CHECK();
   return OIBL_OK;
+}
+
+int oibl_f16r_keep_members(const float* lval, int32_t* lidx, int m, int k, const float* thr, const float* xn,
+                           const float* xaux, const float* ymax_all, int shards, int d, void* stream) {
+  OIBL_REQUIRE(lval && lidx && thr && xn && xaux && ymax_all, "f16r_keep_members: null pointer");
+  OIBL_REQUIRE(m > 0 && k >= 1 && shards >= 1 && d > 0 && f16r_k2(k) <= F16R_MAX_K2, "f16r_keep_members: bad arguments");
+  const int K2 = f16r_k2(k);
+  const long items = (long)m * K2;
+  hipLaunchKernelGGL(f16r_keep_members_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     lval, lidx, m, K2, thr, xn, (const float4*)xaux, ymax_all, shards, (float)d * 5.9604645e-8f);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
+
+int oibl_sqdist_topk_f16r(const void* xh, const float* xaux, const float* xn, const float* xsrc, int m,
+                          const void* yh, const float* yaux, const float* yn, const float* ysrc, int n, int d,
+                          int k, int index_base, int exact, float* out_val, int32_t* out_idx, int32_t* overflow,
+                          void* ws, size_t ws_bytes, void* stream) {
+  OIBL_REQUIRE(xh && xaux && xn && xsrc && yh && yaux && yn && ysrc && out_val && out_idx && ws,
+               "sqdist_topk_f16r: null pointer");
+  int rc = topk_args_ok(m, n, d, k, index_base, OIBL_F32);
+  if (rc) return rc;
+  OIBL_REQUIRE((uintptr_t)ws % 256 == 0 && (uintptr_t)xsrc % 16 == 0 && (uintptr_t)ysrc % 16 == 0,
+               "sqdist_topk_f16r: workspace must be 256-byte, rows 16-byte aligned");
+  const F16rPlan f = f16r_plan(m, n, d, k);
+  if (ws_bytes < f.total) {
+    set_error("sqdist_topk_f16r: workspace %zu < required %zu bytes", ws_bytes, f.total);
+    return OIBL_E_WORKSPACE;
+  }
+  char* wsb = (char*)ws;
+  if (!f.fused || exact) {
+    // the exact path: fp32 distance tiles of the resident fp32 rows + row_topk (what OIBL_F32 runs)
+    return sqdist_topk_core(xsrc, xn, m, ysrc, yn, n, d, k, index_base, OIBL_F32, 1, out_val, out_idx, overflow, wsb,
+                            f.t, (hipStream_t)stream);
+  }
+  float* lval = (float*)(wsb + f.off_lval);
+  int32_t* lidx = (int32_t*)(wsb + f.off_lidx);
+  rc = oibl_f16r_filter_select(xh, xaux, xn, m, yh, yaux, yn, n, d, k, index_base, lval, lidx, nullptr, overflow, ws,
+                               ws_bytes, stream);
+  if (rc) return rc;
+  return oibl_f16r_rescore(xsrc, xn, m, ysrc, yn, d, k, index_base, lidx, out_val, out_idx, stream);
 }
 
 int oibl_first_hit_rank(const int32_t* topk_idx, int m, int k, const int32_t* gt_offsets,

@@ -412,6 +412,29 @@ __global__ __launch_bounds__(256) void f16r_select_kernel(const float* __restric
   }
 }
 
+// Sharded matching, between the two stages: thr[row] = the k-th smallest filter distance over ALL shards' lists; an
+// entry of this shard's list stays a member iff D_h <= thr + 2 eps_any, eps_any from the largest |y| / residual over
+// all shards (ymax_all [W][2]); the others get index -1 (the rescoring skips them).
+__global__ __launch_bounds__(256) void f16r_keep_members_kernel(const float* __restrict__ lval, int32_t* __restrict__ lidx,
+                                                                int m, int K2, const float* __restrict__ thr,
+                                                                const float* __restrict__ xn,
+                                                                const float4* __restrict__ xaux,
+                                                                const float* __restrict__ ymax_all, int W, float gamma) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)m * K2) return;
+  const int row = (int)(e / K2);
+  float ymx = 0.f, rmx = 0.f;
+  for (int w = 0; w < W; ++w) {
+    ymx = fmaxf(ymx, ymax_all[2 * w]);
+    rmx = fmaxf(rmx, ymax_all[2 * w + 1]);
+  }
+  const float4 xa = xaux[row];
+  const float nx = xa.y, rx = xa.z;
+  const float A = 2.0f * (rx + gamma * (nx + rx)), B = 2.0f * (nx + rx) * (1.0f + gamma);
+  const float eps_any = fmaf(A, ymx, B * rmx) + 1e-6f * (xn[row] + ymx * ymx);
+  if (lval[e] > thr[row] + 2.0f * eps_any) lidx[e] = -1;        // (a NaN keeps the entry)
+}
+
 struct F16rRescoreParams {
   const float* xsrc;      // [m][d] fp32 rows
   const float* ysrc;      // [n][d] fp32 rows

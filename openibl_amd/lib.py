@@ -88,6 +88,15 @@ SIGNATURES = {
                                           c_void_p, c_size_t, c_void_p]),
     "oibl_match_prepare_f16r": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "oibl_sqdist_topk_f16r_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "oibl_f16r_members": (c_int, [c_int]),
+    "oibl_f16r_fused": (c_int, [c_int, c_int, c_int, c_int]),
+    "oibl_f16r_filter_select": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                        c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                        c_void_p]),
+    "oibl_f16r_keep_members": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                       c_int, c_void_p]),
+    "oibl_f16r_rescore": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                                  c_void_p, c_void_p, c_void_p]),
     "oibl_sqdist_topk_f16r": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                       c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,

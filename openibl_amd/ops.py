@@ -907,6 +907,61 @@ def sqdist_topk_prepared(x: "PreparedRows", y: "PreparedRows", k: int, index_bas
     return ov, oi
 
 
+# ---- the two stages of the f16r top-k, for gallery-sharded matching (sharded.py) ----------------------------
+def f16r_members(k: int) -> int:
+    """Member slots per query of an f16r selection (K2)."""
+    return int(_lib.load().oibl_f16r_members(int(k)))
+
+
+def f16r_fused(m: int, n: int, d: int, k: int) -> bool:
+    return bool(_lib.load().oibl_f16r_fused(int(m), int(n), int(d), int(k)))
+
+
+def f16r_filter_select(x: "PreparedRows", y: "PreparedRows", k: int, index_base: int = 0):
+    """Stage 1 (sample thresholds, fp16 filter pass, selection): (lval [m][K2] filter distances, lidx [m][K2] int32
+    global indices (-1 paddings), ymax [2] = the gallery's largest row norm and fp16 residual norm, flag [1])."""
+    if x.precision != F16R or y.precision != F16R:
+        raise ValueError("f16r_filter_select expects operands prepared for 'f16r'")
+    dev = x.device
+    (m, d), n = x.shape, y.shape[0]
+    K2 = f16r_members(k)
+    lval = torch.empty((m, K2), dtype=torch.float32, device=dev)
+    lidx = torch.empty((m, K2), dtype=torch.int32, device=dev)
+    ymax = torch.zeros(2, dtype=torch.float32, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    ws = workspace(lib.oibl_sqdist_topk_f16r_workspace_bytes(m, n, d, k), dev, "sqdist_topk")
+    _lib.check(lib.oibl_f16r_filter_select(_ptr(x.operand), _ptr(x.aux), _ptr(x.norms), m, _ptr(y.operand), _ptr(y.aux),
+                                           _ptr(y.norms), n, d, k, int(index_base), _ptr(lval), _ptr(lidx), _ptr(ymax),
+                                           _ptr(flag), _ptr(ws), ws.numel(), _stream(dev)), "f16r_filter_select")
+    return lval, lidx, ymax, flag
+
+
+def f16r_keep_members(lval: torch.Tensor, lidx: torch.Tensor, k: int, thr: torch.Tensor, x: "PreparedRows",
+                      ymax_all: torch.Tensor) -> None:
+    """In place: entries of lidx whose filter distance exceeds thr[row] + 2 eps (eps: x's rows against the maxima
+    over all shards, ymax_all [W][2]) become -1."""
+    dev = _need_cuda(lval, lidx, thr, ymax_all)
+    m = int(lval.shape[0])
+    _lib.check(_lib.load().oibl_f16r_keep_members(_ptr(lval), _ptr(lidx), m, int(k), _ptr(thr.contiguous()), _ptr(x.norms),
+                                                  _ptr(x.aux), _ptr(ymax_all.contiguous()), int(ymax_all.shape[0]),
+                                                  int(x.shape[1]), _stream(dev)), "f16r_keep_members")
+
+
+def f16r_rescore(x: "PreparedRows", y: "PreparedRows", lidx: torch.Tensor, k: int, index_base: int = 0):
+    """Stage 2: exact distances of the listed members, the k smallest (distance, index) per query."""
+    dev = x.device
+    m, d = x.shape
+    ov = torch.full((m, k), float("inf"), dtype=torch.float32, device=dev)
+    oi = torch.full((m, k), -1, dtype=torch.int32, device=dev)
+    if m == 0 or y.shape[0] == 0:
+        return ov, oi
+    _lib.check(_lib.load().oibl_f16r_rescore(_ptr(x._source), _ptr(x.norms), m, _ptr(y._source), _ptr(y.norms), d, int(k),
+                                             int(index_base), _ptr(lidx.contiguous()), _ptr(ov), _ptr(oi), _stream(dev)),
+               "f16r_rescore")
+    return ov, oi
+
+
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, regstage: bool = False) -> torch.Tensor:
     """Diagnostic: C = A . B^T on the MFMA core; A [M][K], B [N][K] both bf16 or both fp32."""
     dev = _need_cuda(a, b)

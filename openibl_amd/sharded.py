@@ -61,6 +61,42 @@ def hip_merge_topk(vals: torch.Tensor, idx: torch.Tensor, k: int):
     return ops.row_topk(vals.contiguous(), k, idx_in=idx.contiguous())
 
 
+class HipF16rStages:
+    """The two stages of the f16r top-k on this rank's shard (ops.f16r_*), as sharded_topk uses them."""
+
+    @staticmethod
+    def members(k):
+        return ops.f16r_members(k)
+
+    @staticmethod
+    def filter_select(q, g, k, index_base):
+        """-> (lval [Q][K2], lidx [Q][K2], ymax [2], flag [1]); a shard too small for the fused path answers with
+        EXACT distances in the same form (error 0 <= any bound), its maxima taken from its prepared rows."""
+        Q, n = q.shape[0], g.shape[0]
+        K2 = ops.f16r_members(k)
+        dev = q.device
+        if n == 0:
+            return (torch.full((Q, K2), float("inf"), device=dev), torch.full((Q, K2), -1, dtype=torch.int32, device=dev),
+                    torch.zeros(2, device=dev), torch.zeros(1, dtype=torch.int32, device=dev))
+        if ops.f16r_fused(Q, n, q.shape[1], k):
+            return ops.f16r_filter_select(q, g, k, index_base)
+        v, i = ops.sqdist_topk_prepared(q, g, K2, index_base=index_base, exact=True)
+        return v, i, torch.stack([g.aux[:, 1].max(), g.aux[:, 2].max()]), torch.zeros(1, dtype=torch.int32, device=dev)
+
+    @staticmethod
+    def kth(vals, k):
+        """k-th smallest of every row (+inf when a row has fewer than k finite entries)"""
+        return ops.row_topk(vals.contiguous(), k)[0][:, k - 1].contiguous()
+
+    @staticmethod
+    def keep_members(lval, lidx, k, thr, q, ymax_all):
+        ops.f16r_keep_members(lval, lidx, k, thr, q, ymax_all)
+
+    @staticmethod
+    def rescore(q, g, lidx, k, index_base):
+        return ops.f16r_rescore(q, g, lidx, k, index_base)
+
+
 def all_gather_rows(x: torch.Tensor, group=None) -> torch.Tensor:
     """Concatenate equally-shaped per-rank tensors along dim 0 (one all_gather)."""
     rank, world = _world(group)
@@ -102,35 +138,15 @@ def _query_block(q, lo: int, hi: int):
     return q[lo:hi]
 
 
-def sharded_topk(q_all: torch.Tensor, g_local: torch.Tensor, k: int, index_base: int,
-                 precision="fp32", group=None,
-                 local_topk_fn: Optional[Callable] = None,
-                 merge_fn: Optional[Callable] = None, blocks: int = 1) -> Tuple[torch.Tensor, torch.Tensor]:
-    """k nearest gallery rows (squared L2) of every query over ALL ranks' gallery slices.
-
-    q_all   [Q][d]  the full query set, identical on every rank (or its ops.PreparedRows, e.g. from
-                    gather_prepared_queries)
-    g_local [n][d]  this rank's valid gallery rows (padding rows removed), or an ops.PreparedRows of
-                    them (a gallery matched repeatedly pays its norm / operand pass once)
-    index_base      global gallery index of g_local[0]
-    Returns (values [Q][k] ascending, indices [Q][k] int32 global), identical on every rank.
-    Ties are broken towards the lowest global index, so the result does not depend on the number
-    of shards.
-    blocks > 1 (and more than one rank): the queries are processed in that many row blocks and the
-    exchange + merge of block b runs on a second stream while the matrix cores already work on the local
-    top-k of block b + 1 — the collective's latency (and the merge) leave the critical path except for the
-    last block.  Same results (every query row is independent)."""
+def _make_stages(g_local, k, index_base, precision, group, local_topk_fn, merge_fn, f16r_stages):
+    """(stage_main, stage_side, gather_and_merge) of one rank: what runs on the caller's stream per query block (the
+    matrix work) and what runs behind it (the exchange(s) + merge)."""
+    use_f16r = f16r_stages is not None or (local_topk_fn is None and ops.precision_code(precision) == ops.F16R)
+    if use_f16r and f16r_stages is None:
+        f16r_stages = HipF16rStages
     local_topk_fn = local_topk_fn or hip_local_topk
     merge_fn = merge_fn or hip_merge_topk
     rank, world = _world(group)
-
-    def local(exact: bool):
-        res = local_topk_fn(q_all, g_local, k, index_base, precision, exact) if exact else \
-            local_topk_fn(q_all, g_local, k, index_base, precision)
-        if len(res) == 3:
-            return res
-        v_, i_ = res                      # an exact implementation (tests): no overflow flag
-        return v_, i_, torch.zeros(1, dtype=torch.int32, device=v_.device)
 
     def gather_and_merge(v, i, flag):
         if world == 1:
@@ -151,6 +167,69 @@ def sharded_topk(q_all: torch.Tensor, g_local: torch.Tensor, k: int, index_base:
         mv, mi = merge_fn(vs, is_, k)
         return mv, mi, flags
 
+    # what runs on the caller's stream per query block (matrix work) and what runs behind it (exchange + merge; f16r:
+    # exchange of the filter lists, global threshold, this rank's share of the rescoring, exchange + merge)
+    two_phase = use_f16r and world > 1
+
+    def stage_main(qb, exact):
+        if two_phase and not exact:
+            return f16r_stages.filter_select(qb, g_local, k, index_base)
+        res = local_topk_fn(qb, g_local, k, index_base, precision, exact) if exact else \
+            local_topk_fn(qb, g_local, k, index_base, precision)
+        if len(res) == 2:
+            res = (res[0], res[1], torch.zeros(1, dtype=torch.int32, device=res[0].device))
+        return res
+
+    def stage_side(qb, res, exact):
+        if not (two_phase and not exact):
+            return gather_and_merge(*res)
+        lval, lidx, ymax, flag = res
+        Qb, K2 = int(lval.shape[0]), int(lval.shape[1])
+        extra = torch.zeros((1, 2 * K2), dtype=torch.float32, device=lval.device)
+        extra[0, 0:1] = flag.view(torch.float32)
+        extra[0, 1:3] = ymax
+        packed = torch.cat([torch.cat([lval, lidx.view(torch.float32)], dim=1), extra]).contiguous()
+        gathered = torch.empty((world * (Qb + 1), 2 * K2), dtype=torch.float32, device=packed.device)
+        dist.all_gather_into_tensor(gathered, packed, group=group)
+        gathered = gathered.view(world, Qb + 1, 2 * K2)
+        flags = gathered[:, Qb, 0].contiguous().view(torch.int32)
+        ymax_all = gathered[:, Qb, 1:3].contiguous()                              # [world][2]
+        vals_all = gathered[:, :Qb, :K2].permute(1, 0, 2).reshape(Qb, world * K2)
+        thr = f16r_stages.kth(vals_all, k)                                        # k-th smallest filter distance, all shards
+        f16r_stages.keep_members(lval, lidx, k, thr, qb, ymax_all)                # this rank's members of the global set
+        v, i = f16r_stages.rescore(qb, g_local, lidx, k, index_base)
+        any_flag = flags.ne(0).any().to(torch.int32).reshape(1)
+        return gather_and_merge(v, i, any_flag)
+
+    return stage_main, stage_side, gather_and_merge
+
+
+def sharded_topk(q_all: torch.Tensor, g_local: torch.Tensor, k: int, index_base: int,
+                 precision="fp32", group=None,
+                 local_topk_fn: Optional[Callable] = None,
+                 merge_fn: Optional[Callable] = None, blocks: int = 1,
+                 f16r_stages=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """k nearest gallery rows (squared L2) of every query over ALL ranks' gallery slices.
+
+    q_all   [Q][d]  the full query set, identical on every rank (or its ops.PreparedRows, e.g. from
+                    gather_prepared_queries)
+    g_local [n][d]  this rank's valid gallery rows (padding rows removed), or an ops.PreparedRows of
+                    them (a gallery matched repeatedly pays its norm / operand pass once)
+    index_base      global gallery index of g_local[0]
+    Returns (values [Q][k] ascending, indices [Q][k] int32 global), identical on every rank.
+    Ties are broken towards the lowest global index, so the result does not depend on the number
+    of shards.
+    blocks > 1 (and more than one rank): the queries are processed in that many row blocks and the
+    exchange + merge of block b runs on a second stream while the matrix cores already work on the local
+    top-k of block b + 1 — the collective's latency (and the merge) leave the critical path except for the
+    last block.  Same results (every query row is independent).
+    f16r (more than one rank, the HIP stages or `f16r_stages`): TWO exchanges — the filter lists first; the threshold
+    is then the k-th smallest filter distance over ALL shards, and every rank rescores only ITS members of the
+    global rescore set (k + a few per query in total, not per rank): the exact-rescoring work divides by the
+    number of ranks instead of being repeated on each (_f16r_two_phase)."""
+    stage_main, stage_side, gather_and_merge = _make_stages(g_local, k, index_base, precision, group, local_topk_fn,
+                                                            merge_fn, f16r_stages)
+    rank, world = _world(group)
     nq = int(q_all.shape[0])
     if blocks > 1 and world > 1 and nq >= blocks:
         bounds = [(b * nq // blocks, (b + 1) * nq // blocks) for b in range(blocks)]
@@ -159,28 +238,21 @@ def sharded_topk(q_all: torch.Tensor, g_local: torch.Tensor, k: int, index_base:
         main = torch.cuda.current_stream(probe.device) if on_gpu else None
         side = _side_stream(probe.device) if on_gpu else None
 
-        def local_block(lo, hi, exact):
-            qb = _query_block(q_all, lo, hi)
-            res = local_topk_fn(qb, g_local, k, index_base, precision, exact) if exact else \
-                local_topk_fn(qb, g_local, k, index_base, precision)
-            if len(res) == 2:
-                res = (res[0], res[1], torch.zeros(1, dtype=torch.int32, device=res[0].device))
-            return res
-
         parts = []
         for lo, hi in bounds:
-            res = local_block(lo, hi, False)
+            qb = _query_block(q_all, lo, hi)
+            res = stage_main(qb, False)
             if on_gpu:
                 side.wait_stream(main)                  # this block's lists are complete
                 with torch.cuda.stream(side):
-                    out = gather_and_merge(*res)
+                    out = stage_side(qb, res, False)
                 for t in res:
                     t.record_stream(side)               # allocated on main, read by the exchange on side
                 for t in out:
                     t.record_stream(main)               # allocated on side, read by the concatenation on main
                 parts.append(out)
             else:
-                parts.append(gather_and_merge(*res))
+                parts.append(stage_side(qb, res, False))
         if on_gpu:
             main.wait_stream(side)
         # the only host synchronisation, after everything has been enqueued; identical on every rank (each block's
@@ -188,12 +260,12 @@ def sharded_topk(q_all: torch.Tensor, g_local: torch.Tensor, k: int, index_base:
         flagged = torch.stack([p_[2].reshape(-1).ne(0).any() for p_ in parts]).tolist()
         for b, (lo, hi) in enumerate(bounds):
             if flagged[b]:
-                parts[b] = gather_and_merge(*local_block(lo, hi, True))
+                parts[b] = gather_and_merge(*stage_main(_query_block(q_all, lo, hi), True))
         return torch.cat([p_[0] for p_ in parts]), torch.cat([p_[1] for p_ in parts])
-    v, i, flags = gather_and_merge(*local(False))
+    v, i, flags = stage_side(q_all, stage_main(q_all, False), False)
     # the only host synchronisation, after everything has been enqueued; identical on every rank
     if bool(flags.any().item()):
-        v, i, _ = gather_and_merge(*local(True))
+        v, i, _ = gather_and_merge(*stage_main(q_all, True))
     return v, i
 
 
@@ -201,7 +273,7 @@ def sharded_topk_pipelined(q_local: torch.Tensor, n_total: int, g_local, k: int,
                            precision="fp32", group=None, blocks: int = 4,
                            local_topk_fn: Optional[Callable] = None, merge_fn: Optional[Callable] = None,
                            prepare_fn: Optional[Callable] = None,
-                           rows_travel: Optional[bool] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                           rows_travel: Optional[bool] = None, f16r_stages=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """sharded_topk fed with the queries THIS RANK extracted (q_local: its DistributedSliceSampler slice of the
     n_total queries, wrap-around padding included), with BOTH exchanges hidden behind matrix work (VERDICT r04 item
     5a): the local slice is cut into `blocks` sub-blocks; sub-block b of every rank is all-gathered on a second
@@ -213,15 +285,16 @@ def sharded_topk_pipelined(q_local: torch.Tensor, n_total: int, g_local, k: int,
     What travels per query: the prepared operand + norm (bf16: 8 KB per 4096-d row; bf16x3 / f16mx: 16 KB), or the
     fp32 row for the arithmetics that need it on every rank (fp32, f16r: 16 KB; prepared after the gather).
     Returns (values [n_total][k], indices [n_total][k] int32 global), identical on every rank."""
-    local_topk_fn = local_topk_fn or hip_local_topk
-    merge_fn = merge_fn or hip_merge_topk
+    stage_main, stage_side, gather_and_merge = _make_stages(g_local, k, index_base, precision, group, local_topk_fn,
+                                                            merge_fn, f16r_stages)
     rank, world = _world(group)
     qper = int(q_local.shape[0])
     d = int(q_local.shape[1])
     if world == 1:
         qp = q_local[:n_total] if prepare_fn is None and not q_local.is_cuda else \
             (prepare_fn or (lambda x: ops.PreparedRows(x, precision)))(q_local[:n_total].contiguous())
-        return sharded_topk(qp, g_local, k, index_base, precision, group, local_topk_fn, merge_fn)
+        return sharded_topk(qp, g_local, k, index_base, precision, group, local_topk_fn, merge_fn,
+                            f16r_stages=f16r_stages)
     blocks = max(1, min(int(blocks), qper))
     bounds = [(b * qper // blocks, (b + 1) * qper // blocks) for b in range(blocks)]
     dev = q_local.device
@@ -244,25 +317,6 @@ def sharded_topk_pipelined(q_local: torch.Tensor, n_total: int, g_local, k: int,
         if g_[0] == "rows":
             return make(g_[1])
         return g_[1].from_parts(g_[2], g_[3], d, precision)
-
-    def exchange(v, i, flag):
-        Qb = v.shape[0]
-        row = flag.view(torch.float32).expand(1, 2 * k)
-        packed = torch.cat([torch.cat([v, i.view(torch.float32)], dim=1), row]).contiguous()
-        gathered = torch.empty((world * (Qb + 1), 2 * k), dtype=torch.float32, device=packed.device)
-        dist.all_gather_into_tensor(gathered, packed, group=group)
-        gathered = gathered.view(world, Qb + 1, 2 * k)
-        flags = gathered[:, Qb, 0].contiguous().view(torch.int32)
-        lists = gathered[:, :Qb, :].permute(1, 0, 2)
-        mv, mi = merge_fn(lists[:, :, :k].reshape(Qb, world * k), lists[:, :, k:].reshape(Qb, world * k).view(torch.int32), k)
-        return mv, mi, flags
-
-    def run_block(qb, exact):
-        res = local_topk_fn(qb, g_local, k, index_base, precision, exact) if exact else \
-            local_topk_fn(qb, g_local, k, index_base, precision)
-        if len(res) == 2:
-            res = (res[0], res[1], torch.zeros(1, dtype=torch.int32, device=res[0].device))
-        return res
 
     def on_side(fn, *a):
         if not on_gpu:
@@ -292,12 +346,12 @@ def sharded_topk_pipelined(q_local: torch.Tensor, n_total: int, g_local, k: int,
                     t.record_stream(main)
         qb = assemble(cur)
         sets.append(qb)
-        res = run_block(qb, False)
+        res = stage_main(qb, False)
         if on_gpu:
             side.wait_stream(main)
             for t in res:
                 t.record_stream(side)
-        out = on_side(exchange, *res)
+        out = on_side(stage_side, qb, res, False)
         if on_gpu:
             for t in out:
                 t.record_stream(main)
@@ -307,7 +361,7 @@ def sharded_topk_pipelined(q_local: torch.Tensor, n_total: int, g_local, k: int,
     flagged = torch.stack([o[2].reshape(-1).ne(0).any() for o in outs]).tolist()   # the only host synchronisation
     for b in range(blocks):
         if flagged[b]:
-            outs[b] = exchange(*run_block(sets[b], True))
+            outs[b] = gather_and_merge(*stage_main(sets[b], True))
     # rows of sub-block b, rank-major: global query r * qper + lo + i (beyond n_total: wrap-around padding, dropped)
     v_all = torch.empty((n_total, k), dtype=outs[0][0].dtype, device=outs[0][0].device)
     i_all = torch.empty((n_total, k), dtype=torch.int32, device=outs[0][0].device)

@@ -54,6 +54,16 @@ for world in worlds:
     lists_dst = torch.empty_like(lists_src)
     vals = torch.randn((world * sub, world * K), device=dev)
     idx = torch.randint(0, G, (world * sub, world * K), device=dev, dtype=torch.int32)
+    if prec == "f16r":
+        K2 = ops.f16r_members(K)
+        f_src = torch.randn((world, world * sub + 1, 2 * K2), device=dev)
+        f_dst = torch.empty_like(f_src)
+        f_vals = torch.rand((world * sub, world * K2), device=dev) + 1.0      # (thr from it: keeps every local member ...
+        ymax_all = torch.tensor([[1.0, 2e-4]] * world, device=dev)
+        # ... so the share of the global rescore set that is THIS rank's is imposed: one member in `world` survives)
+        keep_frac = world > 1
+        keep_mask = (torch.arange(K2, device=dev)[None, :] % world == 0).expand(world * sub, K2)
+        minus1 = torch.full((world * sub, K2), -1, dtype=torch.int32, device=dev)
 
     def step():
         if world == 1:
@@ -75,6 +85,21 @@ for world in worlds:
                     e = torch.cuda.Event(); e.record(side); evs.append(e)
             main.wait_event(evs[b])
             qb = ops.PreparedRows(q_sub, prec) if rows_travel else p_sub
+            if prec == "f16r":                          # two phases: filter lists first, the rescoring behind the exchange
+                lval, lidx, ymax, flag = ops.f16r_filter_select(qb, shard, K)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    f_dst.copy_(f_src)                  # all_gather of the filter lists [world][Qb + 1][2 K2]
+                    thr = ops.row_topk(f_vals, K)[0][:, K - 1].contiguous()
+                    if keep_frac:
+                        lidx2 = torch.where(keep_mask, lidx, minus1)     # 1 / world of the members are this rank's
+                    else:
+                        lidx2 = lidx
+                    ops.f16r_keep_members(lval, lidx2, K, thr, qb, ymax_all)
+                    out = ops.f16r_rescore(qb, shard, lidx2, K)
+                    lists_dst.copy_(lists_src)          # all_gather of the exact lists
+                    ops.row_topk(vals, K, idx_in=idx)   # k-way merge
+                continue
             out = ops.sqdist_topk_prepared(qb, shard, K, defer_check=True)
             side.wait_stream(main)
             with torch.cuda.stream(side):

@@ -64,6 +64,33 @@ def _worker(rank, world, port, ret):
         qp = sharded.gather_prepared_queries(q_loc, Q, "bf16x3")
         vp, ip = sharded.sharded_topk(qp, shard, k, start, precision="bf16x3")
         out["topk_prepared"] = bool(torch.equal(ip, i3) and torch.equal(vp, v3))
+        # f16r across the two shards: the two-phase protocol (filter lists exchanged, global threshold, every rank
+        # rescoring its members only).  A shard too small for the fused path answers with exact distances in the
+        # same form: the small problem's lists are the fp32 lists; a fused-size problem against the oracle and
+        # against ONE rank matching the whole gallery (exact values: bit-equal), also in query blocks and with the
+        # queries travelling in sub-blocks.
+        vr, ir = sharded.sharded_topk(q.to(dev), g_loc, k, start, precision="f16r")
+        gotr = np.take_along_axis(dm, ir.cpu().numpy().astype(np.int64), 1)      # (near-ties may order differently)
+        out["topk_f16r_small"] = bool(np.allclose(gotr, wv, rtol=0, atol=5e-6)
+                                      and np.allclose(vr.cpu().numpy(), wv, rtol=0, atol=5e-6))
+        Q2, G2, d2 = 512, 2 * 9000 + 7, 128
+        q2, g2, _, _ = synth.retrieval_problem(Q2, G2, dim=d2, seed=13, hard_fraction=0.5)
+        s2, per2, nv2 = sharded.slice_bounds(G2, rank, world)
+        shard2 = ops.PreparedRows(g2[s2:s2 + nv2].to(dev), "f16r")
+        v2, i2 = sharded.sharded_topk(ops.PreparedRows(q2.to(dev), "f16r"), shard2, k, s2, precision="f16r")
+        one_v, one_i = ops.sqdist_topk(q2.to(dev), g2.to(dev), k, precision="f16r")
+        d64 = (q2.double() ** 2).sum(1)[:, None] + (g2.double() ** 2).sum(1)[None] - 2.0 * q2.double() @ g2.double().t()
+        w64 = torch.sort(d64, dim=1, stable=True)
+        got64 = torch.gather(d64, 1, i2.cpu().long())
+        out["topk_f16r_two_phase"] = bool(torch.equal(i2, one_i) and torch.equal(v2, one_v)
+                                          and float((got64 - w64.values[:, :k]).abs().max()) < 2e-6
+                                          and float((v2.cpu().double() - got64).abs().max()) < 1e-6)
+        v2b, i2b = sharded.sharded_topk(ops.PreparedRows(q2.to(dev), "f16r"), shard2, k, s2, precision="f16r", blocks=2)
+        qs2, qper2, _ = sharded.slice_bounds(Q2, rank, world)
+        q2_loc = torch.stack([q2[(qs2 + j) % Q2] for j in range(qper2)]).to(dev)
+        v2c, i2c = sharded.sharded_topk_pipelined(q2_loc, Q2, shard2, k, s2, precision="f16r", blocks=2)
+        out["topk_f16r_blocks"] = bool(torch.equal(i2b, i2) and torch.equal(v2b, v2) and torch.equal(i2c, i2)
+                                       and torch.equal(v2c, v2))
         # every rank holds the same merged lists
         both = [torch.empty_like(i3) for _ in range(world)]
         dist.all_gather(both, i3)

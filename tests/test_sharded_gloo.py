@@ -94,6 +94,57 @@ def _first_block_overflows(q, g, k, index_base, precision, exact=False):
 _first_block_overflows.calls = []
 
 
+class _CpuF16rStages:
+    """CPU stand-ins with the protocol of sharded.HipF16rStages: the 'filter distance' is the exact distance plus a
+    deterministic perturbation of at most EPS (what the fp16 pass is to the exact distance), the bound is 2 EPS."""
+    EPS, K2 = 1e-4, 32
+    kept = []            # members this rank rescored, per call
+
+    @staticmethod
+    def members(k):
+        return _CpuF16rStages.K2
+
+    @staticmethod
+    def filter_select(q, g, k, index_base):
+        from oracle import matching as om
+        Q, K2 = q.shape[0], _CpuF16rStages.K2
+        lval = torch.full((Q, K2), float("inf"))
+        lidx = torch.full((Q, K2), -1, dtype=torch.int32)
+        if g.shape[0]:
+            d = om.pairwise_distance(q, g)
+            dh = d + _CpuF16rStages.EPS * torch.sin(1.0e4 * d)
+            v, i = torch.sort(dh, dim=1, stable=True)
+            n = min(K2, g.shape[0])
+            lval[:, :n] = v[:, :n]
+            lidx[:, :n] = (i[:, :n] + index_base).to(torch.int32)
+        return lval, lidx, torch.tensor([1.0, 0.0]), torch.zeros(1, dtype=torch.int32)
+
+    @staticmethod
+    def kth(vals, k):
+        return torch.kthvalue(vals, k, dim=1).values.contiguous()
+
+    @staticmethod
+    def keep_members(lval, lidx, k, thr, q, ymax_all):
+        assert ymax_all.shape == (dist.get_world_size(), 2) and bool((ymax_all[:, 0] == 1.0).all())
+        lidx[lval > thr[:, None] + 2 * _CpuF16rStages.EPS] = -1
+        _CpuF16rStages.kept.append(int((lidx >= 0).sum()))
+
+    @staticmethod
+    def rescore(q, g, lidx, k, index_base):
+        from oracle import matching as om
+        Q = q.shape[0]
+        d = om.pairwise_distance(q, g) if g.shape[0] else torch.zeros((Q, 0))
+        v = torch.full((Q, k), float("inf"))
+        i = torch.full((Q, k), -1, dtype=torch.int32)
+        for r in range(Q):
+            ids = lidx[r][lidx[r] >= 0].long()
+            vals = d[r][ids - index_base]
+            order = sorted(range(len(ids)), key=lambda t: (float(vals[t]), int(ids[t])))[:k]
+            for c, t in enumerate(order):
+                v[r, c], i[r, c] = vals[t], int(ids[t])
+        return v, i
+
+
 def _oracle_merge(vals, idx, k):
     key = np.lexsort((idx.numpy().astype(np.int64) & 0xFFFFFFFF, vals.numpy()), axis=1)[:, :k]
     return (torch.from_numpy(np.take_along_axis(vals.numpy(), key, 1)),
@@ -175,6 +226,21 @@ def _worker(rank, world, port, G, ret):
                                                   prepare_fn=lambda x: x, rows_travel=True)
         ok_topk = ok_topk and bool(np.array_equal(i11.numpy(), wi)) and \
             [c_[0] for c_ in _first_block_overflows.calls] == [False, False, False, True]
+        # f16r across shards: TWO exchanges (filter lists, then exact values), the global threshold, every rank
+        # rescoring only its members of the global set — the lists are the oracle's, and the rescoring work adds up to
+        # ~k + a few per query over ALL ranks, not per rank
+        for nb in (1, 2):
+            _CpuF16rStages.kept = []
+            v12, i12 = sharded.sharded_topk(q, g[start:start + n_valid], 10, start, "f16r", blocks=nb,
+                                            merge_fn=_oracle_merge, f16r_stages=_CpuF16rStages)
+            ok_topk = ok_topk and bool(np.array_equal(i12.numpy(), wi) and np.allclose(v12.numpy(), wv))
+            kept = torch.tensor([sum(_CpuF16rStages.kept)])
+            dist.all_reduce(kept)
+            ok_topk = ok_topk and Qn * 10 <= int(kept) <= Qn * 16
+        v13, i13 = sharded.sharded_topk_pipelined(q_loc, Qn, g[start:start + n_valid], 10, start, "f16r", blocks=3,
+                                                  merge_fn=_oracle_merge, f16r_stages=_CpuF16rStages,
+                                                  prepare_fn=lambda x: x, rows_travel=True)
+        ok_topk = ok_topk and bool(np.array_equal(i13.numpy(), wi) and np.allclose(v13.numpy(), wv))
         rec = evaluators.recalls_from_topk(idx.numpy(), gt)
         ok_rec = bool(np.array_equal(rec, om.evaluate_all(d, gt, pids)))
 
@@ -262,6 +328,13 @@ def _worker8(rank, world, port, ret):
                                     local_topk_fn=_first_block_overflows, merge_fn=_oracle_merge)
         ok = ok and bool(np.array_equal(i.numpy(), wi)) and \
             _first_block_overflows.calls == [(False, 10), (False, 10), (False, 10), (True, 10)]
+        # f16r across 8 shards: two exchanges, global threshold, the rescoring divided over the ranks
+        _CpuF16rStages.kept = []
+        v, i = sharded.sharded_topk(q, g[start:start + n_valid], k, start, "f16r", merge_fn=_oracle_merge,
+                                    f16r_stages=_CpuF16rStages)
+        kept = torch.tensor([sum(_CpuF16rStages.kept)])
+        dist.all_reduce(kept)
+        ok = ok and bool(np.array_equal(i.numpy(), wi) and np.allclose(v.numpy(), wv)) and Q * k <= int(kept) <= Q * (k + 8)
         # the pipelined form: every rank's 4 local queries travel in 1 / 2 / 4 sub-blocks (the last slice wraps)
         for nb in (1, 2, 4):
             v, i = sharded.sharded_topk_pipelined(q_loc, Q, g[start:start + n_valid], k, start, blocks=nb,
