@@ -75,7 +75,7 @@ class HipF16rStages:
         Q, n = q.shape[0], g.shape[0]
         K2 = ops.f16r_members(k)
         dev = q.device
-        if n == 0:
+        if n == 0:          # (an empty shard: no candidates, no maxima)
             return (torch.full((Q, K2), float("inf"), device=dev), torch.full((Q, K2), -1, dtype=torch.int32, device=dev),
                     torch.zeros(2, device=dev), torch.zeros(1, dtype=torch.int32, device=dev))
         if ops.f16r_fused(Q, n, q.shape[1], k):
@@ -94,6 +94,9 @@ class HipF16rStages:
 
     @staticmethod
     def rescore(q, g, lidx, k, index_base):
+        if g.shape[0] == 0:
+            return (torch.full((q.shape[0], k), float("inf"), device=q.device),
+                    torch.full((q.shape[0], k), -1, dtype=torch.int32, device=q.device))
         return ops.f16r_rescore(q, g, lidx, k, index_base)
 
 
@@ -227,6 +230,12 @@ def sharded_topk(q_all: torch.Tensor, g_local: torch.Tensor, k: int, index_base:
     is then the k-th smallest filter distance over ALL shards, and every rank rescores only ITS members of the
     global rescore set (k + a few per query in total, not per rank): the exact-rescoring work divides by the
     number of ranks instead of being repeated on each (_f16r_two_phase)."""
+    if f16r_stages is None and local_topk_fn is None and ops.precision_code(precision) == ops.F16R:
+        # the HIP stages work on prepared operands (one preparation serves filter, threshold and rescoring)
+        if not isinstance(q_all, ops.PreparedRows):
+            q_all = ops.PreparedRows(q_all, ops.F16R)
+        if not isinstance(g_local, ops.PreparedRows) and g_local.shape[0] > 0:
+            g_local = ops.PreparedRows(g_local, ops.F16R)
     stage_main, stage_side, gather_and_merge = _make_stages(g_local, k, index_base, precision, group, local_topk_fn,
                                                             merge_fn, f16r_stages)
     rank, world = _world(group)
@@ -285,6 +294,9 @@ def sharded_topk_pipelined(q_local: torch.Tensor, n_total: int, g_local, k: int,
     What travels per query: the prepared operand + norm (bf16: 8 KB per 4096-d row; bf16x3 / f16mx: 16 KB), or the
     fp32 row for the arithmetics that need it on every rank (fp32, f16r: 16 KB; prepared after the gather).
     Returns (values [n_total][k], indices [n_total][k] int32 global), identical on every rank."""
+    if f16r_stages is None and local_topk_fn is None and ops.precision_code(precision) == ops.F16R and \
+            not isinstance(g_local, ops.PreparedRows) and g_local.shape[0] > 0:
+        g_local = ops.PreparedRows(g_local, ops.F16R)
     stage_main, stage_side, gather_and_merge = _make_stages(g_local, k, index_base, precision, group, local_topk_fn,
                                                             merge_fn, f16r_stages)
     rank, world = _world(group)
