@@ -164,3 +164,36 @@ def test_topk_precision_rule():
     with pytest.raises(ValueError):
         ops.pairwise_sqdist(torch.zeros(2, 64), torch.zeros(2, 64), "f16r")
 
+
+
+def test_long_candidate_list_takes_the_workgroup_selection(dev):
+    """A query whose strided threshold sample is far away lets ~3000 gallery rows through the filter: beyond the 2048
+    entries one wave keeps in registers, inside the list capacity — the workgroup-per-row launch of the selection
+    serves it (no overflow), and its list is the fp64 one."""
+    m, n, d, k = 256, 16384, 256, 10
+    gen = torch.Generator().manual_seed(31)
+    q = torch.nn.functional.normalize(torch.randn((m, d), generator=gen), dim=1)
+    g = torch.nn.functional.normalize(torch.randn((n, d), generator=gen), dim=1)
+    stride = n // 1024                                           # the sample: rows 0, stride, 2 stride, ...
+    far = torch.nn.functional.normalize(-q[0][None] + 0.01 * torch.randn((n, d), generator=gen), dim=1)
+    near = torch.zeros(n, dtype=torch.bool)
+    near[torch.randperm(n, generator=gen)[:3000]] = True
+    near[::stride] = False
+    g = torch.where(near[:, None], g, far)                       # 3000 ordinary rows, everything else ~ -q0 ...
+    g[::stride] = torch.nn.functional.normalize(-q[0][None] + 0.3 * torch.randn((1024, d), generator=gen), dim=1)  # ... the sample a little nearer
+    v, i, flag = ops.sqdist_topk(q.to(dev), g.to(dev), k, precision="f16r", defer_check=True)
+    assert int(flag.item()) == 0
+    _assert_lists("f16r, 3000 candidates for query 0", q, g, v, i, k)
+    assert bool(near[i[0].cpu().long()].all())                   # query 0's neighbours are among the ordinary rows
+
+
+@pytest.mark.parametrize("k", [1, 16, 17, 32])
+def test_member_window_sizes(dev, k):
+    """k = 16 | 17: the member window changes from 32 to 2k + 32 slots; k = 32: the largest k of the fused path."""
+    m, n, d = 256, 16384, 256
+    q, g, _, _ = synth.retrieval_problem(m, n, dim=d, seed=40 + k, hard_fraction=0.5)
+    assert ops.f16r_fused(m, n, d, k) and ops.f16r_members(k) == (32 if k <= 16 else 2 * k + 32)
+    v, i, flag = ops.sqdist_topk(q.to(dev), g.to(dev), k, precision="f16r", defer_check=True)
+    assert int(flag.item()) == 0
+    _assert_lists(f"f16r k={k}", q, g, v, i, k)
+    assert not ops.f16r_fused(m, n, d, 33)                       # beyond the selection's register rounds: exact path
