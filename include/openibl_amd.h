@@ -293,6 +293,18 @@ size_t oibl_pca_workspace_bytes(int N, int D, int d, int precision);
 int oibl_pca_forward(const float* v, int N, int D, const void* w, const float* b, int d,
                      int precision, int l2norm, float* out, void* ws, size_t ws_bytes,
                      void* stream);
+/* The same projection in fp32 from a RE-PACKED copy of the weight (round 5): for 1 <= N <= 32 rows the weight
+ * stream is the whole cost (537 MB for 32768 -> 4096), and the row-major matrix does not stream as an MFMA
+ * operand.  oibl_pca_pack_weight writes w [d][D] fp32 once as 1 KB tiles ([32 output dims][8 k] in operand
+ * lane order, the tiles of a 32-dim group consecutive along k; d * D floats, 16-byte aligned);
+ * oibl_pca_forward_packed streams it (csrc/pca.hip, pca_stream_kernel).  Same arguments and workspace
+ * (oibl_pca_workspace_bytes(N, D, d, OIBL_F32)) as oibl_pca_forward; results differ from it only by the
+ * association of the fp32 sums.  oibl_pca_packed_supported: 1 where the packed form serves the shape
+ * (N <= 32, d % 256 == 0, D % 8192 == 0), else the caller keeps oibl_pca_forward.                      */
+int oibl_pca_pack_weight(const float* w, int D, int d, float* packed, void* stream);
+int oibl_pca_packed_supported(int N, int D, int d);
+int oibl_pca_forward_packed(const float* v, int N, int D, const float* w_packed, const float* b, int d,
+                            int l2norm, float* out, void* ws, size_t ws_bytes, void* stream);
 
 /* Row-wise L2 normalisation x / max(|x|_2, 1e-12)  (F.normalize(dim=-1), e.g. the extra
  * one in extract_cnn_feature, ibl/evaluators.py:29-33).  In place allowed. */

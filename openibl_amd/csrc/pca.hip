@@ -152,6 +152,105 @@ static bool pca_small_ok(int N, int D, int d, int precision) {
   return precision == OIBL_F32 && N <= PS_MAXN && d % (4 * PS_ROWS) == 0 && D % (PS_SPLITS * 512) == 0;
 }
 
+// Streaming form for 3 .. 32 rows (round 5).  W as the B operand of v_mfma_f32_32x32x2_f32 read from the
+// row-major matrix is 32 rows x 32 bytes per wave instruction — not a streaming pattern for the vector memory
+// path (a kernel doing that ran 178 us = 3.0 TB/s).  So W is RE-PACKED ONCE (oibl_pca_pack_weight, a second
+// 537 MB copy) into 1 KB tiles [32 output dims][8 k] laid out lane by lane as the operand registers want them
+// (lane = (k half << 5) | dim: the four floats W[dim][8 kb + 4 half + 0..3]), the tiles of one group of 32
+// output dims consecutive along k: a wave streams ONE contiguous 128 KB run (its 1/32 of K) with eight non-temporal
+// 16-byte loads per lane in flight, four waves per SIMD.  A workgroup is 8 waves = 8 such groups over the same 1/32 of K; the matching piece of
+// the input rows goes through LDS in the same lane order (chunks of 256 k, double-buffered, one barrier per
+// chunk; rows beyond N repeat row N - 1 and are not stored).  fp32 products and sums (the matrix pipe needs
+// 55 us of the 90 the stream takes); partials [32 splits][N][d] for pca_reduce_kernel.  With the reduction and
+// the scaling: 93 us for 3 rows (5.8 TB/s of W), 94 for 8, 102 for 16, 110 for 32 (4.9 TB/s; the row-major tile:
+// 137 us) — the growth with N is the partials (16.7 MB written and read at 32 rows).
+constexpr int PK_WAVES = 8, PK_SPLITS = 32, PK_CHUNK = 256, PK_TILES = PK_CHUNK / 8, PK_MAXN = 32;
+template <int PK_DEPTH, int OCC>
+__global__ __launch_bounds__(PK_WAVES * 64, OCC) void pca_stream_kernel(const float* __restrict__ v,
+                                                                      const float* __restrict__ wp,
+                                                                      float* __restrict__ part, int N, int D, int d,
+                                                                      int kper) {
+  typedef __attribute__((ext_vector_type(4))) float f4;
+  __shared__ __attribute__((aligned(16))) char smem[2 * PK_TILES * 1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nb = blockIdx.x * PK_WAVES + wave;
+  const long k0 = (long)blockIdx.y * kper;
+  const int chunks = kper / PK_CHUNK;
+  const f4* wt = reinterpret_cast<const f4*>(wp) + ((size_t)nb * (D / 8) + k0 / 8) * 64 + lane;   // tile t: wt[64 t]
+  const int m = min(lane & 31, N - 1);
+  const float* vsrc = v + (size_t)m * D + k0 + 4 * (lane >> 5) + wave * 8;   // tile (wave + 8 i) of a chunk: + 64 i
+  char* const lds_w = smem + wave * 1024 + lane * 16;                        // ... its place: + 8192 i
+  const char* const lds_r = smem + lane * 16;                                // tile t of a chunk: + 1024 t
+
+  f4 ring[PK_DEPTH];
+#pragma unroll
+  for (int u = 0; u < PK_DEPTH; ++u) ring[u] = __builtin_nontemporal_load(wt + (size_t)u * 64);
+  f4 vs[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) vs[i] = *reinterpret_cast<const f4*>(vsrc + 64 * i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) *reinterpret_cast<f4*>(lds_w + 8192 * i) = vs[i];
+  f32x16_t acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  __syncthreads();
+
+  auto chunk = [&](int c, auto last_tag) __attribute__((always_inline)) {
+    constexpr bool LAST = decltype(last_tag)::value;
+    const char* cur = lds_r + (c & 1) * (PK_TILES * 1024);
+    if (!LAST) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) vs[i] = *reinterpret_cast<const f4*>(vsrc + (long)(c + 1) * PK_CHUNK + 64 * i);
+    }
+    const f4* wn = wt + ((size_t)c * PK_TILES + PK_DEPTH) * 64;
+    f4 a = *reinterpret_cast<const f4*>(cur);
+#pragma unroll
+    for (int t = 0; t < PK_TILES; ++t) {
+      const f4 w = ring[t % PK_DEPTH];
+      if (!LAST || t + PK_DEPTH < PK_TILES) ring[t % PK_DEPTH] = __builtin_nontemporal_load(wn + (size_t)t * 64);
+      f4 an = a;
+      if (t + 1 < PK_TILES) an = *reinterpret_cast<const f4*>(cur + (t + 1) * 1024);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], w[j], acc, 0, 0, 0);
+      a = an;
+      __builtin_amdgcn_sched_barrier(0);       // keep the written order: the scheduler sinks the refill otherwise
+    }
+    if (!LAST) {
+      char* nxt = lds_w + ((c + 1) & 1) * (PK_TILES * 1024);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<f4*>(nxt + 8192 * i) = vs[i];
+      __syncthreads();
+    }
+  };
+  for (int c = 0; c + 1 < chunks; ++c) chunk(c, std::false_type{});
+  chunk(chunks - 1, std::true_type{});
+
+  float* out = part + (size_t)blockIdx.y * N * d + nb * 32 + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = acc_row(r, lane);
+    if (row < N) out[(size_t)row * d] = acc[r];
+  }
+}
+
+// packed[((nb * D/8 + kb) * 64 + lane) * 4 + j] = w[nb * 32 + (lane & 31)][8 kb + 4 (lane >> 5) + j]
+__global__ __launch_bounds__(256) void pca_pack_kernel(const float* __restrict__ w, float* __restrict__ packed, int D,
+                                                       size_t units) {
+  typedef __attribute__((ext_vector_type(4))) float f4;
+  for (size_t u = (size_t)blockIdx.x * 256 + threadIdx.x; u < units; u += (size_t)gridDim.x * 256) {
+    const int lane = (int)(u & 63);
+    const size_t tile = u >> 6;
+    const size_t kb = tile % (size_t)(D / 8), nb = tile / (size_t)(D / 8);
+    reinterpret_cast<f4*>(packed)[u] =
+        *reinterpret_cast<const f4*>(w + (nb * 32 + (lane & 31)) * (size_t)D + kb * 8 + 4 * (lane >> 5));
+  }
+}
+
+OIBL_HOOK(int, g_pca_stream, 1);   // test hook: 0 = oibl_pca_forward_packed refuses (callers fall back to the tile)
+static bool pca_stream_ok(int N, int D, int d) {
+  return N >= 1 && N <= PK_MAXN && d % (32 * PK_WAVES) == 0 && D % (PK_SPLITS * PK_CHUNK) == 0;
+}
+
 static int pca_splits(int N, int D, int d, int precision) {
   const int bk = precision == OIBL_BF16 ? 64 : 32;
   const int ksteps = D / bk;
@@ -172,6 +271,7 @@ size_t oibl_pca_workspace_bytes(int N, int D, int d, int precision) {
   if (N <= 0 || D <= 0 || d <= 0) return 0;
   int s = pca_splits(N, D, d, precision);
   if (pca_small_ok(N, D, d, precision) && s < PS_SPLITS) s = PS_SPLITS;
+  if (precision == OIBL_F32 && pca_stream_ok(N, D, d) && s < PK_SPLITS) s = PK_SPLITS;
   return align_up((size_t)N * D * oibl_elem_size(precision), 256) +
          align_up((size_t)s * N * d * sizeof(float), 256) +
          align_up((size_t)N * ((d + 255) / 256) * sizeof(float), 256);
@@ -250,9 +350,63 @@ int oibl_pca_forward(const float* v, int N, int D, const void* w, const float* b
   return OIBL_OK;
 }
 
+int oibl_pca_pack_weight(const float* w, int D, int d, float* packed, void* stream) {
+  OIBL_REQUIRE(w && packed, "pca_pack_weight: null pointer");
+  OIBL_REQUIRE(D > 0 && d > 0 && D % 8 == 0 && d % 32 == 0, "pca_pack_weight: unsupported shape D=%d d=%d", D, d);
+  OIBL_REQUIRE((uintptr_t)w % 16 == 0 && (uintptr_t)packed % 16 == 0, "pca_pack_weight: pointers must be 16-byte aligned");
+  const size_t units = (size_t)d * D / 4;
+  const unsigned grid = (unsigned)std::min<size_t>((units + 255) / 256, 65536);
+  hipLaunchKernelGGL(pca_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, packed, D, units);
+  OIBL_LAUNCH_CHECK();
+  return OIBL_OK;
+}
+
+int oibl_pca_packed_supported(int N, int D, int d) { return pca_stream_ok(N, D, d) && g_pca_stream ? 1 : 0; }
+
+int oibl_pca_forward_packed(const float* v, int N, int D, const float* w_packed, const float* b, int d, int l2norm,
+                            float* out, void* ws, size_t ws_bytes, void* stream) {
+  OIBL_REQUIRE(v && w_packed && b && out && ws, "pca_packed: null pointer");
+  OIBL_REQUIRE(pca_stream_ok(N, D, d) && g_pca_stream,
+               "pca_packed: unsupported shape N=%d D=%d d=%d (1 <= N <= %d, d %% %d == 0, D %% %d == 0; "
+               "oibl_pca_packed_supported)", N, D, d, PK_MAXN, 32 * PK_WAVES, PK_SPLITS * PK_CHUNK);
+  OIBL_REQUIRE((uintptr_t)ws % 256 == 0 && (uintptr_t)w_packed % 16 == 0 && (uintptr_t)v % 16 == 0,
+               "pca_packed: workspace must be 256-byte, w_packed and v 16-byte aligned");
+  const size_t need = oibl_pca_workspace_bytes(N, D, d, OIBL_F32);
+  if (ws_bytes < need) {
+    set_error("pca_packed: workspace %zu < required %zu bytes", ws_bytes, need);
+    return OIBL_E_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  char* wsb = (char*)ws;
+  float* part = (float*)(wsb + align_up((size_t)N * D * sizeof(float), 256));
+  const dim3 grid((unsigned)(d / (32 * PK_WAVES)), PK_SPLITS);
+  // 8 loads in flight x 4 waves per SIMD (104 VGPRs) against 16 x 2 (173): 109.8 against 112.8 us at 32 rows, 92.7
+  // against 95.5 at 3 (tests/gpu_pca_bench.py; all three launches)
+  if (g_pca_stream == 2)
+    hipLaunchKernelGGL((pca_stream_kernel<16, 2>), grid, dim3(PK_WAVES * 64), 0, st, v, w_packed, part, N, D, d,
+                       D / PK_SPLITS);
+  else
+    hipLaunchKernelGGL((pca_stream_kernel<8, 4>), grid, dim3(PK_WAVES * 64), 0, st, v, w_packed, part, N, D, d,
+                       D / PK_SPLITS);
+  OIBL_LAUNCH_CHECK();
+  float* ss_part = (float*)((char*)part + align_up((size_t)PK_SPLITS * N * d * sizeof(float), 256));
+  const dim3 rgrid((unsigned)((d + 255) / 256), (unsigned)N);
+  hipLaunchKernelGGL(pca_reduce_kernel, rgrid, dim3(256), 0, st, part, b, out, ss_part, N, d, PK_SPLITS);
+  OIBL_LAUNCH_CHECK();
+  if (l2norm) {
+    hipLaunchKernelGGL(pca_scale_kernel, rgrid, dim3(256), 0, st, out, ss_part, d);
+    OIBL_LAUNCH_CHECK();
+  }
+  return OIBL_OK;
+}
+
 #ifdef OIBL_DEBUG_HOOKS
 int oibl_debug_set_pca_small(int on) {
   g_pca_small = on ? 1 : 0;
+  return OIBL_OK;
+}
+int oibl_debug_set_pca_stream(int on) {
+  g_pca_stream = on;
   return OIBL_OK;
 }
 #endif

@@ -60,6 +60,10 @@ SIGNATURES = {
     "oibl_pca_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "oibl_pca_forward": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                                  c_void_p, c_void_p, c_size_t, c_void_p]),
+    "oibl_pca_pack_weight": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "oibl_pca_packed_supported": (c_int, [c_int, c_int, c_int]),
+    "oibl_pca_forward_packed": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                                        c_void_p, c_void_p, c_size_t, c_void_p]),
     "oibl_l2_normalize_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "oibl_sum_l2_normalize": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "oibl_pairwise_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
@@ -137,6 +141,7 @@ _HOOKS = {"oibl_debug_set_regstage": (c_int, [c_int]),
           "oibl_debug_set_match_group": (c_int, [c_int]),
           "oibl_debug_set_match_splitk": (c_int, [c_int]),
           "oibl_debug_set_pca_small": (c_int, [c_int]),
+          "oibl_debug_set_pca_stream": (c_int, [c_int]),
           "oibl_debug_set_netvlad_slabs": (c_int, [c_int]),
           "oibl_debug_set_ring_bar1": (c_int, [c_int]),
           "oibl_debug_set_ring_stagger": (c_int, [c_int]),
@@ -168,7 +173,7 @@ _HOOK_DEFAULTS = {"oibl_debug_set_regstage": 0, "oibl_debug_set_conv11_valu": 0,
                   "oibl_debug_set_match_ring": 1, "oibl_debug_set_ring_ablate": 0, "oibl_debug_set_ring_raster": 0,
                   "oibl_debug_set_conv_korder": -1, "oibl_debug_set_mx_variant": 0, "oibl_debug_set_conv_splitk": 1,
                   "oibl_debug_set_stem3_prio": 0, "oibl_debug_set_match_group": 4, "oibl_debug_set_match_splitk": 1,
-                  "oibl_debug_set_pca_small": 1, "oibl_debug_set_netvlad_slabs": 1,
+                  "oibl_debug_set_pca_small": 1, "oibl_debug_set_pca_stream": 1, "oibl_debug_set_netvlad_slabs": 1,
                   "oibl_debug_set_ring_bar1": 1, "oibl_debug_set_ring_stagger": 0, "oibl_debug_set_match_bar1": 1, "oibl_debug_set_match_mx_early": 1, "oibl_debug_set_mx_splitk": 1, "oibl_debug_set_stem_u8": 1,
                   "oibl_debug_set_prof_buffer": None}
 

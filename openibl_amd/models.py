@@ -323,7 +323,7 @@ class EmbedNetPCA(_PrecisionMixin, nn.Module):
         hit = self._cache.get("pca")
         if hit is None or hit[0] != key:
             w2 = w.detach().float().reshape(w.shape[0], -1).contiguous()
-            self._cache["pca"] = (key, ops.cast(w2, self.precision), b.detach().float().contiguous())
+            self._cache["pca"] = (key, ops.PcaWeight(ops.cast(w2, self.precision)), b.detach().float().contiguous())
             hit = self._cache["pca"]
         return hit[1], hit[2]
 

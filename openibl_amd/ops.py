@@ -477,8 +477,37 @@ def netvlad(feat: torch.Tensor, assign_w: torch.Tensor, centroids: torch.Tensor,
 
 
 # ---- PCA --------------------------------------------------------------------------------------
-def pca(v: torch.Tensor, w: torch.Tensor, b: torch.Tensor, l2norm: bool = True) -> torch.Tensor:
-    """normalize(W v + b): v [N][D] fp32, w [d][D] bf16|fp32 (selects the precision), b [d] fp32."""
+class PcaWeight:
+    """A PCA weight [d][D] resident on the device, with — fp32 only — the re-packed copy the streaming kernel
+    reads (oibl_pca_pack_weight; made on first use by a batch of 3 .. 32 rows, a second d * D * 4 bytes)."""
+
+    def __init__(self, rows: torch.Tensor):
+        if rows.dim() != 2 or rows.dtype not in (torch.bfloat16, torch.float32) or not rows.is_contiguous():
+            raise ValueError("PcaWeight: a contiguous bf16 or fp32 [d][D] tensor")
+        self.rows = rows
+        self._packed = None
+
+    def packed(self) -> torch.Tensor:
+        if self._packed is None:
+            w = self.rows
+            dev = _need_cuda(w)
+            if w.dtype != torch.float32:
+                raise ValueError("PcaWeight.packed: fp32 weights only")
+            d, D = map(int, w.shape)
+            out = torch.empty_like(w)
+            _lib.check(_lib.load().oibl_pca_pack_weight(_ptr(w), D, d, _ptr(out), _stream(dev)), "pca_pack_weight")
+            self._packed = out
+        return self._packed
+
+
+PCA_STREAM_MIN_ROWS = 3      # one or two rows: the row-major streaming kernel (pca_small_kernel) is as fast
+
+
+def pca(v: torch.Tensor, w, b: torch.Tensor, l2norm: bool = True) -> torch.Tensor:
+    """normalize(W v + b): v [N][D] fp32, w [d][D] bf16|fp32 (selects the precision) or a PcaWeight, b [d] fp32."""
+    holder = w if isinstance(w, PcaWeight) else None
+    if holder is not None:
+        w = holder.rows
     dev = _need_cuda(v, w, b)
     if w.dtype not in (torch.bfloat16, torch.float32):
         raise ValueError("pca: weight must be bf16 or fp32")
@@ -493,6 +522,10 @@ def pca(v: torch.Tensor, w: torch.Tensor, b: torch.Tensor, l2norm: bool = True) 
     ws_bytes = lib.oibl_pca_workspace_bytes(N, D, d, p)
     ws = workspace(ws_bytes, dev, "pca")
     out = torch.empty((N, d), dtype=torch.float32, device=dev)
+    if (holder is not None and p == F32 and N >= PCA_STREAM_MIN_ROWS and lib.oibl_pca_packed_supported(N, D, d)):
+        _lib.check(lib.oibl_pca_forward_packed(_ptr(v), N, D, _ptr(holder.packed()), _ptr(b), d, int(l2norm),
+                                               _ptr(out), _ptr(ws), ws.numel(), _stream(dev)), "pca_forward_packed")
+        return out
     _lib.check(lib.oibl_pca_forward(_ptr(v), N, D, _ptr(w), _ptr(b), d, p, int(l2norm), _ptr(out),
                                     _ptr(ws), ws.numel(), _stream(dev)), "pca_forward")
     return out

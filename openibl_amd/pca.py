@@ -138,7 +138,7 @@ class PCA:
             if pad:
                 w2 = torch.cat([w2, w2.new_zeros((pad, w2.shape[1]))]).contiguous()
                 b = torch.cat([b, b.new_zeros(pad)]).contiguous()
-            self._w_dev = (key, ops.cast(w2, prec), b)
+            self._w_dev = (key, ops.PcaWeight(ops.cast(w2, prec)), b)
         return self._w_dev[1], self._w_dev[2]
 
     def infer(self, data: torch.Tensor) -> torch.Tensor:

@@ -29,3 +29,26 @@ for N in (1, 2, 4, 8, 32):
         row.append(f"{'streaming' if small else 'MFMA tile'} {t * 1e3:7.1f} us ({w.numel() * 4 / t / 1e9:5.2f} TB/s)")
     print(f"N={N:2d}: " + " | ".join(row))
 L.oibl_debug_set_pca_small(1)
+pw = ops.PcaWeight(w)
+for N in (1, 3, 8, 16, 32):
+    v = torch.nn.functional.normalize(torch.randn((N, 32768), device=dev), dim=1)
+    row = []
+    for variant in (1, 2):
+        L.oibl_debug_set_pca_stream(variant)
+        old = ops.PCA_STREAM_MIN_ROWS
+        ops.PCA_STREAM_MIN_ROWS = 1
+        for _ in range(5):
+            ops.pca(v, pw, b)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(50):
+            ops.pca(v, pw, b)
+        e.record()
+        torch.cuda.synchronize()
+        ops.PCA_STREAM_MIN_ROWS = old
+        t = s.elapsed_time(e) / 50
+        row.append(f"packed stream, {'8 loads x 4 waves' if variant == 1 else '16 loads x 2 waves'} per SIMD "
+                   f"{t * 1e3:7.1f} us ({w.numel() * 4 / t / 1e9:5.2f} TB/s)")
+    print(f"N={N:2d}: " + " | ".join(row))
+L.oibl_debug_set_pca_stream(1)

@@ -222,7 +222,7 @@ def test_hot_kernels_stay_inside_their_register_budgets():
         scratch, vgprs = u.get("ScratchSize", 0), u.get("VGPRs", 0) + u.get("AGPRs", 0)
         if any(k in name for k in ("conv3x3_ring_kernel", "pairwise_ring_kernel", "vgg_stem_kernel",
                                    "conv3x3_halo_kernel", "conv3x3_halo4_kernel", "pairwise_f16r_kernel",
-                                   "pca_small_kernel")):
+                                   "pca_small_kernel", "pca_stream_kernel")):
             assert scratch == 0 and vgprs <= 256, (name, u)
             seen.add(re.sub(r"I.*", "", name))
         elif "vgg_stem_x3_kernel" in name:
@@ -269,6 +269,9 @@ def test_hot_kernels_hold_exactly_their_matrix_instructions():
     assert len(halo4) == 2 and all(t["mfma"] == 432 and t["bytes"] < 64 * 1024 for t in halo4.values()), halo4
     f16r = {n: t for n, t in text.items() if "pairwise_f16r_kernel" in n and not n.endswith(".kd")}
     assert len(f16r) == 4 and all(t["mfma"] == (256 if re.search(r"ELb1EEE", n) else 128) for n, t in f16r.items()), f16r
+    # the packed PCA stream: 32 tiles x 4 k-pairs per chunk, a generic and a last-chunk body
+    pk = {n: t for n, t in text.items() if "pca_stream_kernel" in n and not n.endswith(".kd")}
+    assert pk and all(t["mfma"] == 256 for t in pk.values()), pk
     halo = {n: t for n, t in text.items() if "conv3x3_halo_kernel" in n and not n.endswith(".kd")}
     assert halo and all(t["mfma"] == (864 if re.search(r"ELb1EEE", n) else 432) for n, t in halo.items()), halo
     stems = {n: t["mfma"] for n, t in text.items() if "vgg_stem" in n and not n.endswith(".kd")}

@@ -91,6 +91,51 @@ def test_pca_few_rows_streaming_kernel(dev):
     assert_rel_l2("streaming kernel vs MFMA tile", outs[2].cpu(), tile.cpu(), 2e-6)
 
 
+def test_pca_packed_weight_streaming_kernel(dev):
+    """3 .. 32 rows in fp32 through an `ops.PcaWeight` stream the re-packed weight (oibl_pca_forward_packed):
+    the oracle's numbers, the row-major tile's up to the association of the fp32 sums, a row's result independent
+    of its batch mates, repeatable; 33 rows and bf16 weights keep the tile; a smaller shape the C entry serves."""
+    from openibl_amd import lib
+    sd = synth.pca_state(0)
+    w = sd["pca_layer.weight"].reshape(4096, 32768).to(dev)
+    b = sd["pca_layer.bias"].to(dev)
+    g = torch.Generator().manual_seed(78)
+    v = torch.nn.functional.normalize(torch.randn((33, 32768), generator=g), dim=1).to(dev)
+    want = od.pca_project(v.cpu().double(), w.cpu().double(), b.cpu().double())
+    pw = ops.PcaWeight(w)
+    assert pw._packed is None
+    outs = {n: ops.pca(v[:n].contiguous(), pw, b) for n in (2, 3, 7, 32, 33)}
+    assert pw._packed is not None and pw._packed.shape == w.shape
+    for n, o in outs.items():
+        assert_rel_l2(f"pca packed N={n}", o.cpu(), want[:n], 5e-6)
+    tile = {n: ops.pca(v[:n].contiguous(), w, b) for n in (2, 3, 7, 32, 33)}
+    for n in (2, 33):
+        assert torch.equal(outs[n], tile[n])                       # outside 3 .. 32 the holder changes nothing
+    for n in (3, 7, 32):
+        assert not torch.equal(outs[n], tile[n])                   # (the other kernel did run)
+        assert_rel_l2(f"packed vs tile N={n}", outs[n].cpu(), tile[n].cpu(), 2e-6)
+    assert torch.equal(outs[3], outs[32][:3]) and torch.equal(outs[7], outs[32][:7])
+    assert torch.equal(ops.pca(v[:32].contiguous(), pw, b), outs[32])
+    raw = ops.pca(v[:7].contiguous(), pw, b, l2norm=False)
+    assert_rel_l2("packed, without normalize", torch.nn.functional.normalize(raw.cpu().double(), dim=1), want[:7], 5e-6)
+    # the second instantiation (16 loads in flight, 2 waves per SIMD): same sums in the same order
+    lib.debug_hooks().oibl_debug_set_pca_stream(2)
+    try:
+        assert torch.equal(ops.pca(v[:32].contiguous(), pw, b), outs[32])
+        lib.debug_hooks().oibl_debug_set_pca_stream(0)
+        assert torch.equal(ops.pca(v[:7].contiguous(), pw, b), tile[7])    # hook 0: the packed form is not offered
+    finally:
+        lib.debug_hooks().oibl_debug_set_pca_stream(1)
+    pb = ops.PcaWeight(ops.cast(w, "bf16"))
+    assert torch.equal(ops.pca(v[:7].contiguous(), pb, b), ops.pca(v[:7].contiguous(), pb.rows, b)) and pb._packed is None
+    # the smallest shape of the packed form: D = 8192, d = 256
+    w2 = torch.randn((256, 8192), generator=g).to(dev) * 0.01
+    b2 = torch.randn(256, generator=g).to(dev) * 0.1
+    v2 = torch.randn((5, 8192), generator=g).to(dev)
+    got = ops.pca(v2, ops.PcaWeight(w2), b2)
+    assert_rel_l2("packed 8192 -> 256", got.cpu(), od.pca_project(v2.cpu().double(), w2.cpu().double(), b2.cpu().double()), 5e-6)
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_netvlad_pixel_slabs_for_few_images(dev, precision):
     """Five launches (bf16 maps; fp32 maps of up to four images): up to four images the aggregation is split over the pixels (4 slabs, added
