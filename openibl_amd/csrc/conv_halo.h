@@ -68,6 +68,7 @@ struct HaloParams {
   int relu, out_f32;
   unsigned* range_flag;      // raised when an output is beyond fp16 (common.h, mx_raise_range_flag); may be null
   unsigned long long* prof;  // test hook (debug library, conv_halo4.h): per-workgroup stamps, tests/gpu_halo4_phase.py
+  float bias_mul = 1.f, out_mul = 1.f;   // the f16mx backbone's activation scale (conv_ring.h, RingParams)
 };
 
 // one phase's matrix work on two 32x32 accumulator tiles (ring_core.h, compute)
@@ -312,7 +313,7 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloParams& p, char* sme
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     if constexpr (POOL) {
-      float b = p.bias[n0 + wn * 64 + j * 32 + (lane & 31)];
+      float b = p.bias[n0 + wn * 64 + j * 32 + (lane & 31)] * p.bias_mul;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -323,7 +324,8 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloParams& p, char* sme
     } else {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 b = *reinterpret_cast<const float4*>(p.bias + n0 + wn * 64 + j * 32 + 8 * g + 4 * (lane >> 5));
+        float4 b = *reinterpret_cast<const float4*>(p.bias + n0 + wn * 64 + j * 32 + 8 * g + 4 * (lane >> 5));
+        b = make_float4(b.x * p.bias_mul, b.y * p.bias_mul, b.z * p.bias_mul, b.w * p.bias_mul);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           acc[i][j][4 * g] = b.x;
@@ -433,6 +435,14 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloParams& p, char* sme
   }
   wait_vmcnt<0>();  // (sink writes of the last dummies)
   __syncthreads();
+  if (p.out_mul != 1.f) {   // (uniform; the layer handing the fp32 map to the head: conv_ring.h)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= p.out_mul;
+  }
 
   // ---- epilogue: as the f16mx ring kernel's (conv_ring.h) — fp32 staging with the chunk swizzle, one
   //      thread per (row, 32-channel group) packs its f16mx line in place, full lines out — except that

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(H4_THREADS, 2) void conv3x3_halo4_kernel(HaloParams
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     if constexpr (POOL) {
-      float b = p.bias[n0 + wn * 64 + j * 32 + (lane & 31)];
+      float b = p.bias[n0 + wn * 64 + j * 32 + (lane & 31)] * p.bias_mul;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -244,7 +244,8 @@ __global__ __launch_bounds__(H4_THREADS, 2) void conv3x3_halo4_kernel(HaloParams
     } else {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 b = *reinterpret_cast<const float4*>(p.bias + n0 + wn * 64 + j * 32 + 8 * g + 4 * (lane >> 5));
+        float4 b = *reinterpret_cast<const float4*>(p.bias + n0 + wn * 64 + j * 32 + 8 * g + 4 * (lane >> 5));
+        b = make_float4(b.x * p.bias_mul, b.y * p.bias_mul, b.z * p.bias_mul, b.w * p.bias_mul);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           acc[i][j][4 * g] = b.x;

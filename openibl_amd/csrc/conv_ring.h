@@ -47,6 +47,10 @@ struct RingParams {
   int raster;   // xcd_tile() mode
   int korder;   // 0 = (tap, channel chunk), 1 = (channel chunk, tap): see ConvRingALoader::begin_tile
   unsigned* range_flag;  // f16mx output: raised when an output is beyond fp16 (common.h, mx_raise_range_flag); may be null
+  // Activation scale of the f16mx backbone (conv.hip, g_mx_act_shift): the accumulators start at bias * bias_mul, and
+  // out_mul != 1 (the layer that hands the fp32 map to the head) multiplies them once behind the loop.  Both 1
+  // for a stand-alone layer.
+  float bias_mul = 1.f, out_mul = 1.f;
   // Row / K sub-ranges (all zero: the whole problem in one pass).  A launch covers the GEMM rows from m_base
   // on (tiles_m tiles of them); with nsteps_part != 0 it is a SPLIT-K launch: workgroup (tile, blockIdx.y)
   // contracts nsteps_part K-tiles starting at OUTER K index blockIdx.y * k_outer_step (outer = tap in K order
@@ -292,7 +296,7 @@ __device__ __forceinline__ void conv3x3_ring_body(const RingParams& p, char* sme
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     if constexpr (POOL) {
-      float b = p.bias[n0 + wn * 64 + j * 32 + (lane & 31)];
+      float b = p.bias[n0 + wn * 64 + j * 32 + (lane & 31)] * p.bias_mul;
       b = splitk ? 0.f : b;   // (split-K partials start from zero: the reduction adds the bias)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -306,6 +310,7 @@ __device__ __forceinline__ void conv3x3_ring_body(const RingParams& p, char* sme
       for (int g = 0; g < 4; ++g) {
         float4 b =
             *reinterpret_cast<const float4*>(p.bias + n0 + wn * 64 + j * 32 + 8 * g + 4 * (lane >> 5));
+        b = make_float4(b.x * p.bias_mul, b.y * p.bias_mul, b.z * p.bias_mul, b.w * p.bias_mul);
         if (splitk) b = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -322,6 +327,14 @@ __device__ __forceinline__ void conv3x3_ring_body(const RingParams& p, char* sme
   ring_mainloop<WM, ODD, !POOL, P, BAR1, GROUP>(acc, smem, wave, lane, la, lb, nsteps,
                                                 (P == RING_MX_PROF && blockIdx.x == 0 && p.prof) ? p.prof + 8 : nullptr);
   // (the main loop ends on a workgroup barrier: the staging LDS is free for the epilogue)
+  if (p.out_mul != 1.f) {   // (uniform; one layer of the f16mx backbone)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= p.out_mul;
+  }
   const unsigned long long t_epi = prof ? __builtin_amdgcn_s_memtime() : 0;
   if (wgprof) p.prof[64 + 4 * (size_t)blockIdx.x + 3] = __builtin_amdgcn_s_memtime();
 

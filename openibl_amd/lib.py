@@ -142,6 +142,7 @@ _HOOKS = {"oibl_debug_set_regstage": (c_int, [c_int]),
           "oibl_debug_set_match_splitk": (c_int, [c_int]),
           "oibl_debug_set_pca_small": (c_int, [c_int]),
           "oibl_debug_set_pca_stream": (c_int, [c_int]),
+          "oibl_debug_set_mx_act_shift": (c_int, [c_int]),
           "oibl_debug_set_netvlad_slabs": (c_int, [c_int]),
           "oibl_debug_set_ring_bar1": (c_int, [c_int]),
           "oibl_debug_set_ring_stagger": (c_int, [c_int]),
@@ -173,7 +174,7 @@ _HOOK_DEFAULTS = {"oibl_debug_set_regstage": 0, "oibl_debug_set_conv11_valu": 0,
                   "oibl_debug_set_match_ring": 1, "oibl_debug_set_ring_ablate": 0, "oibl_debug_set_ring_raster": 0,
                   "oibl_debug_set_conv_korder": -1, "oibl_debug_set_mx_variant": 0, "oibl_debug_set_conv_splitk": 1,
                   "oibl_debug_set_stem3_prio": 0, "oibl_debug_set_match_group": 4, "oibl_debug_set_match_splitk": 1,
-                  "oibl_debug_set_pca_small": 1, "oibl_debug_set_pca_stream": 1, "oibl_debug_set_netvlad_slabs": 1,
+                  "oibl_debug_set_pca_small": 1, "oibl_debug_set_pca_stream": 1, "oibl_debug_set_mx_act_shift": 3, "oibl_debug_set_netvlad_slabs": 1,
                   "oibl_debug_set_ring_bar1": 1, "oibl_debug_set_ring_stagger": 0, "oibl_debug_set_match_bar1": 1, "oibl_debug_set_match_mx_early": 1, "oibl_debug_set_mx_splitk": 1, "oibl_debug_set_stem_u8": 1,
                   "oibl_debug_set_prof_buffer": None}
 

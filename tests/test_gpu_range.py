@@ -74,6 +74,11 @@ def test_one_layer_at_three_magnitudes(dev, cin, cout, pool, xpeak, wgain, over)
     assert_rel_l2("bf16x3 layer", ops.x3_join(g3).permute(0, 3, 1, 2).cpu(), want, 1e-5)
 
 
+# The f16mx backbone stores its activations multiplied by 2^-3 (conv.hip, g_mx_act_shift): the fp16 bound sits at
+# 65504 * 8 = 5.2e5 in activation units.
+ACT_HEADROOM = 8.0
+
+
 def _scaled(sd, c):
     """The same network on inputs c times as large: conv is linear, ReLU and max-pool are positively
     homogeneous, so scaling the input and every bias by c scales every activation by c — and NetVLAD
@@ -94,11 +99,12 @@ def _model(sd, dev, precision="f16mx"):
     return model
 
 
-@pytest.mark.parametrize("c,over", [(10.0, False), (300.0, False), (2000.0, True)])
+@pytest.mark.parametrize("c,over", [(10.0, False), (300.0, False), (2000.0, False), (2000.0 * ACT_HEADROOM, True)])
 def test_descriptor_at_three_magnitudes(dev, state_dict, c, over):
-    """The whole 480x640 descriptor with activations that reach ~1e3, ~3e4 and ~2e5 between the layers: f16mx
-    (with its guard) stays within 1e-4 of the fp64 oracle in all three, the flag — and the bf16x3 re-run — only
-    in the last; eagerly, through the one-lane and the two-lane replay (bit-identical to the eager result)."""
+    """The whole 480x640 descriptor with activations that reach ~1e3, ~3e4, ~2e5 and ~1.3e6 between the layers: f16mx
+    (with its guard) stays within 1e-4 of the fp64 oracle in all four, the flag — and the bf16x3 re-run — only
+    in the last (2e5 is beyond fp16 but inside the scaled format); eagerly, through the one-lane and the two-lane
+    replay (bit-identical to the eager result)."""
     sd = _scaled(state_dict, c)
     x = synth.images(2, 480, 640, seed=77) * c
     with torch.no_grad():
@@ -106,7 +112,7 @@ def test_descriptor_at_three_magnitudes(dev, state_dict, c, over):
         want = inter["desc"]
         peak = max(float(od.vgg16_conv5(x[:1].double(), sd, upto=u).max()) for u in (2, 4, 7, 10))
     print(f"scale {c:g}: activation peak behind conv1_2 / 2_2 / 3_3 / 4_3: {peak:.3g}")
-    assert (peak > 1e5) if over else (peak < 5e4)
+    assert (peak > 65504 * ACT_HEADROOM * 1.5) if over else (peak < 65504 * ACT_HEADROOM / 2)
     model = _model(sd, dev)
     vgg = model.base_model
     xd = x.to(dev)
@@ -137,11 +143,40 @@ def test_descriptor_at_three_magnitudes(dev, state_dict, c, over):
         assert fwd.range_fallbacks == (3 if over else 0)
 
 
+def test_activation_scale_is_an_exact_image(dev, state_dict):
+    """The backbone's stored activations are the unscaled ones times 2^-3 (test hook: 0 = unscaled).  A power of
+    two commutes with every rounding of the format, so at the reference's input scale (activations in the tens to
+    thousands: images and biases x 100 here) the fp32 map handed to the head is the unscaled pass's, bit for bit —
+    at batch 2 (ring / halo kernels) and for one small image (row sub-ranges + split-K: the reduction kernel
+    scales).  On unit-range images the synthetic state's activations are ~1e-2: values below fp16's normal range
+    after scaling (|x| < 5e-4) lose bits, and the map moves by a fraction of the format's own error."""
+    from openibl_amd import lib
+    for c, shape in [(100.0, (2, 480, 640)), (100.0, (1, 96, 128)), (1.0, (2, 96, 128))]:
+        model = _model(_scaled(state_dict, c), dev)
+        vgg = model.base_model
+        x = (synth.images(*shape, seed=79) * c).to(dev)
+        ws, bs = vgg._packed(x.device, "f16mx")
+        product = ops.vgg16_conv5(x, ws, bs, "f16mx").clone()
+        hooks = lib.debug_hooks()                      # (from here on the debug library computes)
+        try:
+            scaled = ops.vgg16_conv5(x, ws, bs, "f16mx").clone()
+            hooks.oibl_debug_set_mx_act_shift(0)
+            plain = ops.vgg16_conv5(x, ws, bs, "f16mx").clone()
+        finally:
+            hooks.oibl_debug_set_mx_act_shift(3)
+        assert torch.equal(product, scaled)            # the product library's constant is the hook's default
+        d = rel_l2(scaled.cpu(), plain.cpu().double())
+        same = float((scaled == plain).float().mean())
+        print(f"{shape} x {c:g}: map mean {float(plain.mean()):.3g}; scaled against unscaled activations: rel-L2 "
+              f"{d:.2e}, {same:.4f} of the map bit-equal")
+        assert (same > 0.999 and d < 1e-7) if c > 1 else d < 1.5e-5
+
+
 @pytest.mark.parametrize("layer", [4, 8])     # conv3_1 (halo kernel), conv4_2 (256 x 256 ring kernel)
 def test_overflow_in_one_deep_layer_only(dev, state_dict, layer):
-    """conv3_1 / conv4_2 scaled up by 3000 and the next layer down by as much: only that layer's output
-    leaves the fp16 range (the stem and everything else stay at ~100)."""
-    s = 3000.0
+    """conv3_1 / conv4_2 scaled up by 24000 and the next layer down by as much: only that layer's output
+    leaves the format's range (the stem and everything else stay at ~100)."""
+    s = 3000.0 * ACT_HEADROOM
     sd = copy.copy(state_dict)
     i0, i1 = synth.CONV_IDX[layer], synth.CONV_IDX[layer + 1]
     sd[f"base_model.base.{i0}.weight"] = state_dict[f"base_model.base.{i0}.weight"] * s
@@ -244,7 +279,7 @@ def test_extract_features_reruns_only_the_flagged_batches(dev, state_dict):
 
 
 def _extract_flow(dev, state_dict, ev, _GRAPH_STORES, unwrap_model):
-    sd = _scaled(state_dict, 2000.0)
+    sd = _scaled(state_dict, 2000.0 * ACT_HEADROOM)
     model = _model(sd, dev)
 
     class Loader:
@@ -261,7 +296,7 @@ def _extract_flow(dev, state_dict, ev, _GRAPH_STORES, unwrap_model):
     big = {1, 2, 5, 8}                                     # these batches leave the fp16 range
     batches = []
     for k in range(10):
-        x = synth.images(3, 64, 96, seed=900 + k) * (2000.0 if k in big else 1.0)
+        x = synth.images(3, 64, 96, seed=900 + k) * (2000.0 * ACT_HEADROOM if k in big else 1.0)
         batches.append((x.pin_memory() if k % 3 else x, [f"b{k}_{i}" for i in range(3)]))   # every third one pageable
     names = [(f, 0, 0.0, 0.0) for b in batches for f in b[1]]
     feats = ev.extract_features(model, Loader(batches), names, gpu=dev.index)
