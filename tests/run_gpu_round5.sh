@@ -36,6 +36,9 @@ if [ -z "$QUICK" ]; then
   timeout 300 python bench.py --sustain 12 --precision f16mx 2>> $OUT/bench_err.log > $OUT/sustain_f16mx.json
   timeout 300 python bench.py --sustain 12 --precision bf16 2>> $OUT/bench_err.log > $OUT/sustain_bf16.json
   timeout 200 python tests/gpu_halo4_phase.py 2>&1 | grep -v amdgpu.ids | tee $OUT/halo4_phase.log
+  timeout 200 python tests/gpu_head_bench.py 2>&1 | grep -v amdgpu.ids | tee $OUT/head_bench.log
+  timeout 200 python tests/gpu_pca_bench.py 2>&1 | grep -v amdgpu.ids | tee $OUT/pca_bench.log
+  timeout 200 python tests/gpu_scale_probe2.py 2>&1 | grep -v amdgpu.ids | tee $OUT/scale_probe.log
 fi
 cd /tmp && export TMPDIR=/tmp
 # --no-pipeline: one lane, so that the per-kernel durations are those of the roofline's span leg
