@@ -70,7 +70,7 @@ def main():
                     + "\n".join(l[:600] for l in (d / "bench_2ranks_shared.json").read_text().splitlines()
                                 if l.startswith("{")) + "\n\n")
         for n in ("gpu.txt", "precbench.log", "matchbench.log", "halo4_phase.log", "bar1_ab.log", "stem_mx.log", "mx_stamps.log", "mx_probe.log", "timing_bf16x3.log", "timing_bf16.log", "timing_bf16x3_raster1.log",
-                  "timing_bf16_raster1.log", "timing_fp32.log", "pcie.log", "convbench.log", "shardbench.log"):
+                  "timing_bf16_raster1.log", "timing_fp32.log", "pcie.log", "convbench.log", "shardbench.log", "head_bench.log", "pca_bench.log", "scale_probe.log"):
             if (d / n).exists():
                 f.write(f"==== {n}\n" + (d / n).read_text() + "\n")
         if (d / "pytest_gpu.log").exists():
@@ -197,7 +197,7 @@ def traffic_table(fp, wp, prof, tag, prec):
         # matrix-core convolution launches, averaged per launch
         tot_b, tot_n, forwards = 0.0, 0, 0
         for k, (n, v, t) in fe.items():
-            if not any(tag_ in k for tag_ in ("conv3x3_ring_kernel", "conv3x3_halo_kernel", "mx_pack_rows_kernel", "vgg_stem_kernel",
+            if not any(tag_ in k for tag_ in ("conv3x3_ring_kernel", "conv3x3_halo_kernel", "conv3x3_halo4_kernel", "mx_pack_rows_kernel", "vgg_stem_kernel",
                                               "vgg_stem_x3_kernel", "conv3x3_igemm_kernel", "conv3x3_c64_kernel",
                                               "conv_mx_splitk_reduce_kernel", "conv_mx_splitk_reduce8_kernel",
                                               "conv_splitk_reduce_kernel")):
