@@ -243,9 +243,12 @@ int oibl_vgg16_stem_mx(const float* x_nchw, int N, int H, int W, const float* w1
  * activation — conv2_2's input, N (H/2) (W/2) 128 x 4 bytes: 95 images of 480x640 — reaches 3.5 GB is
  * refused with OIBL_E_INVALID); `feat` is plain fp32.  The FIRST
  * 32-BIT WORD OF THE WORKSPACE is the pass's range flag: zeroed (stream-ordered) when the call starts,
- * 1 afterwards if any activation between the layers was beyond +-65504 — `feat` is then not a 1e-4 result
- * and the batch has to be repeated in OIBL_BF16X3 (see OIBL_F16MX at the top).  The other precisions leave
- * the word untouched.
+ * 1 afterwards if any activation between the layers was beyond the format's range — `feat` is then not a 1e-4
+ * result and the batch has to be repeated in OIBL_BF16X3 (see OIBL_F16MX at the top).  The whole-backbone
+ * entry points store their intermediate activations multiplied by 1/8 (exact: a power of two, undone in the
+ * layer that writes `feat`), so that the bound is 8 x 65504 = 5.2e5 in activation units; the stand-alone
+ * layer entries (oibl_conv3x3_nhwc*) store what they compute, bound 65504.  The other precisions leave the
+ * word untouched.
  * The workspace holds the range flag, the two ping-pong activation buffers and the fp32 partial tiles of
  * the layers that run split-K: a layer whose tiling leaves most of the chip idle (small batches), and in
  * OIBL_F16MX also the tiles of a nearly empty LAST ROUND of a big layer (conv5_x at batch 32: 300 tiles on
