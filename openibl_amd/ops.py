@@ -490,9 +490,9 @@ class PcaWeight:
     def packed(self) -> torch.Tensor:
         if self._packed is None:
             w = self.rows
-            dev = _need_cuda(w)
             if w.dtype != torch.float32:
                 raise ValueError("PcaWeight.packed: fp32 weights only")
+            dev = _need_cuda(w)
             d, D = map(int, w.shape)
             out = torch.empty_like(w)
             _lib.check(_lib.load().oibl_pca_pack_weight(_ptr(w), D, d, _ptr(out), _stream(dev)), "pca_pack_weight")

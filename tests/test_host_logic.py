@@ -493,3 +493,25 @@ def test_effective_precision_and_its_counters_host_side():
     m.set_precision("bf16")
     m.invalidate()
     assert m._cache_gen == g0 + 2
+
+
+def test_pca_weight_holder_checks_its_argument_and_has_no_cpu_path():
+    """ops.PcaWeight (the PCA weight + its re-packed copy for the streaming kernel): argument checks on the host; the
+    packing and the projection are device work — a CPU tensor is refused loudly, nothing falls back."""
+    import pytest
+    import torch
+    from openibl_amd import lib, ops
+    with pytest.raises(ValueError):
+        ops.PcaWeight(torch.zeros(8))                                   # not [d][D]
+    with pytest.raises(ValueError):
+        ops.PcaWeight(torch.zeros((4, 8), dtype=torch.float64))
+    with pytest.raises(ValueError):
+        ops.PcaWeight(torch.zeros((8, 4)).t())                          # not contiguous
+    w = ops.PcaWeight(torch.zeros((256, 8192)))
+    assert w.rows.shape == (256, 8192) and w._packed is None
+    with pytest.raises(lib.OpenIBLAmdError):
+        w.packed()
+    with pytest.raises(lib.OpenIBLAmdError):
+        ops.pca(torch.zeros((3, 8192)), w, torch.zeros(256))
+    with pytest.raises(ValueError):
+        ops.PcaWeight(torch.zeros((256, 8192), dtype=torch.bfloat16)).packed()   # fp32 weights only
