@@ -336,8 +336,15 @@ def sharded_topk_pipelined(q_local: torch.Tensor, n_total: int, g_local, k: int,
         with torch.cuda.stream(side):
             return fn(*a)
 
+    # The matrix work of sub-block b runs on compute stream b % 2 (the caller's stream and one more): a rank's sub-block
+    # is a non-integral number of rounds of the chip (world 8: 4096 x 10240 = 640 tiles = 2.5 rounds), and the sample
+    # pass / selections in front of and behind the filter pass are latency-bound — side by side, the next sub-block's
+    # work fills both (projection at 8 shards: f16r 4.5x -> 5.0x, bf16 4.9x -> 5.5x, tests/gpu_shardbench.py).
+    lanes = [main, _side_stream(dev, "lane2")] if on_gpu and blocks > 1 else [main]
     if on_gpu:
         side.wait_stream(main)
+        for cs in lanes[1:]:
+            cs.wait_stream(main)
     pending = on_side(gather, *bounds[0])
     ev_g = None
     if on_gpu:
@@ -351,18 +358,22 @@ def sharded_topk_pipelined(q_local: torch.Tensor, n_total: int, g_local, k: int,
             if on_gpu:
                 ev_g = torch.cuda.Event()
                 ev_g.record(side)
+        cs = lanes[b % len(lanes)]
         if on_gpu:
-            main.wait_event(cur_ev)
+            cs.wait_event(cur_ev)
             for t in cur[1:]:
                 if torch.is_tensor(t):
-                    t.record_stream(main)
-        qb = assemble(cur)
-        sets.append(qb)
-        res = stage_main(qb, False)
-        if on_gpu:
-            side.wait_stream(main)
+                    t.record_stream(cs)
+            with torch.cuda.stream(cs):
+                qb = assemble(cur)
+                res = stage_main(qb, False)
+            side.wait_stream(cs)
             for t in res:
                 t.record_stream(side)
+        else:
+            qb = assemble(cur)
+            res = stage_main(qb, False)
+        sets.append(qb)
         out = on_side(stage_side, qb, res, False)
         if on_gpu:
             for t in out:
@@ -370,6 +381,8 @@ def sharded_topk_pipelined(q_local: torch.Tensor, n_total: int, g_local, k: int,
         outs.append(out)
     if on_gpu:
         main.wait_stream(side)
+        for cs in lanes[1:]:
+            main.wait_stream(cs)
     flagged = torch.stack([o[2].reshape(-1).ne(0).any() for o in outs]).tolist()   # the only host synchronisation
     for b in range(blocks):
         if flagged[b]:
@@ -390,10 +403,11 @@ def sharded_topk_pipelined(q_local: torch.Tensor, n_total: int, g_local, k: int,
 _SIDE = {}
 
 
-def _side_stream(dev: torch.device):
-    """One exchange stream per device, created once (streams created at different times may share a
-    hardware queue: extract._lane_streams)."""
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
+def _side_stream(dev: torch.device, role: str = "exchange"):
+    """One stream per device and role ("exchange": the collectives + merges; "lane2": the second compute stream of
+    sharded_topk_pipelined), created once (streams created at different times may share a hardware queue:
+    extract._lane_streams)."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), role)
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=dev)
     return _SIDE[key]

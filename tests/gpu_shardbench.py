@@ -32,12 +32,16 @@ worlds = [int(w) for w in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1, 
 prec = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 base = None
 BLOCKS = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+LANES = int(sys.argv[4]) if len(sys.argv) > 4 else 2     # matrix work of sub-block b on compute stream b % LANES
 print(f"precision {prec}; the gallery shard is resident (ops.PreparedRows); per step the Q / W queries of every rank "
       f"travel in {BLOCKS} sub-blocks — the all_gather of sub-block b + 1 and the list exchange + merge of sub-block b on a "
       f"second stream under the matrix work (sharded.sharded_topk_pipelined, bench.py's schedule) — both collectives "
       f"EMULATED by device copies of the gathered sizes (one GPU here: no xGMI time in these numbers)")
 side = torch.cuda.Stream()
 main = torch.cuda.current_stream()
+mains = [main] + [torch.cuda.Stream() for _ in range(LANES - 1)]
+print(f"matrix work of sub-block b on compute stream b % {LANES}" + (": the tail round of one sub-block's filter pass and the "
+      "latency-bound sample pass / selections of the next run side by side" if LANES > 1 else ""))
 for world in worlds:
     n = G // world
     shard = ops.PreparedRows(gal[:n].contiguous(), prec)
@@ -69,6 +73,8 @@ for world in worlds:
         if world == 1:
             return ops.sqdist_topk_prepared(ops.PreparedRows(q_mine, prec), shard, K, defer_check=True)
         side.wait_stream(main)
+        for cs in mains[1:]:
+            cs.wait_stream(main)
         evs = []
         for b in range(BLOCKS):                         # sharded.sharded_topk_pipelined with device copies as collectives
             if b == 0:
@@ -83,11 +89,16 @@ for world in worlds:
                         ops.PreparedRows(q_mine[:sub], prec)
                     gathered_dst.copy_(gathered_src)    # sub-block b + 1 travels under sub-block b's matrix work
                     e = torch.cuda.Event(); e.record(side); evs.append(e)
-            main.wait_event(evs[b])
-            qb = ops.PreparedRows(q_sub, prec) if rows_travel else p_sub
-            if prec == "f16r":                          # two phases: filter lists first, the rescoring behind the exchange
-                lval, lidx, ymax, flag = ops.f16r_filter_select(qb, shard, K)
-                side.wait_stream(main)
+            cs = mains[b % LANES]
+            cs.wait_event(evs[b])
+            with torch.cuda.stream(cs):
+                qb = ops.PreparedRows(q_sub, prec) if rows_travel else p_sub
+                if prec == "f16r":                      # two phases: filter lists first, the rescoring behind the exchange
+                    lval, lidx, ymax, flag = ops.f16r_filter_select(qb, shard, K)
+                else:
+                    out = ops.sqdist_topk_prepared(qb, shard, K, defer_check=True)
+            side.wait_stream(cs)
+            if prec == "f16r":
                 with torch.cuda.stream(side):
                     f_dst.copy_(f_src)                  # all_gather of the filter lists [world][Qb + 1][2 K2]
                     thr = ops.row_topk(f_vals, K)[0][:, K - 1].contiguous()
@@ -100,11 +111,11 @@ for world in worlds:
                     lists_dst.copy_(lists_src)          # all_gather of the exact lists
                     ops.row_topk(vals, K, idx_in=idx)   # k-way merge
                 continue
-            out = ops.sqdist_topk_prepared(qb, shard, K, defer_check=True)
-            side.wait_stream(main)
             with torch.cuda.stream(side):
                 lists_dst.copy_(lists_src)              # all_gather of this sub-block's lists (gathered size)
                 ops.row_topk(vals, K, idx_in=idx)       # k-way merge
+        for cs in mains[1:]:
+            main.wait_stream(cs)
         main.wait_stream(side)
         return out
     t = timed(step)
