@@ -390,17 +390,18 @@ int oibl_sqdist_topk_prepared(const void* xo, const float* xn, int m, const void
  *       oibl_match_prepare), rows_f16 [rows][d] (IEEE binary16 of x 2^e, e per row), aux [rows][4] fp32 =
  *       {2^-e, |x| rounded up, |x - rows_f16 2^-e| rounded up, 0}.  The fp32 rows themselves are the fourth
  *       part of a prepared operand: they are read again by the rescoring.
- *   oibl_sqdist_topk_f16r : k <= 1024; problems too small for the fused path, exact != 0, and the repeat after
- *       *overflow (device int32, may be NULL: a candidate list outgrew its capacity, or more than 32 (k <= 16;
- *       2k + 32 otherwise) candidates sat within the bound of the k-th distance — near-duplicate galleries)
- *       run fp32 distance tiles + oibl_row_topk on the fp32 rows (what OIBL_F32 runs).                      */
+ *   oibl_sqdist_topk_f16r : k <= 1024 (fused path: k <= 496); problems too small for the fused path, exact != 0,
+ *       and the repeat after *overflow (device int32, may be NULL: a candidate list outgrew its capacity, or more
+ *       than 32 (k <= 16; 2k + 32 otherwise) candidates sat within the bound of the k-th distance — near-duplicate
+ *       galleries) take their member set from fp32 distance tiles + oibl_row_topk on the fp32 rows (what OIBL_F32
+ *       runs: the oibl_f16r_members(k) nearest) and rescore it like the fused path does.                      */
 int oibl_match_prepare_f16r(const float* x, int rows, int d, float* norms, float* aux, void* rows_f16,
                             void* stream);
 /* The two stages of oibl_sqdist_topk_f16r on their own — for a caller that puts something between them: gallery-
  * sharded matching exchanges the FILTER lists first, takes the threshold from all shards' lists, and lets every rank
  * rescore only its members of the GLOBAL rescore set (openibl_amd/sharded.py: the rescoring work then divides by the
  * number of ranks instead of being repeated on each).
- *   oibl_f16r_members(k)        member slots per query: K2 = 32 (k <= 16), 2k + 32 otherwise
+ *   oibl_f16r_members(k)        member slots per query: K2 = 32 (k <= 16), min(2k + 32, 1024) otherwise
  *   oibl_f16r_fused(m, n, d, k) 1 when the problem takes the fused path (else only oibl_sqdist_topk_f16r serves it)
  *   oibl_f16r_filter_select     stage 1 -> lval / lidx [m][K2]: filter distances and global indices of the candidates
  *       that can belong to the top-k of this gallery (any order; (+inf, -1) paddings); ymax_out (device, 2 floats, may
@@ -418,6 +419,28 @@ int oibl_f16r_filter_select(const void* xh, const float* xaux, const float* xn, 
                             void* stream);
 int oibl_f16r_rescore(const float* xsrc, const float* xn, int m, const float* ysrc, const float* yn, int d, int k,
                       int index_base, const int32_t* lidx, float* out_val, int32_t* out_idx, void* stream);
+/* Storage-typed f16r (descriptors stored as fp32, IEEE half or bf16: OIBL_ST_*, as oibl_pairwise_sqdist_st — the lists
+ * are those of the stored values widened to fp32) and the whole ranked prefix the reference ever reads: k up to 496
+ * on the fused path (spatial NMS looks at max(recall_topk) * 12 = 120 ranks, ibl/evaluators.py:152-153,
+ * examples/test.py:130; the k-th filter distance of a list comes from a bisection instead of k register rounds,
+ * csrc/match_f16r.h).  An fp16-stored row is its own fp16 image (residual 0): the filter bound of such a gallery is
+ * the fp32 accumulation slack alone.  The rescoring reads the STORED rows (8 KB instead of 16 KB per 4096-d member).
+ *   oibl_match_prepare_f16r_st        oibl_match_prepare_f16r on stored rows (norms of the widened rows)
+ *   oibl_sqdist_topk_f16r_st          xsrc / ysrc = the stored rows; workspace from the _st query.  EVERY path ends in
+ *       the same rescoring: the exact path (small problems, exact != 0, the repeat after *overflow) takes the
+ *       oibl_f16r_members(k) nearest by fp32 distance tiles and rescores those, so values and tie order do not depend
+ *       on the path that produced the member set.
+ *   oibl_f16r_rescore_st              stage 2 with an explicit member-slot count (lidx [m][members], <= 1024)      */
+int oibl_match_prepare_f16r_st(const void* x, int x_st, int rows, int d, float* norms, float* aux, void* rows_f16,
+                               void* stream);
+size_t oibl_sqdist_topk_f16r_st_workspace_bytes(int m, int n, int d, int k, int x_st, int y_st);
+int oibl_sqdist_topk_f16r_st(const void* xh, const float* xaux, const float* xn, const void* xsrc, int x_st, int m,
+                             const void* yh, const float* yaux, const float* yn, const void* ysrc, int y_st, int n,
+                             int d, int k, int index_base, int exact, float* out_val, int32_t* out_idx,
+                             int32_t* overflow, void* ws, size_t ws_bytes, void* stream);
+int oibl_f16r_rescore_st(const void* xsrc, int x_st, const float* xn, int m, const void* ysrc, int y_st,
+                         const float* yn, int d, int k, int members, int index_base, const int32_t* lidx,
+                         float* out_val, int32_t* out_idx, void* stream);
 /* Between the stages, sharded: thr [m] (device) = the k-th smallest filter distance over the lists of ALL shards,
  * ymax_all [shards][2] (device) = every shard's ymax_out; entries of lidx [m][K2] whose lval exceeds thr + 2 eps (eps
  * from the maxima over all shards) are set to -1. */

@@ -88,7 +88,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         try:
             if not force and is_current():
                 return LIB_PATH
-            return _build_locked(verbose)
+            return _build_locked(verbose, force)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
 
@@ -174,7 +174,31 @@ def kernel_text() -> dict:
     return out
 
 
-def _build_locked(verbose: bool) -> Path:
+def _includes(src: Path, seen=None) -> list:
+    """The in-tree headers a source reaches through #include "..." (csrc/ and include/), transitively."""
+    import re
+    seen = {} if seen is None else seen
+    for name in re.findall(r'^\s*#\s*include\s+"([^"]+)"', src.read_text(), flags=re.M):
+        for base in (src.parent, CSRC, INCLUDE):
+            h = base / name
+            if h.exists() and h not in seen:
+                seen[h] = True
+                _includes(h, seen)
+                break
+    return sorted(seen)
+
+
+def _object_key(src: Path, dbg: bool) -> str:
+    """What an object file depends on: its source, the headers it reaches, the flags."""
+    h = hashlib.sha256()
+    for p in [src, *_includes(src)]:
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    h.update(" ".join(CXXFLAGS + (["-DOIBL_DEBUG_HOOKS", *DBG_EXPERIMENT_FLAGS] if dbg else [])).encode())
+    return h.hexdigest()
+
+
+def _build_locked(verbose: bool, force: bool = False) -> Path:
     hipcc = _hipcc()
     srcs = sources()
     BUILD_DIR_DBG.mkdir(parents=True, exist_ok=True)
@@ -183,6 +207,11 @@ def _build_locked(verbose: bool) -> Path:
 
     def compile_one(job):
         src, obj, dbg = job
+        # an object whose source, headers and flags are unchanged is kept (conv.hip alone is two minutes of hipcc);
+        # its compiler remarks are kept next to it so that the resource report stays complete
+        key, keyfile, remfile = _object_key(src, dbg), obj.with_suffix(".key"), obj.with_suffix(".remarks")
+        if not force and obj.exists() and keyfile.exists() and remfile.exists() and keyfile.read_text() == key:
+            return dbg, remfile.read_text()
         # -Rpass-analysis: the compiler's per-kernel register / scratch / LDS report, kept next to the
         # objects (build/resource_usage.json; tests/test_abi.py holds the hot kernels to their budgets)
         cmd = [hipcc, *CXXFLAGS, *(["-DOIBL_DEBUG_HOOKS", *DBG_EXPERIMENT_FLAGS] if dbg else []),
@@ -192,6 +221,8 @@ def _build_locked(verbose: bool) -> Path:
             raise RuntimeError(f"hipcc failed on {src.name}{' (debug hooks)' if dbg else ''}:\n{r.stdout}\n{r.stderr}")
         if verbose:
             print(f"[openibl_amd.build] compiled {src.name}{' (debug hooks)' if dbg else ''}", file=sys.stderr)
+        remfile.write_text(r.stderr)
+        keyfile.write_text(key)
         return dbg, r.stderr
 
     # the big translation units first, so that the pool is never left with one long job at the end

@@ -1133,10 +1133,15 @@ static TopkPlan topk_plan(int m, int n, int d, int k, int precision, size_t prep
   // from 1.2 to 0.93 PFLOP/s and saved nothing: the sample pass costs the latency of one 256 x 256
   // tile over K = 4096 whatever S is); galleries beyond 82k rows sample 2048 so that the candidate
   // lists stay on the register selection path of row_topk.
+  // k > SEL_MAX_K (the 120 ranks of spatial NMS): neither the sample's top-k nor the candidate lists are on the
+  // register paths anyway, and the survivor density is what costs — the sample may grow to 8192 rows (k = 120 on a
+  // 76k-row gallery: 1.5 % of a tile survives instead of 5.8 %, for a sample pass of a tenth of the filter pass) as
+  // long as the gallery stays 16 samples deep.
   int S = 1024;
-  while ((S < 4 * k || (long)S * 800 < (long)k * n) && S < SEL_MAX_N) S *= 2;
+  const int s_max = k > SEL_MAX_K ? 8192 : SEL_MAX_N;
+  while ((S < 4 * k || (long)S * 800 < (long)k * n) && S < s_max && (k <= SEL_MAX_K || (long)16 * S <= n)) S *= 2;
   t.fused = mfma16(precision) && g_match_ring && pair_ring_legal(m, n, d, opnd_es(precision)) && n >= 8 * S &&
-            (long)((m + 255) / 256) * ((n + 255) / 256) >= 64;
+            S >= 4 * k && (long)((m + 255) / 256) * ((n + 255) / 256) >= 64;
   t.S = S;
   // The sample pass is one 256 x 256 tile over the whole K per workgroup: with m/256 * S/256 <= 128
   // tiles half of the CUs idle for its ~93 us.  Two K-halves on twice the workgroups halve that
@@ -1360,20 +1365,39 @@ int oibl_sqdist_topk_prepared(const void* xo, const float* xn, int m, const void
 }
 
 // ---- f16r: fp16 filter pass + exact rescoring (match_f16r.h) --------------------------------------
-int oibl_match_prepare_f16r(const float* x, int rows, int d, float* norms, float* aux, void* rows_f16,
-                            void* stream) {
+int oibl_match_prepare_f16r_st(const void* x, int x_st, int rows, int d, float* norms, float* aux, void* rows_f16,
+                               void* stream) {
   OIBL_REQUIRE(x && norms && aux && rows_f16, "match_prepare_f16r: null pointer");
+  OIBL_REQUIRE(st_ok(x_st), "match_prepare_f16r: bad storage type %d", x_st);
   OIBL_REQUIRE(rows > 0 && d > 0 && d % 64 == 0, "match_prepare_f16r: unsupported shape rows=%d d=%d", rows, d);
   OIBL_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)rows_f16 % 16 == 0 && (uintptr_t)aux % 16 == 0,
                "match_prepare_f16r: x, rows_f16 and aux must be 16-byte aligned");
-  hipLaunchKernelGGL(f16r_prepare_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, norms,
-                     (float4*)aux, (uint16_t*)rows_f16, rows, d);
+  const dim3 grid((rows + 3) / 4), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  switch (x_st) {
+    case OIBL_ST_F32:
+      hipLaunchKernelGGL(f16r_prepare_kernel<OIBL_ST_F32>, grid, block, 0, st, x, norms, (float4*)aux,
+                         (uint16_t*)rows_f16, rows, d);
+      break;
+    case OIBL_ST_F16:
+      hipLaunchKernelGGL(f16r_prepare_kernel<OIBL_ST_F16>, grid, block, 0, st, x, norms, (float4*)aux,
+                         (uint16_t*)rows_f16, rows, d);
+      break;
+    default:
+      hipLaunchKernelGGL(f16r_prepare_kernel<OIBL_ST_BF16>, grid, block, 0, st, x, norms, (float4*)aux,
+                         (uint16_t*)rows_f16, rows, d);
+  }
   OIBL_LAUNCH_CHECK();
   return OIBL_OK;
 }
+int oibl_match_prepare_f16r(const float* x, int rows, int d, float* norms, float* aux, void* rows_f16,
+                            void* stream) {
+  return oibl_match_prepare_f16r_st(x, OIBL_ST_F32, rows, d, norms, aux, rows_f16, stream);
+}
 
-// candidates kept per query for the rescoring (row_topk's register selection path up to 32)
-static int f16r_k2(int k) { return k <= 16 ? 32 : 2 * k + 32; }
+// member slots per query for the rescoring: 32 up to k = 16, 2k + 32 beyond (1024 at most: the rescoring's LDS window;
+// the fused path needs the whole 2k + 32, the exact path works with what it gets)
+static int f16r_k2(int k) { return k <= 16 ? 32 : (2 * k + 32 <= F16R_MAX_K2 ? 2 * k + 32 : F16R_MAX_K2); }
 
 struct F16rPlan {
   TopkPlan t;
@@ -1385,7 +1409,7 @@ static F16rPlan f16r_plan(int m, int n, int d, int k) {
   F16rPlan f = {};
   f.t = topk_plan(m, n, d, k, OIBL_BF16, 0);   // 2-byte operand rows: the bf16 plan's sample / capacity / legality
   f.K2 = f16r_k2(k);
-  f.fused = f.t.fused && k <= SEL_MAX_K && f.K2 <= F16R_MAX_K2 && f.K2 <= f.t.cap;   // (k: the selection's register rounds)
+  f.fused = f.t.fused && 2 * k + 32 <= F16R_MAX_K2 && f.K2 <= f.t.cap;   // (k <= 496: a member window of k + k + 32)
   size_t o = f.t.total;
   f.off_lval = o;
   o += align_up((size_t)m * f.K2 * sizeof(float), 256);
@@ -1397,9 +1421,14 @@ static F16rPlan f16r_plan(int m, int n, int d, int k) {
   return f;
 }
 
+size_t oibl_sqdist_topk_f16r_st_workspace_bytes(int m, int n, int d, int k, int x_st, int y_st) {
+  if (m <= 0 || n <= 0 || d <= 0 || k <= 0 || !st_ok(x_st) || !st_ok(y_st)) return 0;
+  // (behind the plan: what the exact path's fp32 tiles need of 16-bit stored rows — their widened copies + norms)
+  const bool widen = x_st != OIBL_ST_F32 || y_st != OIBL_ST_F32;
+  return f16r_plan(m, n, d, k).total + (widen ? align_up(oibl_pairwise_st_workspace_bytes(m, n, d, OIBL_F32, x_st, y_st), 256) : 0);
+}
 size_t oibl_sqdist_topk_f16r_workspace_bytes(int m, int n, int d, int k) {
-  if (m <= 0 || n <= 0 || d <= 0 || k <= 0) return 0;
-  return f16r_plan(m, n, d, k).total;
+  return oibl_sqdist_topk_f16r_st_workspace_bytes(m, n, d, k, OIBL_ST_F32, OIBL_ST_F32);
 }
 
 extern "C++" {
@@ -1507,13 +1536,20 @@ int oibl_f16r_filter_select(const void* xh, const float* xaux, const float* xn, 
   if (rc) return rc;
   // 3. the members of every query's rescore set (a list beyond the window / capacity, or more than K2 members,
   //    raises *overflow)
-  hipLaunchKernelGGL((f16r_select_kernel<32, false>), dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, q.cand_val,
-                     q.cand_idx, cnt, m, t.cap, k, f.K2, 2048, xn, (const float4*)xaux, ymax, q.gamma, lval, lidx,
-                     (int*)overflow);
-  OIBL_LAUNCH_CHECK();
-  // (the rare lists beyond 2048 entries: one workgroup per such query; every other workgroup returns at once)
-  hipLaunchKernelGGL((f16r_select_kernel<32, true>), dim3((unsigned)m), dim3(256), 0, st, q.cand_val, q.cand_idx, cnt,
-                     m, t.cap, k, f.K2, 2048, xn, (const float4*)xaux, ymax, q.gamma, lval, lidx, (int*)overflow);
+  if (k <= SEL_MAX_K) {
+    hipLaunchKernelGGL((f16r_select_kernel<32, false>), dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, q.cand_val,
+                       q.cand_idx, cnt, m, t.cap, k, f.K2, 2048, xn, (const float4*)xaux, ymax, q.gamma, lval, lidx,
+                       (int*)overflow);
+    OIBL_LAUNCH_CHECK();
+    // (the rare lists beyond 2048 entries: one workgroup per such query; every other workgroup returns at once)
+    hipLaunchKernelGGL((f16r_select_kernel<32, true>), dim3((unsigned)m), dim3(256), 0, st, q.cand_val, q.cand_idx,
+                       cnt, m, t.cap, k, f.K2, 2048, xn, (const float4*)xaux, ymax, q.gamma, lval, lidx,
+                       (int*)overflow);
+  } else {
+    // k beyond the register rounds: the k-th smallest by bisection, one workgroup per query (lists up to 8192 entries)
+    hipLaunchKernelGGL((f16r_select_bisect_kernel<32>), dim3((unsigned)m), dim3(256), 0, st, q.cand_val, q.cand_idx,
+                       cnt, m, t.cap, k, f.K2, xn, (const float4*)xaux, ymax, q.gamma, lval, lidx, (int*)overflow);
+  }
   OIBL_LAUNCH_CHECK();
   if (ymax_out) OIBL_HIP_CHECK(hipMemcpyAsync(ymax_out, ymax + 2, 8, hipMemcpyDeviceToDevice, st));
   return OIBL_OK;
@@ -1521,11 +1557,24 @@ int oibl_f16r_filter_select(const void* xh, const float* xaux, const float* xn, 
 
 // stage 2: exact distances (fp64-accumulated, from the fp32 rows) of the listed members lidx [m][K2] (global indices
 // of THIS gallery, -1 = no member), the k smallest (distance, index) per query
-int oibl_f16r_rescore(const float* xsrc, const float* xn, int m, const float* ysrc, const float* yn, int d, int k,
-                      int index_base, const int32_t* lidx, float* out_val, int32_t* out_idx, void* stream) {
+extern "C++" {
+template <int XST>
+static void launch_f16r_rescore(int y_st, unsigned m, unsigned threads, hipStream_t st, const F16rRescoreParams& r) {
+  switch (y_st) {
+    case OIBL_ST_F32: hipLaunchKernelGGL((f16r_rescore_kernel<XST, OIBL_ST_F32>), dim3(m), dim3(threads), 0, st, r); break;
+    case OIBL_ST_F16: hipLaunchKernelGGL((f16r_rescore_kernel<XST, OIBL_ST_F16>), dim3(m), dim3(threads), 0, st, r); break;
+    default: hipLaunchKernelGGL((f16r_rescore_kernel<XST, OIBL_ST_BF16>), dim3(m), dim3(threads), 0, st, r);
+  }
+}
+}  // extern "C++"
+
+int oibl_f16r_rescore_st(const void* xsrc, int x_st, const float* xn, int m, const void* ysrc, int y_st,
+                         const float* yn, int d, int k, int members, int index_base, const int32_t* lidx,
+                         float* out_val, int32_t* out_idx, void* stream) {
   OIBL_REQUIRE(xsrc && xn && ysrc && yn && lidx && out_val && out_idx, "f16r_rescore: null pointer");
-  OIBL_REQUIRE(m > 0 && d > 0 && d % 4 == 0 && k >= 1 && f16r_k2(k) <= F16R_MAX_K2, "f16r_rescore: bad shape m=%d d=%d k=%d", m,
-               d, k);
+  OIBL_REQUIRE(st_ok(x_st) && st_ok(y_st), "f16r_rescore: bad storage type %d / %d", x_st, y_st);
+  OIBL_REQUIRE(m > 0 && d > 0 && d % 4 == 0 && k >= 1 && members >= 1 && members <= F16R_MAX_K2,
+               "f16r_rescore: bad shape m=%d d=%d k=%d members=%d", m, d, k, members);
   OIBL_REQUIRE((uintptr_t)xsrc % 16 == 0 && (uintptr_t)ysrc % 16 == 0, "f16r_rescore: rows must be 16-byte aligned");
   F16rRescoreParams r = {};
   r.xsrc = xsrc;
@@ -1536,19 +1585,31 @@ int oibl_f16r_rescore(const float* xsrc, const float* xn, int m, const float* ys
   r.m = m;
   r.d = d;
   r.k = k;
-  r.K2 = f16r_k2(k);
+  r.K2 = members;
   r.index_base = index_base;
   r.out_val = out_val;
   r.out_idx = out_idx;
-  hipLaunchKernelGGL(f16r_rescore_kernel, dim3((unsigned)m), dim3(256), 0, (hipStream_t)stream, r);
+  // 4 waves walk a 32-slot window; the wide windows of k > 16 (2k + 32 slots, k + a few of them members) get 16
+  const unsigned threads = members <= 64 ? 256u : 1024u;
+  hipStream_t st = (hipStream_t)stream;
+  switch (x_st) {
+    case OIBL_ST_F32: launch_f16r_rescore<OIBL_ST_F32>(y_st, (unsigned)m, threads, st, r); break;
+    case OIBL_ST_F16: launch_f16r_rescore<OIBL_ST_F16>(y_st, (unsigned)m, threads, st, r); break;
+    default: launch_f16r_rescore<OIBL_ST_BF16>(y_st, (unsigned)m, threads, st, r);
+  }
   OIBL_LAUNCH_CHECK();
   return OIBL_OK;
+}
+int oibl_f16r_rescore(const float* xsrc, const float* xn, int m, const float* ysrc, const float* yn, int d, int k,
+                      int index_base, const int32_t* lidx, float* out_val, int32_t* out_idx, void* stream) {
+  return oibl_f16r_rescore_st(xsrc, OIBL_ST_F32, xn, m, ysrc, OIBL_ST_F32, yn, d, k, f16r_k2(k), index_base, lidx,
+                              out_val, out_idx, stream);
 }
 
 int oibl_f16r_keep_members(const float* lval, int32_t* lidx, int m, int k, const float* thr, const float* xn,
                            const float* xaux, const float* ymax_all, int shards, int d, void* stream) {
   OIBL_REQUIRE(lval && lidx && thr && xn && xaux && ymax_all, "f16r_keep_members: null pointer");
-  OIBL_REQUIRE(m > 0 && k >= 1 && shards >= 1 && d > 0 && f16r_k2(k) <= F16R_MAX_K2, "f16r_keep_members: bad arguments");
+  OIBL_REQUIRE(m > 0 && k >= 1 && shards >= 1 && d > 0, "f16r_keep_members: bad arguments");
   const int K2 = f16r_k2(k);
   const long items = (long)m * K2;
   hipLaunchKernelGGL(f16r_keep_members_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
@@ -1557,33 +1618,56 @@ int oibl_f16r_keep_members(const float* lval, int32_t* lidx, int m, int k, const
   return OIBL_OK;
 }
 
-int oibl_sqdist_topk_f16r(const void* xh, const float* xaux, const float* xn, const float* xsrc, int m,
-                          const void* yh, const float* yaux, const float* yn, const float* ysrc, int n, int d,
-                          int k, int index_base, int exact, float* out_val, int32_t* out_idx, int32_t* overflow,
-                          void* ws, size_t ws_bytes, void* stream) {
+int oibl_sqdist_topk_f16r_st(const void* xh, const float* xaux, const float* xn, const void* xsrc, int x_st, int m,
+                             const void* yh, const float* yaux, const float* yn, const void* ysrc, int y_st, int n,
+                             int d, int k, int index_base, int exact, float* out_val, int32_t* out_idx,
+                             int32_t* overflow, void* ws, size_t ws_bytes, void* stream) {
   OIBL_REQUIRE(xh && xaux && xn && xsrc && yh && yaux && yn && ysrc && out_val && out_idx && ws,
                "sqdist_topk_f16r: null pointer");
+  OIBL_REQUIRE(st_ok(x_st) && st_ok(y_st), "sqdist_topk_f16r: bad storage type %d / %d", x_st, y_st);
   int rc = topk_args_ok(m, n, d, k, index_base, OIBL_F32);
   if (rc) return rc;
   OIBL_REQUIRE((uintptr_t)ws % 256 == 0 && (uintptr_t)xsrc % 16 == 0 && (uintptr_t)ysrc % 16 == 0,
                "sqdist_topk_f16r: workspace must be 256-byte, rows 16-byte aligned");
   const F16rPlan f = f16r_plan(m, n, d, k);
-  if (ws_bytes < f.total) {
-    set_error("sqdist_topk_f16r: workspace %zu < required %zu bytes", ws_bytes, f.total);
+  const size_t need = oibl_sqdist_topk_f16r_st_workspace_bytes(m, n, d, k, x_st, y_st);
+  if (ws_bytes < need) {
+    set_error("sqdist_topk_f16r: workspace %zu < required %zu bytes", ws_bytes, need);
     return OIBL_E_WORKSPACE;
   }
   char* wsb = (char*)ws;
-  if (!f.fused || exact) {
-    // the exact path: fp32 distance tiles of the resident fp32 rows + row_topk (what OIBL_F32 runs)
-    return sqdist_topk_core(xsrc, xn, m, ysrc, yn, n, d, k, index_base, OIBL_F32, 1, out_val, out_idx, overflow, wsb,
-                            f.t, (hipStream_t)stream);
-  }
   float* lval = (float*)(wsb + f.off_lval);
   int32_t* lidx = (int32_t*)(wsb + f.off_lidx);
+  if (!f.fused || exact) {
+    // the exact path: the K2 nearest by fp32 distance tiles of the widened rows + row_topk (what OIBL_F32 runs), then
+    // the SAME rescoring — values and tie order do not depend on which path produced the member set
+    // (K2 >= k for every k <= 1024: 32 up to 16, min(2k + 32, 1024) beyond)
+    const int K2 = f.K2;
+    const void *xo = xsrc, *yo = ysrc;
+    const float *xn2 = xn, *yn2 = yn;
+    if (x_st != OIBL_ST_F32 || y_st != OIBL_ST_F32) {   // 16-bit storage: fp32 copies of the rows behind the plan
+      float *xw, *yw;
+      rc = pairwise_prepare(xsrc, x_st, m, ysrc, y_st, n, d, OIBL_F32, wsb + f.total, &xo, &yo, &xw, &yw, stream);
+      if (rc) return rc;
+      xn2 = xw;
+      yn2 = yw;
+    }
+    rc = sqdist_topk_core(xo, xn2, m, yo, yn2, n, d, K2, index_base, OIBL_F32, 1, lval, lidx, overflow, wsb, f.t,
+                          (hipStream_t)stream);
+    if (rc) return rc;
+    return oibl_f16r_rescore_st(xsrc, x_st, xn, m, ysrc, y_st, yn, d, k, K2, index_base, lidx, out_val, out_idx, stream);
+  }
   rc = oibl_f16r_filter_select(xh, xaux, xn, m, yh, yaux, yn, n, d, k, index_base, lval, lidx, nullptr, overflow, ws,
                                ws_bytes, stream);
   if (rc) return rc;
-  return oibl_f16r_rescore(xsrc, xn, m, ysrc, yn, d, k, index_base, lidx, out_val, out_idx, stream);
+  return oibl_f16r_rescore_st(xsrc, x_st, xn, m, ysrc, y_st, yn, d, k, f.K2, index_base, lidx, out_val, out_idx, stream);
+}
+int oibl_sqdist_topk_f16r(const void* xh, const float* xaux, const float* xn, const float* xsrc, int m,
+                          const void* yh, const float* yaux, const float* yn, const float* ysrc, int n, int d,
+                          int k, int index_base, int exact, float* out_val, int32_t* out_idx, int32_t* overflow,
+                          void* ws, size_t ws_bytes, void* stream) {
+  return oibl_sqdist_topk_f16r_st(xh, xaux, xn, xsrc, OIBL_ST_F32, m, yh, yaux, yn, ysrc, OIBL_ST_F32, n, d, k,
+                                  index_base, exact, out_val, out_idx, overflow, ws, ws_bytes, stream);
 }
 
 int oibl_first_hit_rank(const int32_t* topk_idx, int m, int k, const int32_t* gt_offsets,

@@ -65,18 +65,23 @@ struct F16rParams {
   float gamma;            // d * 2^-24
 };
 
-// fp32 rows -> scaled fp16 rows + norms + the four scalars; one wave per row.  The squared norm is formed
-// exactly as row_sqnorm_kernel forms it (same loop, same reduction): bit-identical to the fp32 mode's.
-__global__ __launch_bounds__(256) void f16r_prepare_kernel(const float* __restrict__ x, float* __restrict__ norms,
+// stored rows (fp32, IEEE half or bf16: OIBL_ST_*) -> scaled fp16 rows + norms + the four scalars; one wave per row.
+// The squared norm is formed exactly as row_sqnorm_kernel / row_sqnorm_cast_kernel form it (same loop over the
+// widened row, same reduction): bit-identical to the other modes'.  A 16-bit stored row is widened exactly; an
+// fp16-stored row is its own fp16 image up to the power-of-two scale (residual 0 unless elements fall below the
+// scaled row's fp16 normals), so the filter bound of such a gallery is the accumulation slack alone.
+template <int ST>
+__global__ __launch_bounds__(256) void f16r_prepare_kernel(const void* __restrict__ x, float* __restrict__ norms,
                                                            float4* __restrict__ aux, uint16_t* __restrict__ xh,
                                                            int rows, int d) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const float* xr = x + (size_t)row * d;
+  const size_t es = ST == OIBL_ST_F32 ? 4 : 2;
+  const char* xr = static_cast<const char*>(x) + (size_t)row * d * es;
   float s = 0.f, mx = 0.f;
   for (int i = lane * 4; i < d; i += 256) {
-    const float4 v = *reinterpret_cast<const float4*>(xr + i);
+    const float4 v = load4_widen<ST>(xr, i);
     s = fmaf(v.x, v.x, s);
     s = fmaf(v.y, v.y, s);
     s = fmaf(v.z, v.z, s);
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(256) void f16r_prepare_kernel(const float* __restri
   uint16_t* hr = xh + (size_t)row * d;
   float rs = 0.f;
   for (int i = lane * 4; i < d; i += 256) {
-    const float4 v = *reinterpret_cast<const float4*>(xr + i);
+    const float4 v = load4_widen<ST>(xr, i);
     const float t[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};   // exact (power of two; no under/overflow: |e| <= 100)
     uint16_t h[4];
 #pragma unroll
@@ -412,6 +417,105 @@ __global__ __launch_bounds__(256) void f16r_select_kernel(const float* __restric
   }
 }
 
+// k beyond the register rounds above (k > SEL_MAX_K: the 12 x 10 ranks spatial NMS reads, evaluators.py:152-153 —
+// examples/test.py:130 runs Tokyo 24/7 that way): one 256-thread workgroup per query holds its list (<= 256 NQ
+// entries) in registers as (ordered value bits, index) pairs and finds T = the k-th smallest filter distance by
+// BISECTION over the order-preserving 32-bit image of the values — at most 32 counting rounds of one compare per
+// register, a wave sum and one barrier, whatever k is — instead of k extraction rounds.  T is a value, not a key:
+// entries equal to T are all members, and so is everything within 2 eps_any of it (the same rule as above).
+template <int NQ>
+__global__ __launch_bounds__(256) void f16r_select_bisect_kernel(const float* __restrict__ cand_val,
+                                                                 const int32_t* __restrict__ cand_idx,
+                                                                 const int* __restrict__ cnt, int m, int cap, int k,
+                                                                 int K2, const float* __restrict__ xn,
+                                                                 const float4* __restrict__ xaux,
+                                                                 const unsigned* __restrict__ ymax, float gamma,
+                                                                 float* __restrict__ lval, int32_t* __restrict__ lidx,
+                                                                 int* __restrict__ overflow) {
+  __shared__ int s_part[2][4];
+  __shared__ int s_count;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row = blockIdx.x;
+  int n = cnt[row];
+  const int window = cap < 256 * NQ ? cap : 256 * NQ;
+  if (n > window) {
+    if (tid == 0 && overflow) atomicOr(overflow, 1);
+    n = window;
+  }
+  const float* vr = cand_val + (size_t)row * cap;
+  const int32_t* ir = cand_idx + (size_t)row * cap;
+  uint32_t key[NQ];
+  int32_t id[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int j = tid + 256 * q;
+    key[q] = 0xffffffffu;
+    id[q] = -1;
+    if (j < n) {
+      key[q] = ordered_bits(vr[j]);
+      id[q] = ir[j];
+    }
+  }
+  if (tid == 0) s_count = 0;
+  // smallest T with #{key <= T} >= k (fewer than k entries: every entry is a member, T = the largest image)
+  uint32_t lo = 0u, hi = 0xffffffffu;
+  if (n > k) {
+    for (int it = 0; lo < hi; ++it) {      // (lo, hi are workgroup-uniform: every thread sees the same counts)
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      int c = 0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) c += (id[q] >= 0 && key[q] <= mid) ? 1 : 0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+      // two buffers by parity, one barrier per round: round it + 2 rewrites buffer (it & 1) behind barrier it + 1,
+      // which every thread reaches only after it has read round it's counts
+      if (lane == 0) s_part[it & 1][wave] = c;
+      __syncthreads();
+      const int total = s_part[it & 1][0] + s_part[it & 1][1] + s_part[it & 1][2] + s_part[it & 1][3];
+      if (total >= k) hi = mid;
+      else lo = mid + 1u;
+    }
+  } else {
+    lo = 0xffffffffu;
+  }
+  __syncthreads();      // (s_count = 0 is visible; the bisection's barriers are conditional on n > k)
+  const float T = lo == 0xffffffffu ? INFINITY : from_ordered_bits(lo);
+  const float4 xa = xaux[row];
+  const float nx = xa.y, rx = xa.z, xnr = xn[row];
+  const float A = 2.0f * (rx + gamma * (nx + rx)), B = 2.0f * (nx + rx) * (1.0f + gamma);
+  const float ymx = __uint_as_float(ymax[2]), rmx = __uint_as_float(ymax[3]);
+  const float eps_any = fmaf(A, ymx, B * rmx) + 1e-6f * (xnr + ymx * ymx);
+  const float bound = T + 2.0f * eps_any;
+  float* lv = lval + (size_t)row * K2;
+  int32_t* li = lidx + (size_t)row * K2;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const float v = from_ordered_bits(key[q]);
+    const bool in = id[q] >= 0 && !(v > bound);                   // (NaN on either side: keep)
+    const unsigned long long mask = __ballot(in);
+    if (mask) {                                                   // wave-uniform
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&s_count, __popcll(mask));
+      base = __shfl(base, 0, 64);
+      const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+      if (in && pos < K2) {
+        lv[pos] = v;
+        li[pos] = id[q];
+      }
+    }
+  }
+  __syncthreads();
+  int count = s_count;
+  if (count > K2) {
+    if (tid == 0 && overflow) atomicOr(overflow, 1);
+    count = K2;
+  }
+  for (int e = count + tid; e < K2; e += 256) {
+    lv[e] = INFINITY;
+    li[e] = -1;
+  }
+}
+
 // Sharded matching, between the two stages: thr[row] = the k-th smallest filter distance over ALL shards' lists; an
 // entry of this shard's list stays a member iff D_h <= thr + 2 eps_any, eps_any from the largest |y| / residual over
 // all shards (ymax_all [W][2]); the others get index -1 (the rescoring skips them).
@@ -436,8 +540,8 @@ __global__ __launch_bounds__(256) void f16r_keep_members_kernel(const float* __r
 }
 
 struct F16rRescoreParams {
-  const float* xsrc;      // [m][d] fp32 rows
-  const float* ysrc;      // [n][d] fp32 rows
+  const void* xsrc;       // [m][d] stored rows (OIBL_ST_* of the instantiation)
+  const void* ysrc;       // [n][d] stored rows
   const float* xn;
   const float* yn;
   const int32_t* lidx;    // [m][K2] members of the rescore set (global indices; -1 = padding), any order
@@ -456,27 +560,29 @@ __device__ static inline double wave_sum_f64(double v) {
   return v;
 }
 
-// one workgroup (4 waves) per query: D of every member (one wave per pair: fp64 accumulation over the resident fp32
-// rows), then the k smallest (D, index)
-__global__ __launch_bounds__(256) void f16r_rescore_kernel(F16rRescoreParams p) {
+// one workgroup (4 waves; 16 for the wide member windows of k > 16) per query: D of every member (one wave per pair:
+// fp64 accumulation over the resident stored rows, widened exactly), then the k smallest (D, index)
+template <int XST, int YST>
+__global__ __launch_bounds__(1024) void f16r_rescore_kernel(F16rRescoreParams p) {
   __shared__ float s_val[F16R_MAX_K2];
   __shared__ int s_idx[F16R_MAX_K2];
   __shared__ int s_nmem;
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nthr = (int)blockDim.x, nwave = nthr >> 6;
   const int K2 = p.K2, k = p.k;
   if (tid == 0) s_nmem = 0;
-  for (int e = tid; e < K2; e += 256) s_idx[e] = p.lidx[(size_t)q * K2 + e];
+  for (int e = tid; e < K2; e += nthr) s_idx[e] = p.lidx[(size_t)q * K2 + e];
   __syncthreads();
   const float xn = p.xn[q];
-  const float* xr = p.xsrc + (size_t)q * p.d;
-  for (int e = wave; e < K2; e += 4) {
+  const char* xr = static_cast<const char*>(p.xsrc) + (size_t)q * p.d * (XST == OIBL_ST_F32 ? 4 : 2);
+  for (int e = wave; e < K2; e += nwave) {
     const int id = s_idx[e];                       // wave-uniform
     if (id < 0) continue;
-    const float* yr = p.ysrc + (size_t)(id - p.index_base) * p.d;
+    const char* yr = static_cast<const char*>(p.ysrc) + (size_t)(id - p.index_base) * p.d * (YST == OIBL_ST_F32 ? 4 : 2);
     double acc = 0.0;
     for (int i = lane * 4; i < p.d; i += 256) {
-      const float4 a = *reinterpret_cast<const float4*>(xr + i);
-      const float4 b = *reinterpret_cast<const float4*>(yr + i);
+      const float4 a = load4_widen<XST>(xr, i);
+      const float4 b = load4_widen<YST>(yr, i);
       acc = fma((double)a.x, (double)b.x, acc);
       acc = fma((double)a.y, (double)b.y, acc);
       acc = fma((double)a.z, (double)b.z, acc);
@@ -491,7 +597,7 @@ __global__ __launch_bounds__(256) void f16r_rescore_kernel(F16rRescoreParams p) 
   }
   __syncthreads();
   // rank of every member among the members by (D, index): keys are unique (indices are)
-  for (int e = tid; e < K2; e += 256) {
+  for (int e = tid; e < K2; e += nthr) {
     const int id = s_idx[e];
     if (id < 0) continue;
     const unsigned long long key = ((unsigned long long)ordered_bits(s_val[e]) << 32) | (unsigned)id;
@@ -506,7 +612,7 @@ __global__ __launch_bounds__(256) void f16r_rescore_kernel(F16rRescoreParams p) 
       p.out_idx[(size_t)q * k + rank] = id;
     }
   }
-  for (int r = s_nmem + tid; r < k; r += 256) {   // fewer members than k (a gallery shorter than k): pad
+  for (int r = s_nmem + tid; r < k; r += nthr) {   // fewer members than k (a gallery shorter than k): pad
     p.out_val[(size_t)q * k + r] = INFINITY;
     p.out_idx[(size_t)q * k + r] = -1;
   }

@@ -105,6 +105,14 @@ SIGNATURES = {
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                       c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_size_t, c_void_p]),
+    "oibl_match_prepare_f16r_st": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "oibl_sqdist_topk_f16r_st_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "oibl_sqdist_topk_f16r_st": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                         c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_size_t, c_void_p]),
+    "oibl_f16r_rescore_st": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
+                                     c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "oibl_cast_f32_to_f16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "oibl_cast_f16_to_f32": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "oibl_resize_bilinear_nchw": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int,

@@ -36,14 +36,17 @@ def precision_code(p) -> int:
     raise ValueError(f"unknown precision {p!r}")
 
 
+F16R_MAX_FUSED_K = 496      # the fused f16r path: a member window of 2k + 32 <= 1024 slots (csrc/match.hip, f16r_plan)
+
+
 def topk_precision(precision, storage_dtype=torch.float32, k: int = 10) -> int:
     """The arithmetic the fused distance + top-k of a model precision runs in: an f16mx model's descriptors are
-    matched in f16r — fp16 filter pass + exact rescoring: fp32-exact lists, and faster than contracting every
-    pair in f16mx — when they are stored as float32 (the rescoring reads the fp32 rows) and k fits the register
-    rounds of its selection (k <= 32: Recall@1/5/10; the 120 of spatial NMS stay in f16mx); everything else as
-    asked."""
+    matched in f16r — fp16 filter pass + exact rescoring from the stored rows: fp32-exact lists, and faster than
+    contracting every pair in f16mx — whatever their storage type (float32, float16, bfloat16: a 16-bit row is
+    widened exactly) and for every ranked prefix the reference reads (Recall@1/5/10, and the 120 ranks of spatial
+    NMS, ibl/evaluators.py:152-153); everything else as asked."""
     p = precision_code(precision)
-    if p == F16MX and storage_dtype == torch.float32 and k <= 32:
+    if p == F16MX and storage_dtype in (torch.float32, torch.float16, torch.bfloat16) and k <= F16R_MAX_FUSED_K:
         return F16R
     return p
 
@@ -765,8 +768,6 @@ def sqdist_topk(x: torch.Tensor, y: torch.Tensor, k: int, index_base: int = 0, p
     if x.dim() != 2 or y.dim() != 2:
         raise ValueError("sqdist_topk expects [m][d] and [n][d]")
     if p == F16R:
-        if x.dtype != torch.float32 or y.dtype != torch.float32:
-            raise ValueError("sqdist_topk: 'f16r' rescoring reads float32 rows (use 'f16mx' for 16-bit storage)")
         if x.shape[0] == 0 or y.shape[0] == 0:
             p = F32                                           # (nothing to prepare: the empty result below)
         else:
@@ -841,15 +842,13 @@ class PreparedRows:
         self.aux = None
         if p == F16R:
             # four parts: scaled fp16 rows (the filter pass), {2^-e, |x|, |residual|, 0} per row, the fp32 squared
-            # norms, and the fp32 rows themselves (read again by the rescoring)
-            if x.dtype != torch.float32:
-                raise ValueError("PreparedRows: 'f16r' needs float32 rows (the rescoring reads them)")
+            # norms, and the STORED rows themselves (fp32, fp16 or bf16: read again — widened exactly — by the rescoring)
             self._source = x
             self.operand = torch.empty((rows, d), dtype=torch.float16, device=dev)
             self.aux = torch.empty((rows, 4), dtype=torch.float32, device=dev)
             if rows:
-                _lib.check(_lib.load().oibl_match_prepare_f16r(_ptr(x), rows, d, _ptr(self.norms), _ptr(self.aux),
-                                                               _ptr(self.operand), _stream(dev)), "match_prepare_f16r")
+                _lib.check(_lib.load().oibl_match_prepare_f16r_st(_ptr(x), st, rows, d, _ptr(self.norms), _ptr(self.aux),
+                                                                  _ptr(self.operand), _stream(dev)), "match_prepare_f16r")
             return
         if rows == 0:
             return
@@ -862,24 +861,50 @@ class PreparedRows:
         if buf is not None:
             self.operand = buf
 
+    @property
+    def storage(self) -> int:
+        """OIBL_ST_* of the rows an f16r rescoring reads (the stored descriptors)."""
+        return storage_code(self._source) if self._source is not None else ST_F32
+
     def operand_rows(self) -> torch.Tensor:
         """The operand as a [rows][bytes per row] uint8 matrix (a view): what travels when prepared
         queries are exchanged between ranks instead of fp32 rows."""
         rows = self.shape[0]
         if self.precision == F16R:
-            # one row per query: [d fp16 | 4 fp32 aux | d fp32 source] — what a rank that extracted the query ships
+            # one row per query: [d fp16 | 4 fp32 aux | d stored elements] — what a rank that extracted the query ships
             d = self.shape[1]
+            es = self._source.element_size()
             return torch.cat([self.operand.view(torch.uint8).reshape(rows, 2 * d),
                               self.aux.view(torch.uint8).reshape(rows, 16),
-                              self._source.view(torch.uint8).reshape(rows, 4 * d)], dim=1)
+                              self._source.view(torch.uint8).reshape(rows, es * d)], dim=1)
         per = self.shape[1] * (2 if self.precision == BF16 else 4)
         flat = self.operand.contiguous().view(torch.uint8).reshape(-1)
         return flat[: rows * per].view(rows, per)
 
+    def rows(self, lo: int, hi: int) -> "PreparedRows":
+        """Rows [lo, hi) as prepared rows of their own — views of every part, no copies (a query block of
+        sharded_topk; ADVICE r05: operand_rows() + from_parts concatenated and re-split the whole f16r set)."""
+        n = self.shape[0]
+        lo, hi = max(0, min(int(lo), n)), max(0, min(int(hi), n))
+        out = type(self).__new__(type(self))
+        out.precision, out.device = self.precision, self.device
+        out.shape = (hi - lo, self.shape[1])
+        out.norms = self.norms[lo:hi]
+        out.aux = None if self.aux is None else self.aux[lo:hi]
+        out._source = None if self._source is None else self._source[lo:hi]
+        if self.precision == F16R or self.operand.dim() == 2:
+            out.operand = self.operand[lo:hi]
+        else:                                     # a flat byte buffer of whole rows (oibl_match_prepare's operand)
+            per = self.shape[1] * (2 if self.precision == BF16 else 4)
+            out.operand = self.operand.view(torch.uint8).reshape(-1)[lo * per: hi * per]
+        return out
+
     @classmethod
-    def from_parts(cls, operand_rows: torch.Tensor, norms: torch.Tensor, d: int, precision) -> "PreparedRows":
+    def from_parts(cls, operand_rows: torch.Tensor, norms: torch.Tensor, d: int, precision,
+                   source_dtype: Optional[torch.dtype] = None) -> "PreparedRows":
         """Re-assemble prepared rows from their exchanged parts (operand_rows() and .norms of one or
-        several PreparedRows of the same precision, concatenated along dim 0)."""
+        several PreparedRows of the same precision, concatenated along dim 0).  f16r: `source_dtype` = the
+        storage type of the rows behind the fp16 image (default float32; a 2-byte tail without it: float16)."""
         self = cls.__new__(cls)
         self.precision = precision_code(precision)
         self.device = operand_rows.device
@@ -890,9 +915,14 @@ class PreparedRows:
         if self.precision == F16R:
             rows, dd = self.shape
             b = operand_rows
+            tail = (int(b.shape[1]) - 2 * dd - 16) // dd
+            if source_dtype is None:
+                source_dtype = torch.float32 if tail == 4 else torch.float16
+            if tail != (4 if source_dtype == torch.float32 else 2):
+                raise ValueError("PreparedRows.from_parts: row width does not match the f16r layout of %s rows" % source_dtype)
             self.operand = b[:, : 2 * dd].contiguous().view(torch.float16).reshape(rows, dd)
             self.aux = b[:, 2 * dd: 2 * dd + 16].contiguous().view(torch.float32).reshape(rows, 4)
-            self._source = b[:, 2 * dd + 16:].contiguous().view(torch.float32).reshape(rows, dd)
+            self._source = b[:, 2 * dd + 16:].contiguous().view(source_dtype).reshape(rows, dd)
             return self
         self.operand = operand_rows.contiguous()
         return self
@@ -912,13 +942,16 @@ def sqdist_topk_prepared(x: "PreparedRows", y: "PreparedRows", k: int, index_bas
         return (ov, oi, flag) if defer_check else (ov, oi)
     lib = _lib.load()
     if p == F16R:
-        ws = workspace(lib.oibl_sqdist_topk_f16r_workspace_bytes(m, n, d, k), dev, "sqdist_topk")
+        xs, ys = x.storage, y.storage
+        ws = workspace(lib.oibl_sqdist_topk_f16r_st_workspace_bytes(m, n, d, k, xs, ys), dev, "sqdist_topk")
+        xsrc, ysrc = x._source.contiguous(), y._source.contiguous()
+        xop, xaux, xnorm = x.operand.contiguous(), x.aux.contiguous(), x.norms.contiguous()
 
         def run(ex: int) -> None:
-            _lib.check(lib.oibl_sqdist_topk_f16r(_ptr(x.operand), _ptr(x.aux), _ptr(x.norms), _ptr(x._source), m,
-                                                 _ptr(y.operand), _ptr(y.aux), _ptr(y.norms), _ptr(y._source), n,
-                                                 d, k, int(index_base), ex, _ptr(ov), _ptr(oi), _ptr(flag),
-                                                 _ptr(ws), ws.numel(), _stream(dev)), "sqdist_topk_f16r")
+            _lib.check(lib.oibl_sqdist_topk_f16r_st(_ptr(xop), _ptr(xaux), _ptr(xnorm), _ptr(xsrc), xs, m,
+                                                    _ptr(y.operand), _ptr(y.aux), _ptr(y.norms), _ptr(ysrc), ys, n,
+                                                    d, k, int(index_base), ex, _ptr(ov), _ptr(oi), _ptr(flag),
+                                                    _ptr(ws), ws.numel(), _stream(dev)), "sqdist_topk_f16r")
     else:
         ws = workspace(lib.oibl_sqdist_topk_prepared_workspace_bytes(m, n, d, k, p), dev, "sqdist_topk")
 
@@ -989,9 +1022,11 @@ def f16r_rescore(x: "PreparedRows", y: "PreparedRows", lidx: torch.Tensor, k: in
     oi = torch.full((m, k), -1, dtype=torch.int32, device=dev)
     if m == 0 or y.shape[0] == 0:
         return ov, oi
-    _lib.check(_lib.load().oibl_f16r_rescore(_ptr(x._source), _ptr(x.norms), m, _ptr(y._source), _ptr(y.norms), d, int(k),
-                                             int(index_base), _ptr(lidx.contiguous()), _ptr(ov), _ptr(oi), _stream(dev)),
-               "f16r_rescore")
+    lidx = lidx.contiguous()
+    _lib.check(_lib.load().oibl_f16r_rescore_st(_ptr(x._source.contiguous()), x.storage, _ptr(x.norms.contiguous()), m,
+                                                _ptr(y._source), y.storage, _ptr(y.norms), d, int(k),
+                                                int(lidx.shape[1]), int(index_base), _ptr(lidx), _ptr(ov), _ptr(oi),
+                                                _stream(dev)), "f16r_rescore")
     return ov, oi
 
 

@@ -136,7 +136,9 @@ def gather_prepared_queries(q_local: torch.Tensor, n_total: int, precision, grou
 
 def _query_block(q, lo: int, hi: int):
     """Rows [lo, hi) of a query set given as a tensor or as ops.PreparedRows (views, no copies)."""
-    if hasattr(q, "operand_rows"):           # ops.PreparedRows (or a stand-in with its protocol)
+    if callable(getattr(q, "rows", None)):   # ops.PreparedRows: every part sliced in place
+        return q.rows(lo, hi)
+    if hasattr(q, "operand_rows"):           # a stand-in with the exchange protocol only (CPU tests)
         return type(q).from_parts(q.operand_rows()[lo:hi], q.norms[lo:hi], q.shape[1], getattr(q, "precision", None))
     return q[lo:hi]
 
@@ -172,7 +174,9 @@ def _make_stages(g_local, k, index_base, precision, group, local_topk_fn, merge_
 
     # what runs on the caller's stream per query block (matrix work) and what runs behind it (exchange + merge; f16r:
     # exchange of the filter lists, global threshold, this rank's share of the rescoring, exchange + merge)
-    two_phase = use_f16r and world > 1
+    # (k beyond the fused f16r path — a member window of 2k + 32 > 1024 slots — has no filter lists to exchange:
+    #  the single exchange of the per-shard lists, whose local top-k falls back to the exact path: ADVICE r05)
+    two_phase = use_f16r and world > 1 and k <= ops.F16R_MAX_FUSED_K
 
     def stage_main(qb, exact):
         if two_phase and not exact:
@@ -188,16 +192,18 @@ def _make_stages(g_local, k, index_base, precision, group, local_topk_fn, merge_
             return gather_and_merge(*res)
         lval, lidx, ymax, flag = res
         Qb, K2 = int(lval.shape[0]), int(lval.shape[1])
-        extra = torch.zeros((1, 2 * K2), dtype=torch.float32, device=lval.device)
+        # only the filter VALUES travel (+ one row: the flag and the shard's norm maxima): the indices stay where their
+        # rows are — a rank rescoring its own members never reads another rank's lidx
+        extra = torch.zeros((1, K2), dtype=torch.float32, device=lval.device)
         extra[0, 0:1] = flag.view(torch.float32)
         extra[0, 1:3] = ymax
-        packed = torch.cat([torch.cat([lval, lidx.view(torch.float32)], dim=1), extra]).contiguous()
-        gathered = torch.empty((world * (Qb + 1), 2 * K2), dtype=torch.float32, device=packed.device)
+        packed = torch.cat([lval, extra]).contiguous()
+        gathered = torch.empty((world * (Qb + 1), K2), dtype=torch.float32, device=packed.device)
         dist.all_gather_into_tensor(gathered, packed, group=group)
-        gathered = gathered.view(world, Qb + 1, 2 * K2)
+        gathered = gathered.view(world, Qb + 1, K2)
         flags = gathered[:, Qb, 0].contiguous().view(torch.int32)
         ymax_all = gathered[:, Qb, 1:3].contiguous()                              # [world][2]
-        vals_all = gathered[:, :Qb, :K2].permute(1, 0, 2).reshape(Qb, world * K2)
+        vals_all = gathered[:, :Qb, :].permute(1, 0, 2).reshape(Qb, world * K2)
         thr = f16r_stages.kth(vals_all, k)                                        # k-th smallest filter distance, all shards
         f16r_stages.keep_members(lval, lidx, k, thr, qb, ymax_all)                # this rank's members of the global set
         v, i = f16r_stages.rescore(qb, g_local, lidx, k, index_base)

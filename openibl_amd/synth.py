@@ -221,6 +221,68 @@ def retrieval_problem(num_query: int, num_gallery: int, dim: int = PCA_DIM, seed
     return torch.from_numpy(q), torch.from_numpy(g), gt, pids
 
 
+def tokyo_problem(num_query: int = 315, num_gallery: int = 75984, dim: int = PCA_DIM, seed: int = 5,
+                  views: int = 12, distractors: int = 12, place_noise: float = 0.6, noise: float = 0.6,
+                  hard_fraction: float = 0.5, far=(11.0, 20.0)):
+    """A matching set shaped like Tokyo 24/7 (315 queries x 75 984 gallery images = 12
+    views of each place; the reference evaluates it with spatial NMS — examples/test.py:130 — i.e. de-duplicates
+    the first 120 ranks by place id, ibl/evaluators.py:132-140, 152-153).
+
+    Returns (q [Q][dim], g [G][dim], gt, gallery_pids) like retrieval_problem.  The views of a place are
+    near-duplicates (normalize(centre + place_noise * noise / sqrt(dim))).  Every query has ONE true place — all of
+    its views are ground truth, each its own normalize(query + sigma * noise): near (sigma = `noise`) for the easy
+    queries, sigma = noise * U(far) for the hard ones — and `distractors` other places whose views sit at
+    noise * U(far) from it.  A hard query's first ranks are therefore runs of ~12 near-tied views of one place after
+    the other: without NMS the top-10 is one place, with NMS it is ten — Recall@N with and without NMS differ, and
+    Recall@1 < Recall@5 < Recall@10 < 1."""
+    rng = np.random.default_rng([seed, 24, 7])
+    V = int(views)
+    P = -(-num_gallery // V)
+    if num_query * (1 + distractors) > P:
+        raise ValueError("tokyo_problem: not enough places for one true place + distractors per query")
+    q = rng.standard_normal((num_query, dim), dtype=np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    # the background gallery in 16 blocks of places, each from its own child stream ([seed, 24, 7, block]) on a
+    # thread of its own: the result does not depend on how many threads ran (311M normal draws are 20 s on one core)
+    g = np.empty((num_gallery, dim), dtype=np.float32)
+    amp_v = np.float32(place_noise / math.sqrt(dim))
+    blocks = 16
+
+    def fill(b):
+        p0, p1 = b * P // blocks, (b + 1) * P // blocks
+        r0, r1 = p0 * V, min(p1 * V, num_gallery)
+        if r1 <= r0:
+            return
+        brng = np.random.default_rng([seed, 24, 7, b])
+        c = brng.standard_normal((p1 - p0, dim), dtype=np.float32)
+        c /= np.linalg.norm(c, axis=1, keepdims=True)
+        v = np.repeat(c, V, axis=0)[: r1 - r0]
+        v += amp_v * brng.standard_normal((r1 - r0, dim), dtype=np.float32)
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        g[r0:r1] = v
+
+    from concurrent.futures import ThreadPoolExecutor
+    import os
+    with ThreadPoolExecutor(max_workers=min(blocks, os.cpu_count() or 4)) as ex:
+        list(ex.map(fill, range(blocks)))
+    places = rng.permutation(P)[: num_query * (1 + distractors)].reshape(num_query, 1 + distractors)
+    hard = rng.uniform(size=num_query) < hard_fraction
+    sig = noise * rng.uniform(far[0], far[1], size=(num_query, 1 + distractors))
+    sig[~hard, 0] = noise
+    gt = []
+    for i in range(num_query):
+        for c in range(1 + distractors):
+            r0 = int(places[i, c]) * V
+            r1 = min(r0 + V, num_gallery)
+            v = q[i][None, :] + np.float32(sig[i, c] / math.sqrt(dim)) * rng.standard_normal((r1 - r0, dim),
+                                                                                             dtype=np.float32)
+            g[r0:r1] = v / np.linalg.norm(v, axis=1, keepdims=True)
+            if c == 0:
+                gt.append(list(range(r0, r1)))
+    pids = [int(j // V) for j in range(num_gallery)]
+    return torch.from_numpy(q), torch.from_numpy(g), gt, pids
+
+
 def tie_free_matrix(rows: int, cols: int, seed: int = 41, scale: float = 4.0) -> torch.Tensor:
     """float32 [rows][cols] "distance" matrix whose rows are jittered permutations: every row holds
     distinct values in [0, scale), so its argsort is unique (the mining samplers' torch.argsort and

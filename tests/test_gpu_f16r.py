@@ -74,12 +74,20 @@ def test_fused_lists_are_fp32_exact(dev, m, n, d, k):
 
 
 def test_small_and_ragged_problems_take_the_exact_path(dev):
+    """Below the fused path's size the member set comes from fp32 distance tiles — and is rescored like every other
+    (round 6, ADVICE r05: values and tie order must not depend on the path): the fp32 mode's indices up to fp32
+    near-ties, fp64-accumulated values."""
     for m, n, d, k in [(1, 1, 64, 1), (3, 129, 128, 10), (130, 67, 4096, 10), (5, 3000, 192, 7), (4, 6, 64, 10)]:
         g = torch.Generator().manual_seed(m * 7 + n)
         x, y = torch.randn((m, d), generator=g), torch.randn((n, d), generator=g)
+        assert not ops.f16r_fused(m, n, d, k)
         v, i = ops.sqdist_topk(x.to(dev), y.to(dev), k, precision="f16r")
         v32, i32 = ops.sqdist_topk(x.to(dev), y.to(dev), k, precision="fp32")
-        assert torch.equal(v, v32) and torch.equal(i, i32)        # (k > n: (+inf, -1) tails included)
+        kk = min(k, n)
+        assert torch.equal(i[:, kk:], i32[:, kk:]) and torch.equal(v[:, kk:], v32[:, kk:])   # (k > n: (+inf, -1) tails)
+        _assert_lists(f"f16r exact path {m}x{n}x{d}", x, y, v[:, :kk], i[:, :kk], kk, tie=2e-6, val_tol=3e-7)
+        assert float((v[:, :kk] - v32[:, :kk]).abs().max()) <= 1e-5 * float(v32[:, :kk].abs().max())
+        assert float((i[:, :kk] != i32[:, :kk]).float().mean()) <= 0.01
 
 
 def test_rows_of_any_magnitude(dev):
@@ -113,10 +121,16 @@ def test_near_duplicate_gallery_overflows_into_the_exact_path(dev):
     assert int(flag.item()) == 1
     v, i = ops.sqdist_topk(q.to(dev), g.to(dev), k, precision="f16r")      # reads the flag, repeats exactly
     v32, i32 = ops.sqdist_topk(q.to(dev), g.to(dev), k, precision="fp32")
-    assert torch.equal(i, i32) and torch.equal(v, v32)
+    # the repeat takes the K2 nearest of the fp32 tiles and rescores them: query 0's list is ten of the 200 rows that
+    # sit 1e-12 from it (any ten: they are fp64 near-ties), every other query's list is the fp32 mode's
+    assert torch.equal(i[1:], i32[1:])
+    assert bool(((i[0] >= 1000) & (i[0] < 1200)).all()) and float(v[0].abs().max()) < 1e-6
+    _assert_lists("f16r after overflow", q, g, v, i, k)
+    ve, ie = ops.sqdist_topk(q.to(dev), g.to(dev), k, precision="f16r", exact=True)
+    assert torch.equal(ie, i) and torch.equal(ve, v)
     # through sharded_topk (one rank): the same protocol
     v2, i2 = sharded.sharded_topk(q.to(dev), g.to(dev), k, 0, "f16r")
-    assert torch.equal(i2, i32)
+    assert torch.equal(i2, i) and torch.equal(v2, v)
 
 
 @pytest.mark.parametrize("name", ["match_small", "match_nms"])
@@ -158,8 +172,12 @@ def test_sharded_f16r_equals_global(dev):
 
 def test_topk_precision_rule():
     assert ops.topk_precision("f16mx") == ops.F16R
-    assert ops.topk_precision("f16mx", torch.float16) == ops.F16MX      # 16-bit storage: nothing exact to rescore from
-    assert ops.topk_precision("f16mx", torch.float32, 120) == ops.F16MX      # spatial NMS reads 120 ranks
+    assert ops.topk_precision("f16mx", torch.float16) == ops.F16R       # 16-bit storage: rescored from the stored rows
+    assert ops.topk_precision("f16mx", torch.bfloat16) == ops.F16R
+    assert ops.topk_precision("f16mx", torch.float32, 120) == ops.F16R  # the 120 ranks of spatial NMS (round 6)
+    assert ops.topk_precision("f16mx", torch.float32, 496) == ops.F16R
+    assert ops.topk_precision("f16mx", torch.float32, 497) == ops.F16MX  # beyond the fused path's member window
+    assert ops.topk_precision("f16mx", None, 10) == ops.F16MX           # mixed storage types: as asked
     assert ops.topk_precision("bf16x3") == ops.BF16X3 and ops.topk_precision("fp32") == ops.F32
     with pytest.raises(ValueError):
         ops.pairwise_sqdist(torch.zeros(2, 64), torch.zeros(2, 64), "f16r")
@@ -187,13 +205,52 @@ def test_long_candidate_list_takes_the_workgroup_selection(dev):
     assert bool(near[i[0].cpu().long()].all())                   # query 0's neighbours are among the ordinary rows
 
 
-@pytest.mark.parametrize("k", [1, 16, 17, 32])
+@pytest.mark.parametrize("k", [1, 16, 17, 32, 33, 120, 496])
 def test_member_window_sizes(dev, k):
-    """k = 16 | 17: the member window changes from 32 to 2k + 32 slots; k = 32: the largest k of the fused path."""
+    """k = 16 | 17: the member window changes from 32 to 2k + 32 slots; k = 32 | 33: the selection changes from k
+    register extraction rounds to the bisection (round 6); 120: spatial NMS; 496: the largest k of the fused path."""
     m, n, d = 256, 16384, 256
     q, g, _, _ = synth.retrieval_problem(m, n, dim=d, seed=40 + k, hard_fraction=0.5)
     assert ops.f16r_fused(m, n, d, k) and ops.f16r_members(k) == (32 if k <= 16 else 2 * k + 32)
     v, i, flag = ops.sqdist_topk(q.to(dev), g.to(dev), k, precision="f16r", defer_check=True)
     assert int(flag.item()) == 0
     _assert_lists(f"f16r k={k}", q, g, v, i, k)
-    assert not ops.f16r_fused(m, n, d, 33)                       # beyond the selection's register rounds: exact path
+    assert not ops.f16r_fused(m, n, d, 497) and ops.f16r_members(497) == 1024   # 2k + 32 > 1024: exact path
+
+
+@pytest.mark.parametrize("store", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("k", [10, 120])
+def test_sixteen_bit_storage(dev, store, k):
+    """Descriptors STORED as fp16 / bf16 (BASELINE configs[4]): prepared from the stored rows (an fp16 row is its own
+    fp16 image: residual 0 up to flushed elements; a bf16 row's 8 bits fit fp16's 11), filtered, and rescored from
+    the stored rows widened exactly — the lists of the widened fp32 problem, bit-equal to f16r on the widened copy."""
+    m, n, d = 300, 20000, 512
+    q, g, _, _ = synth.retrieval_problem(m, n, dim=d, seed=77 + k, hard_fraction=0.5)
+    qs, gs = q.to(store), g.to(store)
+    qd, gd = qs.to(dev), gs.to(dev)
+    p = ops.PreparedRows(gd, "f16r")
+    assert p.storage == ops.storage_code(gd) and p._source.dtype == store
+    ref = ops.PreparedRows(gd.float(), "f16r")
+    assert torch.equal(p.norms, ref.norms) and torch.equal(p.operand, ref.operand) and torch.equal(p.aux, ref.aux)
+    if store == torch.float16:
+        assert float(p.aux[:, 2].max()) == 0.0                      # an fp16 row IS its fp16 image
+    assert ops.f16r_fused(m, n, d, k)
+    v, i, flag = ops.sqdist_topk(qd, gd, k, precision="f16r", defer_check=True)
+    assert int(flag.item()) == 0
+    _assert_lists(f"f16r on {store} rows k={k}", qs.float(), gs.float(), v, i, k)
+    vw, iw = ops.sqdist_topk(qd.float(), gd.float(), k, precision="f16r")
+    assert torch.equal(i, iw) and torch.equal(v, vw)
+    # mixed: fp32 queries against the 16-bit gallery, and the exact path on the stored rows
+    vm, im = ops.sqdist_topk(q.to(dev), gd, k, precision="f16r")
+    _assert_lists(f"f16r fp32 queries x {store} gallery k={k}", q, gs.float(), vm, im, k)
+    ve, ie = ops.sqdist_topk(qd, gd, k, precision="f16r", exact=True)
+    _assert_lists(f"f16r exact path on {store} rows k={k}", qs.float(), gs.float(), ve, ie, k)
+    # the exchanged form (what a rank ships) keeps the storage type; a row block is a view of every part
+    qp = ops.PreparedRows(qd, "f16r")
+    qp2 = ops.PreparedRows.from_parts(qp.operand_rows(), qp.norms, d, "f16r", source_dtype=store)
+    v2, i2 = ops.sqdist_topk_prepared(qp2, p, k)
+    assert torch.equal(i2, i) and torch.equal(v2, v)
+    blk = qp.rows(64, 192)
+    assert blk._source.data_ptr() == qp._source[64:].data_ptr() and blk.operand.data_ptr() == qp.operand[64:].data_ptr()
+    v3, i3 = ops.sqdist_topk_prepared(blk, p, k)
+    assert torch.equal(i3, i[64:192]) and torch.equal(v3, v[64:192])
