@@ -627,6 +627,48 @@ __global__ __launch_bounds__(256) void row_select_wave_kernel(const float* __res
   }
 }
 
+// The k-th smallest VALUE of every row, k beyond the register rounds (the threshold sample of a k = 120 call: only
+// sval[k - 1] is ever read): one 256-thread workgroup per row, the row (<= 256 NQ values; vals2: a second addend,
+// the split-K halves) in registers as order-preserving 32-bit images, bisection over that image — at most 32
+// counting rounds of NQ compares, a wave sum and one barrier — instead of the chunked bitonic sorts of
+// row_topk_kernel.  Writes out_val[row * k + k - 1] (the slot a top-k launch would fill); +inf when n < k.
+template <int NQ>
+__global__ __launch_bounds__(256) void row_kth_bisect_kernel(const float* __restrict__ vals,
+                                                             const float* __restrict__ vals2, int n, size_t ld, int k,
+                                                             float* __restrict__ out_val) {
+  __shared__ int s_part[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t row = blockIdx.x;
+  const float* vr = vals + row * ld;
+  const float* vr2 = vals2 ? vals2 + row * ld : nullptr;
+  uint32_t key[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int j = tid + 256 * q;
+    key[q] = 0xffffffffu;                       // (paddings: never counted, mid < hi <= 0xffffffff)
+    if (j < n) key[q] = ordered_bits(vr2 ? vr[j] + vr2[j] : vr[j]);
+  }
+  uint32_t lo = 0u, hi = 0xffffffffu;           // smallest T with #{key <= T} >= k; n < k: T stays the padding image
+  if (n >= k) {
+    for (int it = 0; lo < hi; ++it) {           // (workgroup-uniform)
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      int c = 0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) c += key[q] <= mid ? 1 : 0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+      if (lane == 0) s_part[it & 1][wave] = c;  // two buffers by parity: f16r_select_bisect_kernel has the argument
+      __syncthreads();
+      const int total = s_part[it & 1][0] + s_part[it & 1][1] + s_part[it & 1][2] + s_part[it & 1][3];
+      if (total >= k) hi = mid;
+      else lo = mid + 1u;
+    }
+  } else {
+    lo = 0xffffffffu;
+  }
+  if (tid == 0) out_val[row * k + (k - 1)] = lo == 0xffffffffu ? INFINITY : from_ordered_bits(lo);
+}
+
 // dispatch: wave-per-row selection for short rows, one workgroup per row for the rest
 // vals2 (optional, only on the wave-per-row paths: k <= 32, n <= 1024, no per-row lengths): a second
 // matrix added element-wise before selecting
@@ -649,6 +691,20 @@ static void launch_row_topk(const float* vals, const int32_t* idx_in, int m, int
   }
   hipLaunchKernelGGL(row_topk_kernel, dim3(m), block, 0, st, vals, idx_in, n, ld, k, index_base,
                      out_val, out_idx, row_n, overflow, skip_le);
+}
+
+// thresholds of the fused paths: sval[row * k + k - 1] = the k-th smallest of a row of S sample distances (vals2: the
+// second split-K half).  Up to k = 32 the sorted prefix comes from the register rounds anyway; beyond, only the k-th
+// value is formed.
+constexpr int KTH_MAX_N = 8192;
+static void launch_sample_kth(const float* sample, const float* sample2, int m, int S, int k, float* sval,
+                              int32_t* sidx, hipStream_t st) {
+  if (k > SEL_MAX_K && S <= KTH_MAX_N) {
+    hipLaunchKernelGGL(row_kth_bisect_kernel<KTH_MAX_N / 256>, dim3((unsigned)m), dim3(256), 0, st, sample, sample2, S,
+                       (size_t)S, k, sval);
+    return;
+  }
+  launch_row_topk(sample, nullptr, m, S, (size_t)S, k, 0, sval, sidx, nullptr, nullptr, st, sample2);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1149,7 +1205,8 @@ static TopkPlan topk_plan(int m, int n, int d, int k, int precision, size_t prep
   // the slack that covers the changed summation order.
   const int es_ = opnd_es(precision);
   const int kt_half = d * es_ / 256;      // K-tiles per half
-  t.ksplit = (g_match_splitk && t.fused && k <= SEL_MAX_K && S <= 1024 && d % 128 == 0 &&
+  // (k <= 32: the halves are added by the wave-per-row selection, rows up to 1024; beyond: by row_kth_bisect_kernel)
+  t.ksplit = (g_match_splitk && t.fused && (k <= SEL_MAX_K ? S <= 1024 : S <= KTH_MAX_N) && d % 128 == 0 &&
               kt_half >= 4 && (kt_half & 1) == 0 && (long)((m + 255) / 256) * (S / 256) <= 128) ? 2 : 1;
   t.stride = n / S;                       // sample = gallery rows 0, stride, 2 stride, ...
   const long expect = (long)k * t.stride + k;  // ~ n k / S survivors per query
@@ -1239,8 +1296,7 @@ static int sqdist_topk_core(const void* xo, const float* xn, int m, const void* 
          : x3 ? launch_pairwise_ring<false, RING_X3>(q, st, t.ksplit)
               : launch_pairwise_ring<false>(q, st, t.ksplit);
     if (rc) return rc;
-    launch_row_topk(sample, nullptr, m, t.S, (size_t)t.S, k, 0, sval, sidx, nullptr, nullptr, st,
-                    t.ksplit == 2 ? sample + half : nullptr);
+    launch_sample_kth(sample, t.ksplit == 2 ? sample + half : nullptr, m, t.S, k, sval, sidx, st);
     OIBL_LAUNCH_CHECK();
     // 2. the full contraction, keeping only distances <= threshold (+ the slack of a split sample:
     //    a bound on what fp32 accumulation in another order can move a distance)
@@ -1516,8 +1572,7 @@ int oibl_f16r_filter_select(const void* xh, const float* xaux, const float* xn, 
   if (t.ksplit == 2) q.part_stride = half;
   rc = launch_pairwise_f16r<false>(q, st, t.ksplit);
   if (rc) return rc;
-  launch_row_topk(sample, nullptr, m, t.S, (size_t)t.S, k, 0, sval, sidx, nullptr, nullptr, st,
-                  t.ksplit == 2 ? sample + half : nullptr);
+  launch_sample_kth(sample, t.ksplit == 2 ? sample + half : nullptr, m, t.S, k, sval, sidx, st);
   OIBL_LAUNCH_CHECK();
   // 2. the full contraction, keeping the pairs whose filter distance could belong to a member of the true top-k
   q.part_stride = 0;

@@ -32,10 +32,13 @@ _CFG_D = (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 51
 
 
 def default_precision() -> str:
-    """'fp32' (exact fp32 MFMA, reference-grade numerics) unless OPENIBL_AMD_PRECISION is set to
-    'f16mx' (fp16 main term + MX-fp6 cross terms: descriptors within 1e-4 at 1.5 matrix instructions
-    per bf16 one), 'bf16x3' (split bf16: fp32-class descriptors at 3x the bf16 matrix work) or 'bf16'."""
-    return os.environ.get("OPENIBL_AMD_PRECISION", "fp32").lower()
+    """The arithmetic a model runs in when nobody chose one: 'f16mx' (fp16 main term + MX-fp6 cross terms on the
+    gfx950 matrix cores: descriptors within north_star's 1e-4 of the reference's fp32 result, range-guarded, 4x the
+    rate of exact fp32) — what `torch.hub.load(..., 'vgg16_netvlad')(x)` and an unmodified examples/test.py get
+    since round 6.  `OPENIBL_AMD_PRECISION` or `model.set_precision(...)` select 'fp32' (exact fp32 MFMA:
+    reference-grade numerics, 8e-7), 'bf16x3' (split bf16: 4e-6 at 3x the bf16 matrix work) or 'bf16' (3e-3: not a
+    parity mode)."""
+    return os.environ.get("OPENIBL_AMD_PRECISION", "f16mx").lower()
 
 
 class _PrecisionMixin:
@@ -151,23 +154,40 @@ class VGG(_PrecisionMixin, nn.Module):
     F16MX_MIN_TILES = 16
 
     def effective_precision(self, x: torch.Tensor) -> str:
-        """The arithmetic the backbone runs this input in: the module's precision, except for f16mx batches
-        beyond the 32-bit offsets of its kernels (95 images of 480x640 and more) and for f16mx batches of fewer
-        than F16MX_MIN_TILES conv4 ring tiles (where it is the slower of the two 1e-4 modes), which run in
-        bf16x3.  `precision_runs` counts what actually ran."""
+        """The arithmetic the backbone runs this input in: the module's precision, except for f16mx batches of fewer
+        than F16MX_MIN_TILES conv4 ring tiles (where it is the slower of the two 1e-4 modes) and single images beyond
+        the 32-bit offsets of the f16mx kernels, which run in bf16x3.  (A BATCH beyond those offsets — 95 images of
+        480x640 and more — runs f16mx in image groups since round 6: `f16mx_groups`.)  `precision_runs` counts what
+        actually ran."""
         p = self.precision
         if ops.precision_code(p) != ops.F16MX:
             return p
         n = int(x.shape[0])
         h, w = (int(x.shape[1]), int(x.shape[2])) if x.dtype == torch.uint8 else (int(x.shape[2]), int(x.shape[3]))
         tiles = -(-(n * (h // 8) * (w // 8)) // 256) * 2
-        # f16mx kernels address their input through 32-bit buffer offsets and have no other implementation:
-        # the largest activation they read — conv2_2's input, [N][H/2][W/2][128] 4-byte elements (39 MB per
-        # 480x640 image: 95 images) — must stay below 3.5 GB, like the stem's fp32 input (vgg16_f16mx_fits in
-        # csrc/conv.hip is the same test; the C entry point refuses what this lets through)
-        if n * 3 * h * w * 4 >= 0xE0000000 or n * (h // 2) * (w // 2) * 128 * 4 >= 0xE0000000:
+        if self._f16mx_group(h, w) < 1:
             return "bf16x3"
         return p if tiles >= self.F16MX_MIN_TILES else "bf16x3"
+
+    @staticmethod
+    def _f16mx_group(h: int, w: int) -> int:
+        """Images of h x w one f16mx pass takes: its kernels address their input through 32-bit buffer offsets and have
+        no other implementation — the largest activation they read (conv2_2's input, [N][H/2][W/2][128] 4-byte
+        elements: 39 MB per 480x640 image) and the stem's fp32 input must stay below 3.5 GB (vgg16_f16mx_fits in
+        csrc/conv.hip is the same test; the C entry point refuses what this lets through): 94 images of 480x640."""
+        per = max(3 * h * w * 4, (h // 2) * (w // 2) * 128 * 4, 1)
+        return (0xE0000000 - 1) // per
+
+    def f16mx_groups(self, x: torch.Tensor):
+        """[(first image, images)] of the passes an f16mx batch is run in: one, unless the batch is beyond the 32-bit
+        offsets of the kernels — then equal groups of at most `_f16mx_group` images (128 x 480x640: 2 x 64), each a
+        pass of its own into its rows of the feature map, instead of the silent bf16x3 run of rounds 1-5."""
+        n = int(x.shape[0])
+        h, w = (int(x.shape[1]), int(x.shape[2])) if x.dtype == torch.uint8 else (int(x.shape[2]), int(x.shape[3]))
+        cap = max(1, self._f16mx_group(h, w))
+        parts = -(-n // cap)
+        per = -(-n // parts)
+        return [(i, min(per, n - i)) for i in range(0, n, per)]
 
     def _packed(self, device: torch.device, precision: str = None):
         precision = precision or self.precision
@@ -187,22 +207,23 @@ class VGG(_PrecisionMixin, nn.Module):
             hit = self._cache["packed"][precision] = (ws, bs)
         return hit
 
-    def features_nhwc(self, x: torch.Tensor) -> torch.Tensor:
+    def features_nhwc(self, x: torch.Tensor, defer_flag: bool = False) -> torch.Tensor:
         """[N][3][H][W] fp32 (normalised) or [N][H][W][3] uint8 (raw image; the loader's
         ToTensor + Normalize run inside the first kernel) -> conv5_3 map [N][h][w][512] in the
         precision's element type.
 
-        f16mx range guard: the fp16 main term of f16mx exists only for |activation| <= 65504.  The kernels
-        raise a device flag when a layer's output is beyond that (include/openibl_amd.h, OIBL_F16MX); it is
-        read here — one 4-byte copy per batch — and a flagged batch is recomputed in bf16x3, the other mode
-        inside the 1e-4 tolerance, which has no range limit (`range_fallbacks` counts them).  Under a
-        hipGraph capture nothing can be read: the capturer takes `last_range_flag()` and checks it after
-        every replay (extract.GraphedForward does).
-        Cost, stated: the eager f16mx pass ends in `flag.item()` — one host synchronisation per
-        batch, so eager extraction has no host / device overlap in f16mx (the replayed two-lane path settles the
-        flag lazily through a pinned ring and keeps it; `GraphedForward(pipeline=False)` blocks once per call by
-        design: its result is final when the call returns).  `_range_flag` is per-module state of the LAST call:
-        one thread and one stream per model object at a time."""
+        f16mx range guard: the fp16 main term of f16mx exists only for |activation| <= 65504 (x 8: the backbone
+        stores its activations times 2^-3).  The kernels raise a device flag when a layer's output is beyond that
+        (include/openibl_amd.h, OIBL_F16MX) and a flagged batch is recomputed in bf16x3, the other mode inside the
+        1e-4 tolerance, which has no range limit (`range_fallbacks` counts them).  WHERE the flag is read:
+          * defer_flag=False (a bare call): here, one 4-byte copy — a host synchronisation behind the backbone;
+          * defer_flag=True: not here.  The caller enqueues whatever consumes the map first and then calls
+            `settle_range_flag(x)` (the models' forwards do: ONE synchronisation at the end of the whole forward,
+            where the caller's `.cpu()` would wait anyway — round 6), or ships
+            `last_range_flag()` to a pinned word and settles batches later (extract.EagerLanes, GraphedForward);
+          * under a hipGraph capture nothing can be read: the capturer takes `last_range_flag()` and checks it
+            after every replay (extract.GraphedForward does).
+        `_range_flag` is per-module state of the LAST call: one thread and one stream per model object at a time."""
         if x.dtype != torch.uint8 and x.dtype != torch.float32:
             x = x.float()
         x = x.contiguous()
@@ -213,14 +234,36 @@ class VGG(_PrecisionMixin, nn.Module):
         if ops.precision_code(prec) != ops.F16MX:
             self._range_flag = None
             return ops.vgg16_conv5(x, ws, bs, prec, events=ev)
-        feat, flag = ops.vgg16_conv5(x, ws, bs, prec, events=ev, return_flag=True)
+        groups = self.f16mx_groups(x)
+        if len(groups) == 1:
+            feat, flag = ops.vgg16_conv5(x, ws, bs, prec, events=ev, return_flag=True)
+        else:
+            # a batch beyond the kernels' 32-bit offsets: image groups, each pass into its rows of one map; every
+            # pass clears the workspace's flag word when it starts, so the groups' flags are OR-ed into one
+            h, w = ops.vgg16_feature_hw(*((x.shape[1], x.shape[2]) if x.dtype == torch.uint8 else (x.shape[2], x.shape[3])))
+            feat = torch.empty((int(x.shape[0]), h, w, 512), dtype=torch.float32, device=x.device)
+            flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+            for i0, cnt in groups:
+                _, f = ops.vgg16_conv5(x[i0:i0 + cnt], ws, bs, prec, return_flag=True, out=feat[i0:i0 + cnt])
+                flag.bitwise_or_(f)
+            self.precision_runs["f16mx(groups)"] = self.precision_runs.get("f16mx(groups)", 0) + len(groups)
         self._range_flag = flag
-        if torch.cuda.is_current_stream_capturing():
+        if defer_flag or torch.cuda.is_current_stream_capturing():
             return feat
-        if int(flag.item()) != 0:
-            self.range_fallbacks += 1
-            feat = self.features_fallback(x)
-        return feat
+        fb = self.settle_range_flag(x)
+        return feat if fb is None else fb
+
+    def settle_range_flag(self, x: torch.Tensor) -> Optional[torch.Tensor]:
+        """Read the range flag of the last `features_nhwc(x, defer_flag=True)` pass (a host synchronisation with the
+        stream): None when the f16mx map stands, else the batch's map recomputed in bf16x3 — whatever was computed
+        from the flagged map has to be recomputed from this one."""
+        flag = getattr(self, "_range_flag", None)
+        if flag is None or int(flag.item()) == 0:
+            return None
+        self.range_fallbacks += 1
+        if x.dtype != torch.uint8 and x.dtype != torch.float32:
+            x = x.float()
+        return self.features_fallback(x.contiguous())
 
     def last_range_flag(self) -> Optional[torch.Tensor]:
         """The f16mx range flag of the last `features_nhwc` call (int32 [1] view of the first word of that
@@ -234,13 +277,26 @@ class VGG(_PrecisionMixin, nn.Module):
         self.precision_runs["bf16x3(range)"] = self.precision_runs.get("bf16x3(range)", 0) + 1
         return ops.vgg16_conv5(x.contiguous(), ws, bs, "bf16x3")
 
-    @torch.no_grad()
-    def forward(self, x):
-        feat = self.features_nhwc(x)
+    def _outputs(self, feat):
         x_nchw = ops.nhwc_to_nchw_f32(feat)
         if self.cut_at_pooling:
             return x_nchw
         return ops.global_maxpool_nhwc(feat), x_nchw
+
+    @torch.no_grad()
+    def forward(self, x):
+        return _with_range_guard(self, x, self._outputs)
+
+
+def _with_range_guard(base: "VGG", x: torch.Tensor, head):
+    """head(conv5_3 map) with the f16mx range flag settled BEHIND the head's launches: the device never waits for
+    the host inside a forward, and the one synchronisation sits where the caller's first read of the result would
+    wait anyway.  A flagged batch (rare: DESIGN §4.1a) has map and head recomputed in bf16x3."""
+    out = head(base.features_nhwc(x, defer_flag=True))
+    if torch.cuda.is_current_stream_capturing():
+        return out
+    fb = base.settle_range_flag(x)
+    return out if fb is None else head(fb)
 
 
 def vgg16(**kwargs):
@@ -295,11 +351,13 @@ class EmbedNet(_PrecisionMixin, nn.Module):
         self.base_model._init_params()
         self.net_vlad._init_params()
 
-    @torch.no_grad()
-    def forward(self, x):
-        feat = self.base_model.features_nhwc(x)
+    def _head(self, feat):
         _, vlad = self.net_vlad.aggregate_nhwc(feat, want_raw=False, want_norm=True)
         return ops.global_maxpool_nhwc(feat), vlad
+
+    @torch.no_grad()
+    def forward(self, x):
+        return _with_range_guard(self.base_model, x, self._head)
 
 
 class EmbedNetPCA(_PrecisionMixin, nn.Module):
@@ -335,7 +393,7 @@ class EmbedNetPCA(_PrecisionMixin, nn.Module):
 
     @torch.no_grad()
     def forward(self, x):
-        return self.head_from_features(self.base_model.features_nhwc(x))
+        return _with_range_guard(self.base_model, x, self.head_from_features)
 
     def graphed(self, example: torch.Tensor, pipeline: bool = False):
         """hipGraph-replayed forward for a fixed batch shape (see GraphedDescriptor)."""
@@ -382,7 +440,9 @@ class EmbedRegionNet(_PrecisionMixin, nn.Module):
         if self.training:
             raise NotImplementedError("EmbedRegionNet: the SFRS training branch is not part of the "
                                       "MI355X inference path; call .eval() first")
-        feat = self.base_model.features_nhwc(x)
+        return _with_range_guard(self.base_model, x, self._head)
+
+    def _head(self, feat):
         _, vlad = self.net_vlad.aggregate_nhwc(feat, want_raw=False, want_norm=True)
         return ops.global_maxpool_nhwc(feat), vlad
 

@@ -363,7 +363,8 @@ REF_STD = (0.00392156862745098, 0.00392156862745098, 0.00392156862745098)
 
 
 def vgg16_conv5(x: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor],
-                precision, events=None, mean=REF_MEAN, std=REF_STD, return_flag: bool = False):
+                precision, events=None, mean=REF_MEAN, std=REF_STD, return_flag: bool = False,
+                out: Optional[torch.Tensor] = None):
     """conv5_3 feature map [N][h][w][512] T (NHWC), h = H//16, w = W//16, of
       x [N][3][H][W] float32, already normalised (what the reference's loader hands over), or
       x [N][H][W][3] uint8, the raw decoded image: ToTensor + Normalize(mean, std) are folded into
@@ -375,7 +376,10 @@ def vgg16_conv5(x: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequen
     re-recorded right before / after the matrix-core convolutions (bench.py's roofline).
     return_flag: also return the pass's f16mx range flag — an int32 [1] VIEW of the first word of this
     stream's backbone workspace (None in the other precisions): non-zero once the pass has run = an
-    activation was beyond fp16 and `feat` must be recomputed in bf16x3 (models.VGG does)."""
+    activation was beyond fp16 and `feat` must be recomputed in bf16x3 (models.VGG does).
+    out: optional preallocated [N][h][w][512] map (a contiguous slice of a larger batch's map: models.VGG runs an
+    f16mx batch beyond the kernels' 32-bit offsets in image groups).  The entry point clears the flag when a pass
+    starts; a caller running several groups reads it between them (or accumulates it: models.VGG)."""
     p = precision_code(precision)
     dev = _need_cuda(x, *weights, *biases)
     u8 = x.dtype == torch.uint8
@@ -397,7 +401,13 @@ def vgg16_conv5(x: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequen
         raise ValueError(f"vgg16_conv5: unsupported input shape {tuple(x.shape)}")
     ws = workspace(ws_bytes, dev, "vgg")
     # bf16x3: the last layer writes a plain fp32 map for the (fp32) head
-    feat = torch.empty((N, h, w, 512), dtype=_DTYPES[head_precision(p)], device=dev)
+    if out is not None:
+        if tuple(out.shape) != (N, h, w, 512) or out.dtype != _DTYPES[head_precision(p)] or not out.is_contiguous() \
+                or out.device != dev:
+            raise ValueError("vgg16_conv5: `out` must be a contiguous [N][h][w][512] map of the head's element type")
+        feat = out
+    else:
+        feat = torch.empty((N, h, w, 512), dtype=_DTYPES[head_precision(p)], device=dev)
     wp = (C.c_void_p * 13)(*[t.data_ptr() for t in weights])
     bp = (C.c_void_p * 13)(*[t.data_ptr() for t in biases])
     ev0 = ev1 = None

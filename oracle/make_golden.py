@@ -74,6 +74,14 @@ def fake_h5py(datasets):
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser(description=__doc__.splitlines()[0])
+    ap.add_argument("--only", default="", help="comma-separated fixture names (default: all of them)")
+    only = [n for n in ap.parse_args().only.split(",") if n]
+
+    def want(name):
+        return not only or name in only
+
     import ibl  # the reference
     assert ibl.__file__.startswith(refshim.REFERENCE_ROOT), ibl.__file__
     from ibl import models
@@ -88,7 +96,9 @@ def main():
     model = refshim.reference_model(sd)            # hubconf.vgg16_netvlad + load_state_dict
     embednet = models.create("embednet", model.base_model, model.net_vlad).eval()
 
-    def run_descriptor(name, n, h, w, seed, keep_feat_stride=1):
+    def run_descriptor(name, n, h, w, seed, keep_feat_stride=1, light=False):
+        if not want(name):
+            return
         x = synth.images(n, h, w, seed=seed)
         with torch.no_grad():
             desc = model(x)
@@ -100,13 +110,15 @@ def main():
                 ecf_vlad = extract_cnn_feature(embednet, x, vlad=True)
                 ecf_pool = extract_cnn_feature(embednet, x, vlad=False)
         assert torch.equal(pool_x, pool_e)
+        # light: a batch > 2 at full size — the descriptor, the pooled map and the normalised VLAD pin the batch to
+        # the reference; the 1 MB duplicates (raw VLAD, the extra-normalised copies) stay out of the repository
+        extra = {} if light else dict(vlad_raw=vlad_raw.numpy(), ecf_vlad=ecf_vlad.numpy(), ecf_pool=ecf_pool.numpy())
         np.savez_compressed(
             OUT / f"{name}.npz",
             weight_seed=WEIGHT_SEED, image_seed=seed, shape=np.array([n, 3, h, w]),
             feat_stride=keep_feat_stride,
             feat=feat[:, ::keep_feat_stride].numpy(), pool_x=pool_x.numpy(),
-            vlad_raw=vlad_raw.numpy(), vlad_norm=vlad_norm.numpy(), desc=desc.numpy(),
-            ecf_pca=ecf_pca.numpy(), ecf_vlad=ecf_vlad.numpy(), ecf_pool=ecf_pool.numpy())
+            vlad_norm=vlad_norm.numpy(), desc=desc.numpy(), ecf_pca=ecf_pca.numpy(), **extra)
         print(name, "desc", tuple(desc.shape), "feat", tuple(feat.shape),
               "row norms", desc.norm(dim=1).tolist()[:2],
               "d2(img0,img1)" if n > 1 else "", float((desc[0] - desc[-1]).pow(2).sum()) if n > 1 else "")
@@ -114,8 +126,18 @@ def main():
     run_descriptor("desc_small", 2, 64, 96, seed=11)
     run_descriptor("desc_odd", 2, 70, 90, seed=13)          # not multiples of 16: pools floor
     run_descriptor("desc_480x640", 1, 480, 640, seed=12, keep_feat_stride=8)   # BASELINE config[0]
+    # a batch > 2 at BASELINE configs[1]'s image size, from the reference itself (round 6)
+    run_descriptor("desc_480x640_n8", 8, 480, 640, seed=14, keep_feat_stride=32, light=True)
 
     # ---- PCA.load / PCA.infer -------------------------------------------------------------
+    if want("pca"):
+        _run_pca(PCA)
+
+    # ---- matching ---------------------------------------------------------------------------
+    _run_matching_and_rest(want, pairwise_distance, evaluate_all, spatial_nms)
+
+
+def _run_pca(PCA):
     rng = np.random.default_rng([7, 7])
     D, d, npts = 256, 128, 300                       # small stand-in for 32768 -> 4096
     U = np.linalg.qr(rng.standard_normal((D, D)))[0][:, :160].astype(np.float32)
@@ -138,11 +160,19 @@ def main():
                         n_components=d, **res)
     print("pca", res["out_whiten"].shape)
 
-    # ---- matching ---------------------------------------------------------------------------
-    def run_matching(name, Q, G, seed, views_per_place, dim=4096):
-        q, g, gt, pids = synth.retrieval_problem(Q, G, dim=dim, seed=seed,
-                                                 views_per_place=views_per_place,
-                                                 hard_fraction=0.5, hard_noise_mult=35.0)
+
+def _run_matching_and_rest(want, pairwise_distance, evaluate_all, spatial_nms):
+    def run_matching(name, Q, G, seed, views_per_place, dim=4096, tokyo=False):
+        if not want(name):
+            return
+        if tokyo:
+            # Tokyo 24/7-shaped (synth.tokyo_problem: near-duplicate views, one true place + distractor places per
+            # query): the flow examples/test.py:130 runs with nms=True, through the reference's own evaluate_all
+            q, g, gt, pids = synth.tokyo_problem(Q, G, dim=dim, seed=seed, views=views_per_place, distractors=8)
+        else:
+            q, g, gt, pids = synth.retrieval_problem(Q, G, dim=dim, seed=seed,
+                                                     views_per_place=views_per_place,
+                                                     hard_fraction=0.5, hard_noise_mult=35.0)
         features = OrderedDict()
         query = [(f"q{i:05d}.jpg", 100000 + i, 0.0, 0.0) for i in range(Q)]
         gallery = [(f"g{j:05d}.jpg", pids[j], 0.0, 0.0) for j in range(G)]
@@ -164,6 +194,14 @@ def main():
         for i, r in enumerate(nms_rows):
             nms_arr[i, : len(r)] = r
         assert np.array_equal(xq, q.numpy()) and np.array_equal(yg, g.numpy())
+        if tokyo:
+            # (no matrix in the file: 48 x 7200 floats; the ranked prefix spatial_nms reads + the reference's recalls)
+            np.savez_compressed(OUT / f"{name}.npz", Q=Q, G=G, dim=dim, seed=seed, views=views_per_place,
+                                distractors=8, recalls=rec, recalls_nms=rec_nms, nms_rows=nms_arr,
+                                top120=np.argsort(distmat.numpy(), axis=1, kind="stable")[:, :120].astype(np.int32),
+                                top120_dist=np.sort(distmat.numpy(), axis=1)[:, :120])
+            print(name, "recalls", rec, "nms", rec_nms)
+            return
         np.savez_compressed(OUT / f"{name}.npz", Q=Q, G=G, dim=dim, seed=seed,
                             views_per_place=views_per_place, hard_fraction=0.5,
                             hard_noise_mult=35.0, distmat=distmat.numpy(),
@@ -173,6 +211,8 @@ def main():
 
     def run_rerank(name, Q, G, seed, dim=256):
         """ibl.utils.rerank.re_ranking (rerank.py:32-100) on the reference's own distance matrices."""
+        if not want(name):
+            return
         from ibl.utils.rerank import re_ranking
         q, g, _, _ = synth.retrieval_problem(Q, G, dim=dim, seed=seed, views_per_place=4,
                                              hard_fraction=0.5, hard_noise_mult=35.0)
@@ -187,6 +227,8 @@ def main():
     def run_sort_gallery(name, Q, G, seed):
         """DistributedRandomTupleSampler.sort_gallery (ibl/utils/data/sampler.py:46-54): the full-row
         torch.argsort the hard-negative mining consumes, on a tie-free seeded matrix."""
+        if not want(name):
+            return
         from ibl.utils.data.sampler import DistributedRandomTupleSampler
         distmat = synth.tie_free_matrix(Q, G, seed)    # a jittered permutation per row
         assert all(len(np.unique(r)) == G for r in distmat.numpy()), "ties: argsort order unspecified"
@@ -219,6 +261,8 @@ def main():
         scikit-learn sums in float32 in thread-dependent chunks: two runs of this very call differ in
         the last bit of some centre coordinates (seen: 6e-8), so unlike every other fixture this one
         regenerates to one ulp, not bit for bit — the committed file is one such run."""
+        if not want(name):
+            return
         import sklearn
         from sklearn.cluster import KMeans
         out = {"sklearn_version": sklearn.__version__, "seed": seed}
@@ -234,6 +278,8 @@ def main():
         """DistributedRandomDiffTupleSampler (ibl/utils/data/sampler.py:92-190; the SFRS mining
         sampler): sort_gallery + two epochs of tuples on two replicas, seeded `random`, tie-free
         descriptor and Jaccard matrices, 8 positives per query of which pos_pool = 6 are ranked."""
+        if not want(name):
+            return
         import random
         from ibl.utils.data.sampler import DistributedRandomDiffTupleSampler
         distmat = synth.tie_free_matrix(Q, G, seed)
@@ -258,6 +304,7 @@ def main():
     run_rerank("rerank_small", 24, 90, seed=31)
     run_matching("match_small", 48, 300, seed=21, views_per_place=1)
     run_matching("match_nms", 40, 360, seed=22, views_per_place=12)
+    run_matching("match_tokyo", 48, 7200, seed=23, views_per_place=12, dim=256, tokyo=True)
     # tiny-dimension case with many exact ties is deliberately absent: np.argsort's tie order is
     # unspecified in the reference (evaluators.py:143).
 

@@ -6,6 +6,11 @@ import numpy as np
 import pytest
 import torch
 
+# The suite is written against the EXACT mode (fp32 MFMA) wherever a test does not name an arithmetic: a model nobody
+# called set_precision() on runs f16mx since round 6 (openibl_amd.models.default_precision), and the tests that mean
+# that default say so (tests/test_gpu_api.py::test_default_precision_is_the_fast_parity_mode removes the variable).
+os.environ.setdefault("OPENIBL_AMD_PRECISION", "fp32")
+
 ROOT = Path(__file__).resolve().parent.parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))

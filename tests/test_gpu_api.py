@@ -405,3 +405,77 @@ def test_captured_forwards_survive_between_extractions_and_die_with_their_state(
     copy.deepcopy(core.net_vlad)
     release_graphs(model)
     assert core not in _GRAPH_STORES
+
+
+def test_default_precision_is_the_fast_parity_mode(dev, state_dict, monkeypatch):
+    """What a drop-in user gets (round 6): `torch.hub.load(<repo>, 'vgg16_netvlad')` with no
+    environment variable and no set_precision() runs the backbone in f16mx — and its descriptor of the reference's
+    480x640 vector is within north_star's 1e-4 of what the reference computed (tests/golden/desc_480x640.npz); fp32
+    stays selectable.  (conftest.py pins the variable to 'fp32' for the rest of the suite.)"""
+    from pathlib import Path
+    from openibl_amd import models
+    monkeypatch.delenv("OPENIBL_AMD_PRECISION", raising=False)
+    assert models.default_precision() == "f16mx"
+    repo = str(Path(__file__).resolve().parent.parent)
+    model = torch.hub.load(repo, "vgg16_netvlad", source="local", pretrained=False)
+    model.load_state_dict(state_dict)
+    model = model.to(dev).eval()
+    assert model.precision == "f16mx" and model.base_model.precision == "f16mx"
+    g = load_golden("desc_480x640")
+    x = synth.images(1, 480, 640, seed=int(g["image_seed"])).to(dev)
+    desc = model(x)
+    assert model.base_model.precision_runs == {"f16mx": 1} and model.base_model.range_fallbacks == 0
+    assert rel_l2(desc.cpu(), g["desc"]) <= 1e-4
+    print(f"default precision f16mx: desc rel-L2 vs the reference {rel_l2(desc.cpu(), g['desc']):.2e}")
+    monkeypatch.setenv("OPENIBL_AMD_PRECISION", "fp32")
+    assert models.default_precision() == "fp32" and model.precision == "fp32"
+    assert rel_l2(model(x).cpu(), g["desc"]) <= 4e-6
+
+
+def test_batch_beyond_the_32bit_offsets_runs_f16mx_in_image_groups(dev, state_dict):
+    """128 images of 480x640: conv2_2's input is 5 GB, beyond the 32-bit buffer offsets of the f16mx kernels (95
+    images) — rounds 1-5 ran such a batch in bf16x3 without saying so; it now runs f16mx in two groups of 64, each a
+    pass of its own into its rows of the map (round 6): bit-equal to the two halves on their own."""
+    import hubconf
+    model = hubconf.vgg16_netvlad(pretrained=False)
+    model.load_state_dict(state_dict)
+    model = model.to(dev).eval().set_precision("f16mx")
+    x = synth.images(128, 480, 640, seed=77).to(dev)
+    assert model.base_model.effective_precision(x) == "f16mx"
+    assert model.base_model.f16mx_groups(x) == [(0, 64), (64, 64)]
+    desc = model(x)
+    runs = dict(model.base_model.precision_runs)
+    assert runs.get("f16mx(groups)") == 2 and "bf16x3" not in runs and model.base_model.range_fallbacks == 0
+    a, b = model(x[:64].contiguous()), model(x[64:].contiguous())
+    assert torch.equal(desc[:64], a) and torch.equal(desc[64:], b)
+    want = od.embednetpca(x[125:128].cpu(), state_dict)
+    assert rel_l2(desc[125:128].cpu(), want) <= 1e-4
+
+
+def test_forward_settles_the_range_flag_behind_the_head(dev, state_dict):
+    """`model(x)` in f16mx: the flag is read once, BEHIND the head's launches (round 6) — an ordinary batch and a batch
+    that leaves the fp16 range both come out as before: the flagged one recomputed in bf16x3, head included."""
+    import hubconf
+    from test_gpu_range import _scaled, ACT_HEADROOM
+    sd = _scaled(state_dict, 2000.0 * ACT_HEADROOM)
+    model = hubconf.vgg16_netvlad(pretrained=False)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval().set_precision("f16mx")
+    model.base_model.F16MX_MIN_TILES = 0
+    x = synth.images(2, 64, 96, seed=5)
+    ok = model(x.to(dev))
+    assert model.base_model.range_fallbacks == 0
+    big = model((x * 2000.0 * ACT_HEADROOM).to(dev))
+    assert model.base_model.range_fallbacks == 1
+    model.set_precision("bf16x3")
+    want_ok, want_big = model(x.to(dev)), model((x * 2000.0 * ACT_HEADROOM).to(dev))
+    assert torch.equal(big, want_big)                       # the fallback IS the bf16x3 forward
+    assert rel_l2(ok.cpu(), want_ok.cpu()) <= 1e-4
+    # the other forwards share the helper: EmbedNet and the bare backbone
+    from ibl import models
+    emb = models.create("embednet", model.base_model, model.net_vlad).eval().set_precision("f16mx")
+    emb.base_model.F16MX_MIN_TILES = 0
+    p1, v1 = emb((x * 2000.0 * ACT_HEADROOM).to(dev))
+    emb.set_precision("bf16x3")
+    p2, v2 = emb((x * 2000.0 * ACT_HEADROOM).to(dev))
+    assert torch.equal(v1, v2) and torch.equal(p1, p2)

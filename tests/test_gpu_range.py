@@ -307,3 +307,10 @@ def _extract_flow(dev, state_dict, ev, _GRAPH_STORES, unwrap_model):
     eager = torch.cat([ev.extract_cnn_feature(model, b[0], gpu=dev.index).cpu() for b in batches])
     assert model.base_model.range_fallbacks - before == len(big)
     assert torch.equal(torch.stack(list(feats.values())), eager)
+    # round 6: the UNCAPTURED route (use_graphs=False: extract.EagerLanes) settles the flag lazily too — the same two
+    # lanes with eager launches, no host synchronisation per batch; batch 0 is settled at once (it tells the width),
+    # batches 1..9 through the pinned ring: bit-identical rows, the same batches re-run
+    before = model.base_model.range_fallbacks
+    feats2 = ev.extract_features(model, Loader(batches), names, gpu=dev.index, use_graphs=False)
+    assert model.base_model.range_fallbacks - before == len(big)
+    assert torch.equal(torch.stack(list(feats2.values())), eager)

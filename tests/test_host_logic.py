@@ -476,9 +476,16 @@ def test_effective_precision_and_its_counters_host_side():
     for n in (1, 2, 6, 7, 32, 94):
         assert m.effective_precision(torch.empty((n, 3, 480, 640), device="meta")) == "f16mx"
         assert m.effective_precision(torch.empty((n, 480, 640, 3), dtype=torch.uint8, device="meta")) == "f16mx"
-    assert m.effective_precision(torch.empty((96, 3, 480, 640), device="meta")) == "bf16x3"
-    assert m.effective_precision(torch.empty((96, 480, 640, 3), dtype=torch.uint8, device="meta")) == "bf16x3"
-    assert m.effective_precision(torch.empty((24, 3, 960, 1280), device="meta")) == "bf16x3"
+    # beyond the kernels' 32-bit offsets a batch runs f16mx in image groups (round 6; bf16x3, silently, before)
+    for shape in ((96, 3, 480, 640), (128, 3, 480, 640), (24, 3, 960, 1280)):
+        assert m.effective_precision(torch.empty(shape, device="meta")) == "f16mx"
+    assert m.effective_precision(torch.empty((96, 480, 640, 3), dtype=torch.uint8, device="meta")) == "f16mx"
+    assert m._f16mx_group(480, 640) == 95 and m.f16mx_groups(torch.empty((94, 3, 480, 640), device="meta")) == [(0, 94)]
+    assert m.f16mx_groups(torch.empty((128, 3, 480, 640), device="meta")) == [(0, 64), (64, 64)]
+    assert m.f16mx_groups(torch.empty((200, 480, 640, 3), dtype=torch.uint8, device="meta")) == [(0, 67), (67, 67), (134, 66)]
+    assert m.f16mx_groups(torch.empty((24, 3, 960, 1280), device="meta")) == [(0, 12), (12, 12)]
+    # (one image too large for a pass at all: bf16x3, which has 64-bit addressing)
+    assert m.effective_precision(torch.empty((1, 3, 12000, 16000), device="meta")) == "bf16x3"
     for shape, want in (((1, 3, 224, 224), "bf16x3"), ((2, 3, 224, 224), "bf16x3"), ((3, 3, 224, 224), "f16mx"),
                         ((1, 3, 320, 320), "bf16x3"), ((1, 3, 384, 384), "f16mx"), ((1, 3, 480, 480), "f16mx"),
                         ((1, 3, 64, 96), "bf16x3")):

@@ -9,11 +9,21 @@ from openibl_amd import synth
 from oracle import descriptor as od
 from oracle import matching as om
 
-# fp32 on a possibly different CPU (other SIMD width -> other summation order in oneDNN/MKL)
-TOL = 2e-5
+# fp32 on a possibly different CPU (other SIMD width -> other summation order in oneDNN/MKL).  Round 6 (VERDICT r05 item
+# 8): the bound is 2.7x the largest difference the oracle shows against the reference's vectors in this container
+# (descriptors 7.3e-7, normalised VLAD 1.9e-7, feature maps bit-equal; it was 2e-5 / 5e-5 — half of north_star's
+# budget), so that the chain reference -> oracle -> HIP path (f16mx <= 4e-5) cannot add up to 1e-4.
+TOL = 2e-6
+OBSERVED = {}
 
 
-@pytest.mark.parametrize("name", ["desc_small", "desc_odd", "desc_480x640"])
+def _close(name, got, want, tol):
+    from conftest import rel_l2
+    OBSERVED[name] = max(OBSERVED.get(name, 0.0), rel_l2(got, want))
+    assert_rel_l2(name, got, want, tol)
+
+
+@pytest.mark.parametrize("name", ["desc_small", "desc_odd", "desc_480x640", "desc_480x640_n8"])
 def test_descriptor_pipeline_matches_reference(name, state_dict):
     g = load_golden(name)
     n, _, h, w = [int(v) for v in g["shape"]]
@@ -22,17 +32,20 @@ def test_descriptor_pipeline_matches_reference(name, state_dict):
         out = od.embednetpca(x, state_dict, return_intermediates=True)
         pool = od.global_max(out["feat"])
         ecf = od.extract_cnn_feature(x, state_dict)
-        ecf_vlad = od.extract_cnn_feature(x, state_dict, vlad=True, with_pca=False)
-        ecf_pool = od.extract_cnn_feature(x, state_dict, vlad=False, with_pca=False)
     s = int(g["feat_stride"])
-    assert_rel_l2("feat", out["feat"][:, ::s], g["feat"], TOL)
-    assert_rel_l2("pool_x", pool, g["pool_x"], TOL)
-    assert_rel_l2("vlad_raw", out["vlad_raw"], g["vlad_raw"], 5e-5)
-    assert_rel_l2("vlad_norm", out["vlad_norm"], g["vlad_norm"], 5e-5)
-    assert_rel_l2("desc", out["desc"], g["desc"], 5e-5)
-    assert_rel_l2("extract_cnn_feature(pca)", ecf, g["ecf_pca"], 5e-5)
-    assert_rel_l2("extract_cnn_feature(vlad)", ecf_vlad, g["ecf_vlad"], 5e-5)
-    assert_rel_l2("extract_cnn_feature(pool)", ecf_pool, g["ecf_pool"], TOL)
+    _close("feat", out["feat"][:, ::s], g["feat"], TOL)
+    _close("pool_x", pool, g["pool_x"], TOL)
+    _close("vlad_norm", out["vlad_norm"], g["vlad_norm"], TOL)
+    _close("desc", out["desc"], g["desc"], TOL)
+    _close("extract_cnn_feature(pca)", ecf, g["ecf_pca"], TOL)
+    if "vlad_raw" in g:          # (the batch-8 fixture keeps only what pins a batch: make_golden.py, light=True)
+        with torch.no_grad():
+            ecf_vlad = od.extract_cnn_feature(x, state_dict, vlad=True, with_pca=False)
+            ecf_pool = od.extract_cnn_feature(x, state_dict, vlad=False, with_pca=False)
+        _close("vlad_raw", out["vlad_raw"], g["vlad_raw"], TOL)
+        _close("extract_cnn_feature(vlad)", ecf_vlad, g["ecf_vlad"], TOL)
+        _close("extract_cnn_feature(pool)", ecf_pool, g["ecf_pool"], TOL)
+    print("observed rel-L2, oracle vs the reference's vectors:", {k: f"{v:.2e}" for k, v in OBSERVED.items()})
 
 
 def test_netvlad_gemm_form_equals_residual_form():
@@ -52,7 +65,7 @@ def test_oracle_fp64_close_to_fp32(state_dict):
     with torch.no_grad():
         a = od.embednetpca(x, state_dict, dtype=torch.float32)
         b = od.embednetpca(x, state_dict, dtype=torch.float64)
-    assert_rel_l2("fp32 vs fp64 oracle", a, b, 2e-5)
+    assert_rel_l2("fp32 vs fp64 oracle", a, b, 4e-6)
 
 
 @pytest.mark.parametrize("tag", ["whiten", "nowhiten"])
@@ -61,7 +74,7 @@ def test_pca_projection_matches_reference(tag):
     w = torch.from_numpy(g[f"weight_{tag}"])
     b = torch.from_numpy(g[f"bias_{tag}"])
     out = od.pca_project(torch.from_numpy(g["data"]), w, b)
-    assert_rel_l2(f"pca {tag}", out, g[f"out_{tag}"], TOL)
+    assert_rel_l2(f"pca {tag}", out, g[f"out_{tag}"], 2e-6)
 
 
 @pytest.mark.parametrize("name", ["match_small", "match_nms"])
@@ -81,6 +94,29 @@ def test_matching_matches_reference(name):
     np.testing.assert_array_equal(om.evaluate_all(g["distmat"], gt, pids, nms=True),
                                   g["recalls_nms"])
     order = om.ranking(g["distmat"])
+    for i, row in enumerate(g["nms_rows"]):
+        want = [int(v) for v in row if v >= 0]
+        assert om.spatial_nms(order[i].tolist(), pids, 120) == want
+
+
+def test_tokyo_shaped_nms_flow_matches_reference():
+    """A Tokyo 24/7-shaped problem (12 near-duplicate views per place, distractor places: synth.tokyo_problem) through
+    the REFERENCE's pairwise_distance + evaluate_all(nms=True) (examples/test.py:130; tests/golden/match_tokyo.npz):
+    the oracle's matrix, its 120-rank prefix, the NMS'd lists and both recalls are the reference's."""
+    g = load_golden("match_tokyo")
+    q, gal, gt, pids = synth.tokyo_problem(int(g["Q"]), int(g["G"]), dim=int(g["dim"]), seed=int(g["seed"]),
+                                           views=int(g["views"]), distractors=int(g["distractors"]))
+    d = om.pairwise_distance(q, gal).numpy()
+    order = om.ranking(d)
+    np.testing.assert_allclose(np.take_along_axis(d, order[:, :120], axis=1), g["top120_dist"], rtol=0, atol=2e-6)
+    agree = (order[:, :120] == g["top120"])
+    if not agree.all():          # another CPU may round a near-tie the other way: then the two distances are within 2e-6
+        r, c = np.argwhere(~agree).T
+        assert np.abs(d[r, order[r, c]] - d[r, g["top120"][r, c]]).max() <= 2e-6
+    assert agree.mean() > 0.999
+    np.testing.assert_array_equal(om.evaluate_all(d, gt, pids), g["recalls"])
+    np.testing.assert_array_equal(om.evaluate_all(d, gt, pids, nms=True), g["recalls_nms"])
+    assert g["recalls_nms"][2] > g["recalls"][2]                       # the NMS window matters on this problem
     for i, row in enumerate(g["nms_rows"]):
         want = [int(v) for v in row if v >= 0]
         assert om.spatial_nms(order[i].tolist(), pids, 120) == want
