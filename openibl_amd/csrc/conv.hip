@@ -2095,6 +2095,15 @@ __device__ static inline void x3_split_pair(float v0, float v1, uint32_t& hi, ui
   lo = pack_bf16x2(v0 - __builtin_bit_cast(float, hi << 16), v1 - __builtin_bit_cast(float, hi & 0xffff0000u));
 }
 
+// the lane id, recomputed where it is needed (two VALU instructions, never hoisted): at 128 VGPRs the f16mx stem has
+// no register to keep `lane >> 5` alive across its loops — the allocator parked it in scratch and reloaded it once
+// per tile in front of a vmcnt(0) (round 6, after the b128 tails took three more registers)
+__device__ static inline int fresh_lane_id() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
 constexpr int S3_W_BYTES = 2 * 9 * 32 * 128;
 constexpr int S3_BIAS_OFF = S3_W_BYTES + 2 * ST_HALO_BYTES;   // conv1_1 bias: 64 floats; MX: + this half's 32 of conv1_2
 constexpr int S3_LDS_BYTES = S3_BIAS_OFF + 256 + 128;
@@ -2214,7 +2223,14 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
     // halo pixel of this lane in block bi: r = 32 (pw + 4 bi) + l31 (clamped to the last pixel for the
     // 12 surplus lanes of block 10), (hy, hx) = (r / 34, r % 34); kept per block: the swizzle of its
     // LDS row and its element offset from the tile's halo origin (the rest is recomputed where needed)
-    auto row_of = [&](int bi) __attribute__((always_inline)) { return 32 * (pw + bi) + l31; };
+    // f16mx (round 6): lanes 0-7 of a block take its EVEN pixels 0, 2, .., 14, lanes 8-15 the odd ones (and so on
+    // for pixels 16-31).  A line write is serviced in contiguous 8-lane groups over 32 banks, and the slot swizzle
+    // ((hx >> 1) & 7) gives two neighbouring pixels the same slot: with lane = pixel every 16-byte write of a line
+    // was a 2-way conflict (884 extra LDS cycles per tile, tools/lds_stem_model.py — with the consumers' tail reads,
+    // below, the 2.0e8 SQ_LDS_BANK_CONFLICT cycles per launch of profiles/r05_z_pmc.md: 2604 per tile measured,
+    // 2612 modelled).  Which halo pixel a producer lane computes is free: only this function says.
+    const int lpix = MX ? 2 * (l31 & 7) + ((l31 >> 3) & 1) + 16 * (l31 >> 4) : l31;
+    auto row_of = [&](int bi) __attribute__((always_inline)) { return 32 * (pw + bi) + lpix; };
     auto hyx_of = [&](int bi, int& hy, int& hx) __attribute__((always_inline)) {
       const int r = row_of(bi), rc = r < ST_HALO_PX ? r : ST_HALO_PX - 1;
       hy = rc / C64_HW;
@@ -2323,8 +2339,7 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
         const bool interior = is_interior(ty, tx);
         if (has_block) {
           constexpr int bi = 0;
-          int hsel = half;
-          asm volatile("" : "+v"(hsel));
+          const int hsel = fresh_lane_id() >> 5;
           bool in = true, ya = true, yc = true;
           int shift = -1;
           xfix[bi] = 0;
@@ -2418,8 +2433,7 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
           const unsigned b0 = __builtin_amdgcn_perm(w[2][0], t, 0x05040100u);
           const unsigned b1 = __builtin_amdgcn_alignbyte(w[2][1], w[2][0], 2u);
           const unsigned b2 = __builtin_amdgcn_alignbyte(w[2][2], w[2][1], 2u) & 0x00ffffffu;
-          int hsel = half;
-          asm volatile("" : "+v"(hsel));
+          const int hsel = fresh_lane_id() >> 5;
           const unsigned dw[4] = {hsel ? b0 : w[0][0], hsel ? b1 : w[0][1], hsel ? b2 : a2, hsel ? 0u : a3};
 #pragma unroll
           for (int j = 0; j < 16; ++j) {
@@ -2472,6 +2486,7 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
       // slot 4 / 5 (hi / lo: dwords 0-3) and slot 6 / 7 (dwords 4, 5, zero, scale byte)
       char* row = buf + row_of(bi) * 128;
       const int sw = g_swz[bi];
+      const int half = fresh_lane_id() >> 5;     // (shadows the kernel's: see fresh_lane_id)
       *reinterpret_cast<u4*>(row + (((2 * half) ^ sw) << 4)) = (u4){ph16[0], ph16[1], ph16[2], ph16[3]};
       *reinterpret_cast<u4*>(row + (((2 * half + 1) ^ sw) << 4)) = (u4){ph16[4], ph16[5], ph16[6], ph16[7]};
       if (half == 0) {
@@ -2642,9 +2657,10 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
       e_kx[1] = (lx & 1) ? e_kx[2] : e_kx[0];
       pxb = (ly * C64_HW + lx) * 128;
     }
-    int w_off[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) w_off[kk] = l31 * 128 + (((2 * kk + half) ^ ((l31 >> 1) & 7)) << 4);
+    // weight row of this lane; slot 2 kk + half of its line = w_base ^ (kk << 5) (the slot bits XOR; ONE register for
+    // the four fragment addresses: the b128 tails cost three registers this 128-VGPR kernel did not have)
+    int w_base = l31 * 128 + ((half ^ ((l31 >> 1) & 7)) << 4);
+    auto w_off = [&](int kk) __attribute__((always_inline)) { return w_base ^ (kk << 5); };
     // (the builtin, not inline asm: the compiler models a pending global_load_lds as a FLAT access and turns
     //  every later lgkmcnt wait into lgkmcnt(0) until IT has seen vmcnt(0))
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
@@ -2655,10 +2671,15 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
     // operand registers, single-buffered: a fragment is reloaded for the next tap right behind the last
     // MFMA that reads it, and the MFMA order (w0.b0, w0.b1, w1.b0, w1.b1, wm.b0, wm.b1 — accumulators
     // alternate) leaves every reload at least four MFMAs (128 cycles) before its first use
+    // (round 6) the MX operand's tail — e2m3 dwords 4, 5, a zero dword, the scale byte: one 16-byte slot of the line —
+    // is read as ONE ds_read_b128, the scale taken from dword 7 of the operand.  As ds_read_b64 + ds_read_b32 (rounds
+    // 3-5: the form the ring kernels keep, whose loop is not bound by LDS cycles) the 32 lanes of a b64 group reach
+    // 16 of their 32 bank pairs and the 32 scale dwords sit on 8 banks: 12 LDS cycles per tail instead of 4, 1728
+    // extra cycles per tile on the one role whose passes ARE the LDS port's time (4 waves x 48 cycles x 18 taps =
+    // the 3456 matrix-pipe cycles of a SIMD: tools/lds_stem_model.py).
     f16x8_t w0, w1, b0[2], b1[2];
     u4 wma, bma[2];
-    u2 wmd, bmd[2];
-    unsigned wms, bms[2];
+    u4 wmt, bmt[2];
     auto run_pass = [&](auto h_c) __attribute__((always_inline)) {
       constexpr int h = decltype(h_c)::value;
       const unsigned long long c0 = cprof ? __builtin_amdgcn_s_memtime() : 0;
@@ -2684,22 +2705,22 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
       auto ld_b1 = [&](int tap, int i, int a) __attribute__((always_inline)) { b1[i] = *reinterpret_cast<const f16x8_t*>(pbase(tap, i) + a); };
       auto ld_bm = [&](int tap, int i, int a2, int a3) __attribute__((always_inline)) {
         bma[i] = *reinterpret_cast<const u4*>(pbase(tap, i) + a2);
-        bmd[i] = *reinterpret_cast<const u2*>(pbase(tap, i) + a3);
-        bms[i] = *reinterpret_cast<const unsigned*>(pbase(tap, i) + a3 + 12);
+        bmt[i] = *reinterpret_cast<const u4*>(pbase(tap, i) + a3);
       };
-      auto ld_w0 = [&](int tap) __attribute__((always_inline)) { w0 = *reinterpret_cast<const f16x8_t*>(smem + tap * 4096 + w_off[0]); };
-      auto ld_w1 = [&](int tap) __attribute__((always_inline)) { w1 = *reinterpret_cast<const f16x8_t*>(smem + tap * 4096 + w_off[1]); };
+      auto ld_w0 = [&](int tap) __attribute__((always_inline)) { w0 = *reinterpret_cast<const f16x8_t*>(smem + tap * 4096 + w_off(0)); };
+      auto ld_w1 = [&](int tap) __attribute__((always_inline)) { w1 = *reinterpret_cast<const f16x8_t*>(smem + tap * 4096 + w_off(1)); };
       auto ld_wm = [&](int tap) __attribute__((always_inline)) {
-        wma = *reinterpret_cast<const u4*>(smem + tap * 4096 + w_off[2]);
-        wmd = *reinterpret_cast<const u2*>(smem + tap * 4096 + w_off[3]);
-        wms = *reinterpret_cast<const unsigned*>(smem + tap * 4096 + w_off[3] + 12);
+        wma = *reinterpret_cast<const u4*>(smem + tap * 4096 + w_off(2));
+        wmt = *reinterpret_cast<const u4*>(smem + tap * 4096 + w_off(3));
       };
       auto mx = [&](int i) __attribute__((always_inline)) {
-        const i32x8_t a8 = __builtin_shufflevector(__builtin_bit_cast(i4, wma),
-                                                   __builtin_bit_cast(i4, (u4){wmd.x, wmd.y, wms, 0u}), 0, 1, 2, 3, 4, 5, 6, 7);
-        const i32x8_t b8 = __builtin_shufflevector(__builtin_bit_cast(i4, bma[i]),
-                                                   __builtin_bit_cast(i4, (u4){bmd[i].x, bmd[i].y, bms[i], 0u}), 0, 1, 2, 3, 4, 5, 6, 7);
-        acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[i], 2, 2, 0, a8[6], 0, b8[6]);
+        // e2m3 x e2m3 (cbsz = blgp = 2): registers 0-5 of either operand; its scale: byte 0 of register 7 = the
+        // tail slot's last dword [d4 d5 0 scale]
+        const i32x8_t a8 = __builtin_shufflevector(__builtin_bit_cast(i4, wma), __builtin_bit_cast(i4, wmt),
+                                                   0, 1, 2, 3, 4, 5, 6, 7);
+        const i32x8_t b8 = __builtin_shufflevector(__builtin_bit_cast(i4, bma[i]), __builtin_bit_cast(i4, bmt[i]),
+                                                   0, 1, 2, 3, 4, 5, 6, 7);
+        acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[i], 2, 2, 0, a8[7], 0, b8[7]);
       };
       {
         const int a0 = paddr(0, 0), a1 = paddr(0, 1), a2 = paddr(0, 2), a3 = paddr(0, 3);
@@ -2773,18 +2794,19 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
         ct[1] += c2 - c1;
         if (h == 0) ct0w += c2 - c1;
       }
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) w_off[kk] += h == 0 ? 9 * 32 * 128 : -(9 * 32 * 128);
+      w_base += h == 0 ? 9 * 32 * 128 : -(9 * 32 * 128);     // (a multiple of 4096: the slot bits stay)
     };
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
-    const float* const bias2 = reinterpret_cast<const float*>(smem + S3_BIAS_OFF) + 64 + 16 * half;
     for (int it = 0; it < niter; ++it) {
       run_pass(C0{});
       run_pass(C1{});
       const unsigned long long e0 = cprof ? __builtin_amdgcn_s_memtime() : 0;
       // 2x2 max-pool (the window = the lane quad: two DPP steps), bias, ReLU, pack, store.  Lane quad q of
       // block i is pooled pixel (wave, 8 i + q) of the tile's 4 x 16.
+      const int lane_e = fresh_lane_id();
+      const int half = lane_e >> 5, l31 = lane_e & 31;   // (shadow the kernel's: nothing lane-derived stays live across the passes)
+      const float* const bias2 = reinterpret_cast<const float*>(smem + S3_BIAS_OFF) + 64 + 16 * half;
       const int tile = first + it * stride;
       const unsigned r2 = (unsigned)tile / (unsigned)p.tiles_x;
       const int tx = tile - (int)r2 * p.tiles_x;

@@ -387,9 +387,11 @@ def test_small_batch_threshold_is_a_knob_and_off_by_default(dev, state_dict):
     assert m.base_model.precision_runs == {"bf16x3": 1}
     m.set_precision("bf16x3")
     assert torch.equal(m(one), got)
-    # 95 images of 480x640 and more: beyond the 32-bit offsets of the f16mx kernels (conv2_2's input)
+    # 96 images of 480x640 and more are beyond the 32-bit offsets of the f16mx kernels (conv2_2's input): f16mx in
+    # image groups since round 6 (tests/test_gpu_api.py runs 128), bf16x3 before
     m.set_precision("f16mx")
     m.base_model.F16MX_MIN_TILES = 0
     assert m.base_model.effective_precision(torch.empty((94, 3, 480, 640), device="meta")) == "f16mx"
-    assert m.base_model.effective_precision(torch.empty((96, 3, 480, 640), device="meta")) == "bf16x3"
-    assert m.base_model.effective_precision(torch.empty((32, 3, 960, 1280), device="meta")) == "bf16x3"
+    assert m.base_model.effective_precision(torch.empty((96, 3, 480, 640), device="meta")) == "f16mx"
+    assert m.base_model.f16mx_groups(torch.empty((96, 3, 480, 640), device="meta")) == [(0, 48), (48, 48)]
+    assert m.base_model.f16mx_groups(torch.empty((32, 3, 960, 1280), device="meta")) == [(0, 16), (16, 16)]
