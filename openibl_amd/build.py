@@ -43,7 +43,9 @@ CXXFLAGS = [
 # library and through this one: tests/gpu_dbgvariant_ab.py).  Round 4: ["-DOIBL_MX_TAIL_B128"] — the f16mx fragment
 # tail as one ds_read_b128 instead of b64 + b32 (same bits, 6.950 -> 6.936 ms over the layers: nothing; off again);
 # ["-DOIBL_RING_LGKM0"] — lgkmcnt(0) in front of every COMPUTE segment, the schedule before the counted waits.
-DBG_EXPERIMENT_FLAGS = []
+# Round 6: ["-DOIBL_STEM_R5_LDS"] — the f16mx stem with the LDS access pattern of rounds 3-5 (b64 + b32 tails, producer
+# lane = pixel: 2612 bank-conflict cycles per tile against 452): profiles/r06_*_stem_lds_ab.txt; off again.
+DBG_EXPERIMENT_FLAGS = ["-DOIBL_STEM_R5_LDS"]
 
 
 def _hipcc() -> str:

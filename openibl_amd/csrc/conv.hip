@@ -2104,6 +2104,13 @@ __device__ static inline int fresh_lane_id() {
   return l;
 }
 
+// -DOIBL_STEM_R5_LDS (debug library, tests/gpu_dbgvariant_ab.py style A/B): the LDS access pattern of rounds 3-5 —
+// MX tails as ds_read_b64 + ds_read_b32, producer lane = halo pixel
+#ifdef OIBL_STEM_R5_LDS
+constexpr bool S3_TAIL128 = false, S3_LANE_PERM = false;
+#else
+constexpr bool S3_TAIL128 = true, S3_LANE_PERM = true;
+#endif
 constexpr int S3_W_BYTES = 2 * 9 * 32 * 128;
 constexpr int S3_BIAS_OFF = S3_W_BYTES + 2 * ST_HALO_BYTES;   // conv1_1 bias: 64 floats; MX: + this half's 32 of conv1_2
 constexpr int S3_LDS_BYTES = S3_BIAS_OFF + 256 + 128;
@@ -2229,7 +2236,7 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
     // was a 2-way conflict (884 extra LDS cycles per tile, tools/lds_stem_model.py — with the consumers' tail reads,
     // below, the 2.0e8 SQ_LDS_BANK_CONFLICT cycles per launch of profiles/r05_z_pmc.md: 2604 per tile measured,
     // 2612 modelled).  Which halo pixel a producer lane computes is free: only this function says.
-    const int lpix = MX ? 2 * (l31 & 7) + ((l31 >> 3) & 1) + 16 * (l31 >> 4) : l31;
+    const int lpix = (MX && S3_LANE_PERM) ? 2 * (l31 & 7) + ((l31 >> 3) & 1) + 16 * (l31 >> 4) : l31;
     auto row_of = [&](int bi) __attribute__((always_inline)) { return 32 * (pw + bi) + lpix; };
     auto hyx_of = [&](int bi, int& hy, int& hx) __attribute__((always_inline)) {
       const int r = row_of(bi), rc = r < ST_HALO_PX ? r : ST_HALO_PX - 1;
@@ -2703,15 +2710,24 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
       };
       auto ld_b0 = [&](int tap, int i, int a) __attribute__((always_inline)) { b0[i] = *reinterpret_cast<const f16x8_t*>(pbase(tap, i) + a); };
       auto ld_b1 = [&](int tap, int i, int a) __attribute__((always_inline)) { b1[i] = *reinterpret_cast<const f16x8_t*>(pbase(tap, i) + a); };
+      auto ld_tail = [&](const char* a) __attribute__((always_inline)) -> u4 {
+        if constexpr (S3_TAIL128) {
+          return *reinterpret_cast<const u4*>(a);
+        } else {
+          const u2 d = *reinterpret_cast<const u2*>(a);
+          const unsigned sc = *reinterpret_cast<const unsigned*>(a + 12);
+          return (u4){d.x, d.y, 0u, sc};
+        }
+      };
       auto ld_bm = [&](int tap, int i, int a2, int a3) __attribute__((always_inline)) {
         bma[i] = *reinterpret_cast<const u4*>(pbase(tap, i) + a2);
-        bmt[i] = *reinterpret_cast<const u4*>(pbase(tap, i) + a3);
+        bmt[i] = ld_tail(pbase(tap, i) + a3);
       };
       auto ld_w0 = [&](int tap) __attribute__((always_inline)) { w0 = *reinterpret_cast<const f16x8_t*>(smem + tap * 4096 + w_off(0)); };
       auto ld_w1 = [&](int tap) __attribute__((always_inline)) { w1 = *reinterpret_cast<const f16x8_t*>(smem + tap * 4096 + w_off(1)); };
       auto ld_wm = [&](int tap) __attribute__((always_inline)) {
         wma = *reinterpret_cast<const u4*>(smem + tap * 4096 + w_off(2));
-        wmt = *reinterpret_cast<const u4*>(smem + tap * 4096 + w_off(3));
+        wmt = ld_tail(smem + tap * 4096 + w_off(3));
       };
       auto mx = [&](int i) __attribute__((always_inline)) {
         // e2m3 x e2m3 (cbsz = blgp = 2): registers 0-5 of either operand; its scale: byte 0 of register 7 = the
