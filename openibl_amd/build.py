@@ -43,9 +43,10 @@ CXXFLAGS = [
 # library and through this one: tests/gpu_dbgvariant_ab.py).  Round 4: ["-DOIBL_MX_TAIL_B128"] — the f16mx fragment
 # tail as one ds_read_b128 instead of b64 + b32 (same bits, 6.950 -> 6.936 ms over the layers: nothing; off again);
 # ["-DOIBL_RING_LGKM0"] — lgkmcnt(0) in front of every COMPUTE segment, the schedule before the counted waits.
-# Round 6: ["-DOIBL_STEM_R5_LDS"] — the f16mx stem with the LDS access pattern of rounds 3-5 (b64 + b32 tails, producer
-# lane = pixel: 2612 bank-conflict cycles per tile against 452): profiles/r06_*_stem_lds_ab.txt; off again.
-DBG_EXPERIMENT_FLAGS = ["-DOIBL_STEM_R5_LDS"]
+# Round 6: ["-DOIBL_STEM_R6_LDS"] — the f16mx stem with MX tails as one ds_read_b128 and conflict-free producer line
+# writes (2612 -> 452 modelled bank-conflict cycles per tile, 2.0e8 -> 3.5e7 measured per launch): not faster (1.609
+# against 1.598 ms — the kernel is bound by VALU issue: profiles/r06_d_stem_lds_ab.txt); not adopted, off again.
+DBG_EXPERIMENT_FLAGS = []
 
 
 def _hipcc() -> str:

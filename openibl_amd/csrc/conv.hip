@@ -2104,12 +2104,19 @@ __device__ static inline int fresh_lane_id() {
   return l;
 }
 
-// -DOIBL_STEM_R5_LDS (debug library, tests/gpu_dbgvariant_ab.py style A/B): the LDS access pattern of rounds 3-5 —
-// MX tails as ds_read_b64 + ds_read_b32, producer lane = halo pixel
-#ifdef OIBL_STEM_R5_LDS
-constexpr bool S3_TAIL128 = false, S3_LANE_PERM = false;
-#else
+// -DOIBL_STEM_R6_LDS (debug library; tests/gpu_stem_lds_ab.py): the conflict-free LDS access pattern built in round 6
+// — MX tails as ONE ds_read_b128 (scale = register 7) and producer lanes 0-7 on a block's even pixels.  It removes
+// 83 % of the kernel's SQ_LDS_BANK_CONFLICT cycles (2.01e8 -> 3.47e7 per launch; tools/lds_stem_model.py predicts
+// 2612 -> 452 per tile) and a quarter of its LDS-active cycles — and the launch is NOT faster: 1.609 against 1.598 ms,
+// slower in each of five alternating rounds (profiles/r06_d_stem_lds_ab.txt).  The consumers' passes do shrink
+// (6.4k -> 5.2k cycles per tile) but the time moves into their waits: the tile is bound by what the four waves of a
+// SIMD can ISSUE on the vector ALU (1374 VALU wave-instructions per SIMD and tile = 5.5k of its 9.8k cycles at four
+// cycles each, three quarters of them the producers' conv1_1 + line packing, which BOTH workgroups of a tile run), and
+// the b128 operands cost 6 % more VALU instructions (register moves).  The product keeps the rounds 3-5 pattern.
+#ifdef OIBL_STEM_R6_LDS
 constexpr bool S3_TAIL128 = true, S3_LANE_PERM = true;
+#else
+constexpr bool S3_TAIL128 = false, S3_LANE_PERM = false;
 #endif
 constexpr int S3_W_BYTES = 2 * 9 * 32 * 128;
 constexpr int S3_BIAS_OFF = S3_W_BYTES + 2 * ST_HALO_BYTES;   // conv1_1 bias: 64 floats; MX: + this half's 32 of conv1_2

@@ -25,19 +25,29 @@
 //     conv2_1 0.76 -> 0.71 ms, conv2_2 1.10 -> 1.03 ms at batch 32 (the halved L2 -> LDS traffic pays for it).
 //   * with one wave per SIMD and no stagger discipline the weights need TWO barriers per K-tile, not four / eight.
 //
-// Schedule of K-tile t = tap `tap` of chunk cc (weights: two K-tile buffers of B0 | B1, 64 rows x 128 B each):
-//   P0  read A0(tap) from the halo                                             mma  A0 x B0(t)     [B0(t) in registers]
-//   P1  vmcnt(2 NB); barrier; read B1(t); issue B0(t+2) over B0(t)             mma  A0 x B1(t)
-//   P2  read A1(tap)                                                           mma  A1 x B1(t)
-//   P3  vmcnt(2 NB); barrier; read B0(t+1) into the registers B1 vacates;
-//       issue B1(t+2) over B1(t); tap 8: issue the next chunk's halo           mma  A1 x B0(t)
-//   chunk start (tap 0, not the first): vmcnt(0); barrier   — the halo has landed
-// Hazards.  RAW: a weight unit is read behind a barrier that every wave crosses after its own counted wait (the
-// unit's NB instructions are the oldest outstanding: 2 NB younger ones in flight).  WAR: B0(t) is last read in
-// P3(t-1) and overwritten in P1(t), B1(t) read in P1(t) and overwritten in P3(t) — a barrier in between, crossed
-// after the lgkmcnt(0) that closes every mma segment.  The halo is last read in P2 of tap 8 and overwritten behind
-// the barrier of P3.  Units beyond the last K-tile load an in-range line into a per-wave sink, so the counts
-// are constants.
+// Schedule of K-tile t = tap `tap` of chunk cc (weights: two K-tile buffers of B0 | B1, 64 rows x 128 B each), round 6.
+// Rounds 5's phases were LOAD (ten fragment reads, wait) then MMA (six matrix instructions): with ONE wave per SIMD and
+// workgroup nothing covers a wave's own LOAD, and two uncoordinated workgroups per CU reached 57-68 % of the matrix
+// pipe inside the K loop (2260-2660 cycles per K-tile against 2 x 768).  Now a wave never stops issuing matrix
+// instructions to load: every A fragment is re-read for its NEXT use right behind the last instruction that reads it
+// (the order of halo4_mma6 leaves each reload five instructions = 160 pipe cycles before its first reader — the
+// discipline of the f16mx stem's consumers), and the B sets are read a whole phase ahead:
+//   P0  read B1(t) into the set B0(t-1) vacated                              mma  A0 x B0(t)
+//   P1  lgkmcnt(0); barrier SA; issue B0(t+2), B1(t+2) over K-tile t         mma  A0 x B1(t), A0 <- A1(tap) behind its readers
+//   P2                                                                        mma  A1 x B1(t)
+//   P3  vmcnt(2 NB); barrier SB; read B0(t+1) into the set B1(t) vacated     mma  A1 x B0(t), A1 <- A0(tap + 1) behind its readers
+//   chunk start (tap 0, not the first): vmcnt(0); barrier; read A0(tap 0)    — the halo has landed (tap 8 pre-reads
+//       nothing: the next chunk's halo is issued behind SB of tap 8 and overwrites the buffer the reads would hit)
+// Hazards.  RAW: K-tile t+1's units were issued behind SA(t-1); at SB(t) a wave allows only the 2 NB instructions of
+// K-tile t+2 (issued behind SA(t)) in flight, every wave crosses SB behind its own wait: B0(t+1) (read in P3(t)) and
+// B1(t+1) (read in P0(t+1)) have landed.  WAR: K-tile t's buffer is last read in P3(t-1) (B0) and P0(t) (B1); both
+// reads are retired by the lgkmcnt(0) in front of SA(t) — which P1's first instruction needs anyway — so the units
+// of K-tile t+2 issued behind SA(t) overwrite nothing a wave still reads.  Nothing is outstanding at SB (P1's A
+// reloads were consumed by P2), so neither barrier exposes an LDS latency.  The halo is last read in P1 of tap 8 (A1)
+// and overwritten behind SB of tap 8.  Units beyond the last K-tile load an in-range line into a per-wave sink, so
+// the counts are constants.  The MX operand's tail is read as ONE ds_read_b128 ([d4 d5 0 scale], scale = register 7):
+// with both workgroups issuing continuously the LDS port is the next limit, and the b64 + b32 tails' bank conflicts
+// (12 cycles instead of 4, tools/lds_stem_model.py) were a third of its read cycles.
 #pragma once
 
 #include "conv_halo.h"
@@ -188,39 +198,99 @@ __global__ __launch_bounds__(H4_THREADS, 2) void conv3x3_halo4_kernel(HaloParams
   const int row_pitch = HP * 128;
 
   bf16x8_t fa[2][4], fbx[4], fby[4];
-  auto ld_frag = [&](const char* a, int kk) __attribute__((always_inline)) -> bf16x8_t {
-    if (kk == 3) {
-      typedef __attribute__((ext_vector_type(2))) unsigned u2;   // (not uint2: ring_core.h, read_frag)
-      const u2 d = *reinterpret_cast<const u2*>(a);
-      const unsigned sc = *reinterpret_cast<const unsigned*>(a + 12);
-      typedef __attribute__((ext_vector_type(4))) unsigned u4;
-      return __builtin_bit_cast(bf16x8_t, (u4){d.x, d.y, sc, 0u});
-    }
+  // (every piece of a fragment — fp16 k-halves, e2m3 dwords 0-3, the tail slot [d4 d5 0 scale] — is one 16-byte slot)
+  auto ld_frag = [&](const char* a) __attribute__((always_inline)) -> bf16x8_t {
     return *reinterpret_cast<const bf16x8_t*>(a);
   };
-  auto read_a = [&](auto h_c, auto tap_c) __attribute__((always_inline)) {
+  // the two row blocks' base addresses of A(h) at tap: fragment kk of block i2 is at a0[i2] ^ ((kk << 5) ^ cdy)
+  int a_cur[2];
+  auto a_base = [&](auto h_c, auto tap_c) __attribute__((always_inline)) {
     constexpr int h = decltype(h_c)::value, tap = decltype(tap_c)::value;
     constexpr int dyi = tap / 3, dxi = tap % 3;
-    constexpr int cdy = (dyi != 1) ? 64 : 0;
     int rp_ = row_pitch;
     asm volatile("" : "+s"(rp_));     // (opaque: keeps 9 taps x 16 loop-invariant addresses out of scratch)
     const int tapoff = dyi * rp_ + dxi * 128;
-    int a0[2];
 #pragma unroll
     for (int i2 = 0; i2 < 2; ++i2) {
-      a0[i2] = pre[h][i2][dxi];
-      asm volatile("" : "+v"(a0[i2]));
-      a0[i2] += tapoff;
+      a_cur[i2] = pre[h][i2][dxi];
+      asm volatile("" : "+v"(a_cur[i2]));
+      a_cur[i2] += tapoff;
     }
+  };
+  auto ld_a = [&](auto tap_c, int i2, int kk) __attribute__((always_inline)) {
+    constexpr int tap = decltype(tap_c)::value;
+    constexpr int cdy = (tap / 3 != 1) ? 64 : 0;
+    fa[i2][kk] = ld_frag(smem + (a_cur[i2] ^ ((kk << 5) ^ cdy)));
+  };
+  auto read_a = [&](auto h_c, auto tap_c) __attribute__((always_inline)) {   // all of A(h) at once (prologue, chunk starts)
+    a_base(h_c, tap_c);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-      for (int i2 = 0; i2 < 2; ++i2) fa[i2][kk] = ld_frag(smem + (a0[i2] ^ ((kk << 5) ^ cdy)), kk);
+      for (int i2 = 0; i2 < 2; ++i2) ld_a(tap_c, i2, kk);
   };
   auto read_b = [&](int buf, int h, bf16x8_t (&f)[4]) __attribute__((always_inline)) {
     const char* s = rd_b + buf * H4_B_TILE + h * H4_B_UNIT;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) f[kk] = ld_frag(s + frag_off[kk], kk);
+    for (int kk = 0; kk < 4; ++kk) f[kk] = ld_frag(s + frag_off[kk]);
+  };
+  // one phase: six matrix instructions on two accumulator tiles; after(q) runs right behind instruction q (the
+  // reloads of the fragments it was the last reader of).  sched_barrier pins the written order: left alone, the
+  // scheduler sinks every reload to just in front of its use (conv.hip, the f16mx stem's consumers).
+  auto mma6 = [&](f32x16_t& acc0, f32x16_t& acc1, const bf16x8_t (&fb)[4], auto&& after) __attribute__((always_inline)) {
+    typedef __attribute__((ext_vector_type(4))) int i4;
+    auto f16 = [&](f32x16_t& acc, int i2, int k) __attribute__((always_inline)) {
+      const f16x8_t a = __builtin_bit_cast(f16x8_t, fa[i2][k]), b = __builtin_bit_cast(f16x8_t, fb[k]);
+      acc = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, acc, 0, 0, 0)
+                 : __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+    };
+    auto mx = [&](f32x16_t& acc, int i2) __attribute__((always_inline)) {
+      const i32x8_t a8 = __builtin_shufflevector(__builtin_bit_cast(i4, fa[i2][2]), __builtin_bit_cast(i4, fa[i2][3]),
+                                                 0, 1, 2, 3, 4, 5, 6, 7);
+      const i32x8_t b8 = __builtin_shufflevector(__builtin_bit_cast(i4, fb[2]), __builtin_bit_cast(i4, fb[3]), 0, 1, 2,
+                                                 3, 4, 5, 6, 7);
+      // e2m3 x e2m3 (cbsz = blgp = 2); scales: byte 0 of register 7 of either operand (the tail slot's last dword)
+      acc = SWAP ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8, a8, acc, 2, 2, 0, b8[7], 0, a8[7])
+                 : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc, 2, 2, 0, a8[7], 0, b8[7]);
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    f16(acc0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    after(0);
+    __builtin_amdgcn_sched_barrier(0);
+    f16(acc1, 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    after(1);
+    __builtin_amdgcn_sched_barrier(0);
+    f16(acc0, 0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    after(2);
+    __builtin_amdgcn_sched_barrier(0);
+    f16(acc1, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    after(3);
+    __builtin_amdgcn_sched_barrier(0);
+    mx(acc0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    after(4);
+    __builtin_amdgcn_sched_barrier(0);
+    mx(acc1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    after(5);
+    asm volatile("" : "+v"(acc0), "+v"(acc1));  // pin the results inside the segment (ring_core.h)
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // the reload of A behind its readers: instruction q was the last reader of fa[q & 1][q >> 1] (q < 4), of
+  // fa[0][2..3] (q = 4), of fa[1][2..3] (q = 5)
+  auto reload_a = [&](auto tap_c, int q) __attribute__((always_inline)) {
+    if (q < 4) {
+      ld_a(tap_c, q & 1, q >> 1);
+    } else {
+      ld_a(tap_c, q - 4, 2);
+      ld_a(tap_c, q - 4, 3);
+    }
   };
   auto bar = [&]() __attribute__((always_inline)) {
     __builtin_amdgcn_sched_barrier(0);
@@ -259,7 +329,7 @@ __global__ __launch_bounds__(H4_THREADS, 2) void conv3x3_halo4_kernel(HaloParams
 
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
-  // ---- prologue: the halo of chunk 0, the weights of K-tiles 0 and 1; everything landed
+  // ---- prologue: the halo of chunk 0, the weights of K-tiles 0 and 1; everything landed; B0(0) and A0(tap 0) read
   stage_halo(0);
   begin_tile();
   stage_b(0, 0, true);
@@ -270,42 +340,48 @@ __global__ __launch_bounds__(H4_THREADS, 2) void conv3x3_halo4_kernel(HaloParams
   wait_vmcnt<0>();
   bar();
   read_b(0, 0, fbx);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  read_a(I0{}, std::integral_constant<int, 0>{});
 
 #define H4_IC(x) std::integral_constant<int, (x)> {}
   auto ktile = [&](auto par_c, auto tap_c, int cc, int kt) __attribute__((always_inline)) {
     constexpr int PAR = decltype(par_c)::value;
     constexpr int TAP = decltype(tap_c)::value;
+    constexpr int NXT = TAP == 8 ? 0 : TAP + 1;
     bf16x8_t(&b0)[4] = PAR ? fby : fbx;
     bf16x8_t(&b1)[4] = PAR ? fbx : fby;
     const bool more = kt + 2 < nk;
     if constexpr (TAP == 0) {
-      if (kt > 0) {          // a new chunk: its halo (issued in P3 of the previous tap 8) has landed
+      if (kt > 0) {          // a new chunk: its halo (issued behind SB of the previous tap 8) has landed
         wait_vmcnt<0>();
         bar();
+        read_a(I0{}, tap_c);
       }
     }
-    // P0: A0 x B0
-    read_a(I0{}, tap_c);
-    halo_phase_mma<P, SWAP>(acc[0][0], acc[1][0], fa, b0, [&] { begin_tile(); });
-    // P1: A0 x B1
-    wait_vmcnt<2 * NB>();
-    bar();
+    // P0: A0 x B0; B1(t) arrives under it
     read_b(PAR, 1, b1);
-    stage_b(PAR, 0, more);    // B0(t+2)
-    halo_phase_mma<P, SWAP>(acc[0][1], acc[1][1], fa, b1, [] {});
+    mma6(acc[0][0], acc[1][0], b0, [&](int q) __attribute__((always_inline)) {
+      if (q == 1) begin_tile();   // (scalar cursor of the K-tile staged in P1, in the shadow of the matrix pipe)
+    });
+    // P1: A0 x B1; A1(tap) behind A0's readers.  SA: every wave's reads of K-tile t's buffer are retired
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    bar();
+    stage_b(PAR, 0, more);    // K-tile t + 2 over K-tile t
+    stage_b(PAR, 1, more);
+    a_base(I1{}, tap_c);
+    mma6(acc[0][1], acc[1][1], b1, [&](int q) __attribute__((always_inline)) { reload_a(tap_c, q); });
     // P2: A1 x B1
-    read_a(I1{}, tap_c);
-    halo_phase_mma<P, SWAP>(acc[2][1], acc[3][1], fa, b1, [] {});
-    // P3: A1 x B0   (B0 of the next K-tile goes into the register set B1 just vacated)
+    mma6(acc[2][1], acc[3][1], b1, [](int) __attribute__((always_inline)) {});
+    // P3: A1 x B0; B0(t+1) into the set B1 vacated; A0(tap + 1) behind A1's readers.  SB: K-tile t+1 has landed
     wait_vmcnt<2 * NB>();
     bar();
     read_b(PAR ^ 1, 0, b1);
-    stage_b(PAR, 1, more);    // B1(t+2)
     if constexpr (TAP == 8) {
-      if (cc + 1 < chunks) stage_halo(cc + 1);
+      if (cc + 1 < chunks) stage_halo(cc + 1);     // (over the halo A1(tap 8) was the last to read: no pre-read of A0)
+      mma6(acc[2][0], acc[3][0], b0, [](int) __attribute__((always_inline)) {});
+    } else {
+      a_base(I0{}, H4_IC(NXT));
+      mma6(acc[2][0], acc[3][0], b0, [&](int q) __attribute__((always_inline)) { reload_a(H4_IC(NXT), q); });
     }
-    halo_phase_mma<P, SWAP>(acc[2][0], acc[3][0], fa, b0, [] {});
   };
   for (int cc = 0; cc < chunks; cc += 2) {
     const int kt = 9 * cc;
@@ -329,6 +405,7 @@ __global__ __launch_bounds__(H4_THREADS, 2) void conv3x3_halo4_kernel(HaloParams
     ktile(I1{}, H4_IC(8), cc + 1, kt + 17);
   }
 #undef H4_IC
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the last P3's pre-read of a K-tile that does not exist)
   wait_vmcnt<0>();  // (sink writes of the last dummies)
   __syncthreads();
   if (wgprof) p.prof[64 + 4 * (size_t)blockIdx.x + 3] = __builtin_amdgcn_s_memtime();

@@ -1,7 +1,8 @@
-"""The f16mx stem of this build (product library) against the debug library compiled with -DOIBL_STEM_R5_LDS (the LDS
-access pattern of rounds 3-5: MX tails as ds_read_b64 + ds_read_b32, producer lane = halo pixel): time per launch at
-batch 32 x 480x640, alternating, the role breakdown of workgroup (0, 0) through the debug library's stamps, and
-bit-identity of the outputs (diagnostic, not a pytest).   python tests/gpu_stem_lds_ab.py [rounds]"""
+"""The f16mx stem of this build (product library: MX tails as ds_read_b64 + ds_read_b32, producer lane = halo pixel)
+against the debug library compiled with -DOIBL_STEM_R6_LDS (openibl_amd/build.py, DBG_EXPERIMENT_FLAGS: tails as one
+ds_read_b128, producer lanes on even / odd pixels — the conflict-free LDS pattern of tools/lds_stem_model.py): time per
+launch at batch 32 x 480x640, alternating, and bit-identity of the outputs (diagnostic, not a pytest).
+    python tests/gpu_stem_lds_ab.py [rounds]          (profiles/r06_d_stem_lds_ab.txt: run with the roles swapped)"""
 import sys
 from pathlib import Path
 
@@ -10,7 +11,7 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from openibl_amd import build, lib, ops  # noqa: E402
 
-assert "-DOIBL_STEM_R5_LDS" in build.DBG_EXPERIMENT_FLAGS, "build the debug library with -DOIBL_STEM_R5_LDS first"
+assert "-DOIBL_STEM_R6_LDS" in build.DBG_EXPERIMENT_FLAGS, "build the debug library with -DOIBL_STEM_R6_LDS first"
 dev = torch.device("cuda", 0)
 N, H, W = 32, 480, 640
 g = torch.Generator(device=dev).manual_seed(1)
@@ -36,10 +37,10 @@ def timed(iters=10):
     return a.elapsed_time(b) / iters, out
 
 
-ts, outs = {"round 6 (product)": [], "rounds 3-5 (debug, OIBL_STEM_R5_LDS)": []}, {}
+ts, outs = {"product (b64 + b32 tails, lane = pixel)": [], "debug, OIBL_STEM_R6_LDS (b128 tails, lane permutation)": []}, {}
 for r in range(rounds):
     for name in ts:
-        if name.startswith("round 6"):
+        if name.startswith("product"):
             lib.use_product_library()
         else:
             lib.debug_hooks()
