@@ -245,6 +245,10 @@ __global__ __launch_bounds__(H4_THREADS, 2) void conv3x3_halo4_kernel(HaloParams
                  : __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
     };
     auto mx = [&](f32x16_t& acc, int i2) __attribute__((always_inline)) {
+      // (the tail slot's zero dword is never read: without a use the allocator hands that register to a temporary
+      //  while the ds_read_b128 that writes it is still in flight — and protects the temporary with an lgkmcnt(0) in
+      //  front of the phase's first matrix instruction, i.e. the exposed LOAD this schedule is there to remove)
+      asm volatile("" ::"v"(fa[i2][3]), "v"(fb[3]));
       const i32x8_t a8 = __builtin_shufflevector(__builtin_bit_cast(i4, fa[i2][2]), __builtin_bit_cast(i4, fa[i2][3]),
                                                  0, 1, 2, 3, 4, 5, 6, 7);
       const i32x8_t b8 = __builtin_shufflevector(__builtin_bit_cast(i4, fb[2]), __builtin_bit_cast(i4, fb[3]), 0, 1, 2,
