@@ -25,7 +25,21 @@
 //     conv2_1 0.76 -> 0.71 ms, conv2_2 1.10 -> 1.03 ms at batch 32 (the halved L2 -> LDS traffic pays for it).
 //   * with one wave per SIMD and no stagger discipline the weights need TWO barriers per K-tile, not four / eight.
 //
-// Schedule of K-tile t = tap `tap` of chunk cc (weights: two K-tile buffers of B0 | B1, 64 rows x 128 B each), round 6.
+// Schedule of K-tile t = tap `tap` of chunk cc (weights: two K-tile buffers of B0 | B1, 64 rows x 128 B each):
+//   P0  read A0(tap) from the halo                                             mma  A0 x B0(t)     [B0(t) in registers]
+//   P1  vmcnt(2 NB); barrier; read B1(t); issue B0(t+2) over B0(t)             mma  A0 x B1(t)
+//   P2  read A1(tap)                                                           mma  A1 x B1(t)
+//   P3  vmcnt(2 NB); barrier; read B0(t+1) into the registers B1 vacates;
+//       issue B1(t+2) over B1(t); tap 8: issue the next chunk's halo           mma  A1 x B0(t)
+//   chunk start (tap 0, not the first): vmcnt(0); barrier   — the halo has landed
+// Hazards.  RAW: a weight unit is read behind a barrier that every wave crosses after its own counted wait (the
+// unit's NB instructions are the oldest outstanding: 2 NB younger ones in flight).  WAR: B0(t) is last read in
+// P3(t-1) and overwritten in P1(t), B1(t) read in P1(t) and overwritten in P3(t) — a barrier in between, crossed
+// after the lgkmcnt(0) that closes every mma segment.  The halo is last read in P2 of tap 8 and overwritten behind
+// the barrier of P3.  Units beyond the last K-tile load an in-range line into a per-wave sink, so the counts
+// are constants.
+// -DOIBL_HALO4_CONT (debug library, round 6; VERDICT r05 item 3 "give the two workgroups of a CU a stagger discipline"):
+// a CONTINUOUS-ISSUE K loop instead of the phases below.
 // Rounds 5's phases were LOAD (ten fragment reads, wait) then MMA (six matrix instructions): with ONE wave per SIMD and
 // workgroup nothing covers a wave's own LOAD, and two uncoordinated workgroups per CU reached 57-68 % of the matrix
 // pipe inside the K loop (2260-2660 cycles per K-tile against 2 x 768).  Now a wave never stops issuing matrix
@@ -48,6 +62,12 @@
 // the counts are constants.  The MX operand's tail is read as ONE ds_read_b128 ([d4 d5 0 scale], scale = register 7):
 // with both workgroups issuing continuously the LDS port is the next limit, and the b64 + b32 tails' bank conflicts
 // (12 cycles instead of 4, tools/lds_stem_model.py) were a third of its read cycles.
+// Measured (one box, gpurun r06_e; profiles/r06_e_halo4_cont.txt): all 136 tests of test_gpu_mx / splitk / range green,
+// K loop + prologue per workgroup 45.5k -> 42.5k shader cycles on conv2_1 and 81.6k -> 79.0k on conv2_2 — and the
+// layers' WALL time unchanged (0.721 -> 0.721 ms, 1.010 -> 1.034 ms against an unchanged ring kernel on the same
+// boxes): these launches sit at the board's power cap (1.75-1.87 GHz of 2.4), where cycles saved on stalls come back as
+// a lower clock — what moves them is fewer joules per tile, not a tighter interleave.  256 VGPRs against
+// 239; the pooled variant parks ten values in scratch.  Not adopted: the product keeps the phases.
 #pragma once
 
 #include "conv_halo.h"
@@ -197,6 +217,7 @@ __global__ __launch_bounds__(H4_THREADS, 2) void conv3x3_halo4_kernel(HaloParams
   }
   const int row_pitch = HP * 128;
 
+#ifdef OIBL_HALO4_CONT
   bf16x8_t fa[2][4], fbx[4], fby[4];
   // (every piece of a fragment — fp16 k-halves, e2m3 dwords 0-3, the tail slot [d4 d5 0 scale] — is one 16-byte slot)
   auto ld_frag = [&](const char* a) __attribute__((always_inline)) -> bf16x8_t {
@@ -410,9 +431,162 @@ __global__ __launch_bounds__(H4_THREADS, 2) void conv3x3_halo4_kernel(HaloParams
   }
 #undef H4_IC
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the last P3's pre-read of a K-tile that does not exist)
+#else
+  bf16x8_t fa[2][4], fbx[4], fby[4];
+  auto ld_frag = [&](const char* a, int kk) __attribute__((always_inline)) -> bf16x8_t {
+    if (kk == 3) {
+      typedef __attribute__((ext_vector_type(2))) unsigned u2;   // (not uint2: ring_core.h, read_frag)
+      const u2 d = *reinterpret_cast<const u2*>(a);
+      const unsigned sc = *reinterpret_cast<const unsigned*>(a + 12);
+      typedef __attribute__((ext_vector_type(4))) unsigned u4;
+      return __builtin_bit_cast(bf16x8_t, (u4){d.x, d.y, sc, 0u});
+    }
+    return *reinterpret_cast<const bf16x8_t*>(a);
+  };
+  auto read_a = [&](auto h_c, auto tap_c) __attribute__((always_inline)) {
+    constexpr int h = decltype(h_c)::value, tap = decltype(tap_c)::value;
+    constexpr int dyi = tap / 3, dxi = tap % 3;
+    constexpr int cdy = (dyi != 1) ? 64 : 0;
+    int rp_ = row_pitch;
+    asm volatile("" : "+s"(rp_));     // (opaque: keeps 9 taps x 16 loop-invariant addresses out of scratch)
+    const int tapoff = dyi * rp_ + dxi * 128;
+    int a0[2];
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2) {
+      a0[i2] = pre[h][i2][dxi];
+      asm volatile("" : "+v"(a0[i2]));
+      a0[i2] += tapoff;
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2) fa[i2][kk] = ld_frag(smem + (a0[i2] ^ ((kk << 5) ^ cdy)), kk);
+  };
+  auto read_b = [&](int buf, int h, bf16x8_t (&f)[4]) __attribute__((always_inline)) {
+    const char* s = rd_b + buf * H4_B_TILE + h * H4_B_UNIT;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) f[kk] = ld_frag(s + frag_off[kk], kk);
+  };
+  auto bar = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // accumulators start at the bias (conv_halo.h)
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    if constexpr (POOL) {
+      float b = p.bias[n0 + wn * 64 + j * 32 + (lane & 31)] * p.bias_mul;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          asm volatile("" : "+v"(b));
+          acc[i][j][r] = b;
+        }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 b = *reinterpret_cast<const float4*>(p.bias + n0 + wn * 64 + j * 32 + 8 * g + 4 * (lane >> 5));
+        b = make_float4(b.x * p.bias_mul, b.y * p.bias_mul, b.z * p.bias_mul, b.w * p.bias_mul);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[i][j][4 * g] = b.x;
+          acc[i][j][4 * g + 1] = b.y;
+          acc[i][j][4 * g + 2] = b.z;
+          acc[i][j][4 * g + 3] = b.w;
+        }
+      }
+    }
+  }
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  // ---- prologue: the halo of chunk 0, the weights of K-tiles 0 and 1; everything landed
+  stage_halo(0);
+  begin_tile();
+  stage_b(0, 0, true);
+  stage_b(0, 1, true);
+  begin_tile();
+  stage_b(1, 0, true);
+  stage_b(1, 1, true);
+  wait_vmcnt<0>();
+  bar();
+  read_b(0, 0, fbx);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+#define H4_IC(x) std::integral_constant<int, (x)> {}
+  auto ktile = [&](auto par_c, auto tap_c, int cc, int kt) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par_c)::value;
+    constexpr int TAP = decltype(tap_c)::value;
+    bf16x8_t(&b0)[4] = PAR ? fby : fbx;
+    bf16x8_t(&b1)[4] = PAR ? fbx : fby;
+    const bool more = kt + 2 < nk;
+    if constexpr (TAP == 0) {
+      if (kt > 0) {          // a new chunk: its halo (issued in P3 of the previous tap 8) has landed
+        wait_vmcnt<0>();
+        bar();
+      }
+    }
+    // P0: A0 x B0
+    read_a(I0{}, tap_c);
+    halo_phase_mma<P, SWAP>(acc[0][0], acc[1][0], fa, b0, [&] { begin_tile(); });
+    // P1: A0 x B1
+    wait_vmcnt<2 * NB>();
+    bar();
+    read_b(PAR, 1, b1);
+    stage_b(PAR, 0, more);    // B0(t+2)
+    halo_phase_mma<P, SWAP>(acc[0][1], acc[1][1], fa, b1, [] {});
+    // P2: A1 x B1
+    read_a(I1{}, tap_c);
+    halo_phase_mma<P, SWAP>(acc[2][1], acc[3][1], fa, b1, [] {});
+    // P3: A1 x B0   (B0 of the next K-tile goes into the register set B1 just vacated)
+    wait_vmcnt<2 * NB>();
+    bar();
+    read_b(PAR ^ 1, 0, b1);
+    stage_b(PAR, 1, more);    // B1(t+2)
+    if constexpr (TAP == 8) {
+      if (cc + 1 < chunks) stage_halo(cc + 1);
+    }
+    halo_phase_mma<P, SWAP>(acc[2][0], acc[3][0], fa, b0, [] {});
+  };
+  for (int cc = 0; cc < chunks; cc += 2) {
+    const int kt = 9 * cc;
+    ktile(I0{}, H4_IC(0), cc, kt);
+    ktile(I1{}, H4_IC(1), cc, kt + 1);
+    ktile(I0{}, H4_IC(2), cc, kt + 2);
+    ktile(I1{}, H4_IC(3), cc, kt + 3);
+    ktile(I0{}, H4_IC(4), cc, kt + 4);
+    ktile(I1{}, H4_IC(5), cc, kt + 5);
+    ktile(I0{}, H4_IC(6), cc, kt + 6);
+    ktile(I1{}, H4_IC(7), cc, kt + 7);
+    ktile(I0{}, H4_IC(8), cc, kt + 8);
+    ktile(I1{}, H4_IC(0), cc + 1, kt + 9);
+    ktile(I0{}, H4_IC(1), cc + 1, kt + 10);
+    ktile(I1{}, H4_IC(2), cc + 1, kt + 11);
+    ktile(I0{}, H4_IC(3), cc + 1, kt + 12);
+    ktile(I1{}, H4_IC(4), cc + 1, kt + 13);
+    ktile(I0{}, H4_IC(5), cc + 1, kt + 14);
+    ktile(I1{}, H4_IC(6), cc + 1, kt + 15);
+    ktile(I0{}, H4_IC(7), cc + 1, kt + 16);
+    ktile(I1{}, H4_IC(8), cc + 1, kt + 17);
+  }
+#undef H4_IC
+#endif
   wait_vmcnt<0>();  // (sink writes of the last dummies)
   __syncthreads();
   if (wgprof) p.prof[64 + 4 * (size_t)blockIdx.x + 3] = __builtin_amdgcn_s_memtime();
+  if (p.out_mul != 1.f) {   // (uniform; the layer handing the fp32 map to the head — only when the "every layer on
+                            //  this kernel" experiment, hook 13, sends conv5_3 here: conv_halo.h)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= p.out_mul;
+  }
 
   // ---- epilogue: conv_halo.h's — fp32 staging with the chunk swizzle, one thread per (row, 32-channel group) packs
   //      its f16mx line in place, full lines out — for 128 channels and 256 threads
