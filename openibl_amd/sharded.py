@@ -143,7 +143,10 @@ def _query_block(q, lo: int, hi: int):
     return q[lo:hi]
 
 
-def _make_stages(g_local, k, index_base, precision, group, local_topk_fn, merge_fn, f16r_stages):
+SLICED_POSTPROCESSING = True    # False: the all_gather + replicated merge of rounds 1-5 (tests compare the two)
+
+
+def _make_stages(g_local, k, index_base, precision, group, local_topk_fn, merge_fn, f16r_stages, sliced=None):
     """(stage_main, stage_side, gather_and_merge) of one rank: what runs on the caller's stream per query block (the
     matrix work) and what runs behind it (the exchange(s) + merge)."""
     use_f16r = f16r_stages is not None or (local_topk_fn is None and ops.precision_code(precision) == ops.F16R)
@@ -152,10 +155,13 @@ def _make_stages(g_local, k, index_base, precision, group, local_topk_fn, merge_
     local_topk_fn = local_topk_fn or hip_local_topk
     merge_fn = merge_fn or hip_merge_topk
     rank, world = _world(group)
+    sliced = SLICED_POSTPROCESSING if sliced is None else bool(sliced)
 
     def gather_and_merge(v, i, flag):
         if world == 1:
             return v, i, flag
+        if sliced:
+            return exchange_and_merge_sliced(v, i, flag)
         # one collective for everything: the int32 indices travel as the bit pattern of a float32
         # next to the values, the overflow flag as one more row ([Q + 1][2k] per rank; nothing
         # computes on them in transit), so every rank sees every rank's flag
@@ -171,6 +177,47 @@ def _make_stages(g_local, k, index_base, precision, group, local_topk_fn, merge_
         is_ = lists[:, :, k:].reshape(Q, world * k).view(torch.int32)
         mv, mi = merge_fn(vs, is_, k)
         return mv, mi, flags
+
+    # Query-SLICED post-processing (round 6): with the all_gather above every rank receives W lists
+    # per query and merges ALL Q queries — work that does not shrink with the number of ranks and capped the 8-shard
+    # projection below 6x.  Here rank r post-processes only the queries [r Q / W, (r + 1) Q / W): an all_to_all hands it
+    # every rank's lists for that slice (sent: (W - 1) / W of what it has, received: as much), it merges Q / W queries,
+    # and one all_gather of the merged [Q / W][2k] slices (+ the flag row) gives every rank the full result: 2 Q lists
+    # over the links per rank instead of W Q, and the merge divides by W.  Same lists (a query's merge sees the same
+    # W x k entries; ties go to the lowest global index either way).
+    def _slices(Q):
+        per = -(-Q // world)
+        return per, world * per
+
+    def _pad_rows(t, rows, fill):
+        if t.shape[0] == rows:
+            return t
+        pad = torch.full((rows - t.shape[0],) + tuple(t.shape[1:]), fill, dtype=t.dtype, device=t.device)
+        return torch.cat([t, pad])
+
+    def _to_slices(x):
+        """x [W * per][c]: block r goes to rank r -> [per][W][c]: what every rank holds for MY query slice"""
+        out = torch.empty_like(x)
+        dist.all_to_all_single(out, x.contiguous(), group=group)
+        per = x.shape[0] // world
+        return out.view(world, per, x.shape[1]).permute(1, 0, 2)
+
+    def exchange_and_merge_sliced(v, i, flag):
+        Q = v.shape[0]
+        per, Qp = _slices(Q)
+        packed = torch.cat([_pad_rows(v, Qp, float("inf")), _pad_rows(i, Qp, -1).view(torch.float32)], dim=1)
+        mine = _to_slices(packed)                                       # [per][W][2k]
+        vs = mine[:, :, :k].reshape(per, world * k)
+        is_ = mine[:, :, k:].reshape(per, world * k).view(torch.int32)
+        mv, mi = merge_fn(vs, is_, k)                                   # Q / W queries, not Q
+        row = flag.view(torch.float32).expand(1, 2 * k)
+        out = torch.cat([torch.cat([mv, mi.view(torch.float32)], dim=1), row]).contiguous()
+        gathered = torch.empty((world * (per + 1), 2 * k), dtype=torch.float32, device=out.device)
+        dist.all_gather_into_tensor(gathered, out, group=group)
+        gathered = gathered.view(world, per + 1, 2 * k)
+        flags = gathered[:, per, 0].contiguous().view(torch.int32)
+        lists = gathered[:, :per, :].reshape(Qp, 2 * k)[:Q]
+        return lists[:, :k].contiguous(), lists[:, k:].contiguous().view(torch.int32), flags
 
     # what runs on the caller's stream per query block (matrix work) and what runs behind it (exchange + merge; f16r:
     # exchange of the filter lists, global threshold, this rank's share of the rescoring, exchange + merge)
@@ -192,6 +239,22 @@ def _make_stages(g_local, k, index_base, precision, group, local_topk_fn, merge_
             return gather_and_merge(*res)
         lval, lidx, ymax, flag = res
         Qb, K2 = int(lval.shape[0]), int(lval.shape[1])
+        if sliced:
+            # the filter values of MY query slice from every rank -> its thresholds; the Q / W thresholds of every rank
+            # (+ its flag and its shard's norm maxima) are all-gathered: 4 bytes per query instead of W K2 values
+            per, Qp = _slices(Qb)
+            mine = _to_slices(_pad_rows(lval, Qp, float("inf")))          # [per][W][K2]
+            thr_mine = f16r_stages.kth(mine.reshape(per, world * K2), k)      # [per]
+            row = torch.cat([thr_mine, flag.view(torch.float32), ymax.to(torch.float32)]).contiguous()
+            allrows = torch.empty((world, per + 3), dtype=torch.float32, device=row.device)
+            dist.all_gather_into_tensor(allrows.view(-1), row, group=group)
+            thr = allrows[:, :per].reshape(Qp)[:Qb].contiguous()
+            flags = allrows[:, per].contiguous().view(torch.int32)
+            ymax_all = allrows[:, per + 1: per + 3].contiguous()
+            f16r_stages.keep_members(lval, lidx, k, thr, qb, ymax_all)
+            v, i = f16r_stages.rescore(qb, g_local, lidx, k, index_base)
+            any_flag = flags.ne(0).any().to(torch.int32).reshape(1)
+            return gather_and_merge(v, i, any_flag)
         # only the filter VALUES travel (+ one row: the flag and the shard's norm maxima): the indices stay where their
         # rows are — a rank rescoring its own members never reads another rank's lidx
         extra = torch.zeros((1, K2), dtype=torch.float32, device=lval.device)

@@ -28,15 +28,38 @@ def timed(fn, iters=10, warm=3):
     return (time.perf_counter() - t0) / iters * 1e3
 
 
+# xGMI time is CHARGED (round 6): every emulated collective also holds the exchange stream for
+# (bytes this rank receives) / (7 links x 50 GB/s) — torch.cuda._sleep, calibrated against HIP events below.  The
+# device copy of the gathered size stays (it is what the received data costs in HBM).  LINK_GBS = 0 switches it off.
+LINK_GBS = 350.0
+_cal = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+torch.cuda._sleep(1000)
+torch.cuda.synchronize()
+_cal[0].record()
+torch.cuda._sleep(20_000_000)
+_cal[1].record()
+torch.cuda.synchronize()
+SLEEP_CYCLES_PER_MS = 20_000_000 / _cal[0].elapsed_time(_cal[1])
+
+
+def link(nbytes):
+    """hold the current stream for the time `nbytes` take to arrive over the rank's seven xGMI links"""
+    if LINK_GBS > 0 and nbytes > 0:
+        torch.cuda._sleep(int(nbytes / (LINK_GBS * 1e9) * 1e3 * SLEEP_CYCLES_PER_MS))
+
+
 worlds = [int(w) for w in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1, 2, 4, 8]
 prec = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 base = None
 BLOCKS = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 LANES = int(sys.argv[4]) if len(sys.argv) > 4 else 2     # matrix work of sub-block b on compute stream b % LANES
+SLICED = (sys.argv[5] != "0") if len(sys.argv) > 5 else True   # query-sliced post-processing (sharded.py, round 6)
 print(f"precision {prec}; the gallery shard is resident (ops.PreparedRows); per step the Q / W queries of every rank "
       f"travel in {BLOCKS} sub-blocks — the all_gather of sub-block b + 1 and the list exchange + merge of sub-block b on a "
-      f"second stream under the matrix work (sharded.sharded_topk_pipelined, bench.py's schedule) — both collectives "
-      f"EMULATED by device copies of the gathered sizes (one GPU here: no xGMI time in these numbers)")
+      f"second stream under the matrix work (sharded.sharded_topk_pipelined, bench.py's schedule) — every collective "
+      f"EMULATED by a device copy of the received size + a hold of the exchange stream for received bytes / "
+      f"{LINK_GBS:.0f} GB/s (one GPU here; 7 xGMI links x 50 GB/s); post-processing "
+      f"{'SLICED: all_to_all of the lists, merge of Q / W queries per rank, all_gather of the merged slices' if SLICED else 'replicated: all_gather of every list, every rank merges all Q queries (rounds 1-5)'}")
 side = torch.cuda.Stream()
 main = torch.cuda.current_stream()
 mains = [main] + [torch.cuda.Stream() for _ in range(LANES - 1)]
@@ -69,6 +92,23 @@ for world in worlds:
         keep_mask = (torch.arange(K2, device=dev)[None, :] % world == 0).expand(world * sub, K2)
         minus1 = torch.full((world * sub, K2), -1, dtype=torch.int32, device=dev)
 
+    qrow_bytes = gathered_src.numel() * gathered_src.element_size() // max(1, world * sub)
+    recv = (world - 1) / world                       # share of a gathered / exchanged buffer that crosses the links
+    per = -(-(world * sub) // world)                 # queries of a sub-block this rank post-processes when SLICED
+
+    def exchange_lists(vals_, idx_):
+        """the exact lists of one sub-block: exchange + merge (+ final all_gather when sliced)"""
+        if SLICED:
+            lists_dst[0].copy_(lists_src[0])        # all_to_all: [world * sub][2K] out, as much in
+            link(recv * world * sub * 2 * K * 4)
+            ops.row_topk(vals_[:per], K, idx_in=idx_[:per])     # merge of Q / W queries
+            lists_dst[1].copy_(lists_src[1])        # all_gather of the merged slices
+            link(recv * world * sub * 2 * K * 4)
+        else:
+            lists_dst.copy_(lists_src)              # all_gather of every rank's lists
+            link(recv * world * world * sub * 2 * K * 4)
+            ops.row_topk(vals_, K, idx_in=idx_)     # k-way merge of all queries
+
     def step():
         if world == 1:
             return ops.sqdist_topk_prepared(ops.PreparedRows(q_mine, prec), shard, K, defer_check=True)
@@ -82,12 +122,14 @@ for world in worlds:
                     if not rows_travel:
                         ops.PreparedRows(q_mine[:sub], prec)
                     gathered_dst.copy_(gathered_src)    # all_gather of sub-block 0 (gathered size)
+                    link(recv * world * sub * qrow_bytes)
                     e0 = torch.cuda.Event(); e0.record(side); evs.append(e0)
             if b + 1 < BLOCKS:
                 with torch.cuda.stream(side):
                     if not rows_travel:
                         ops.PreparedRows(q_mine[:sub], prec)
                     gathered_dst.copy_(gathered_src)    # sub-block b + 1 travels under sub-block b's matrix work
+                    link(recv * world * sub * qrow_bytes)
                     e = torch.cuda.Event(); e.record(side); evs.append(e)
             cs = mains[b % LANES]
             cs.wait_event(evs[b])
@@ -100,20 +142,26 @@ for world in worlds:
             side.wait_stream(cs)
             if prec == "f16r":
                 with torch.cuda.stream(side):
-                    f_dst.copy_(f_src)                  # all_gather of the filter lists [world][Qb + 1][2 K2]
-                    thr = ops.row_topk(f_vals, K)[0][:, K - 1].contiguous()
+                    if SLICED:
+                        f_dst[0, :, :K2].copy_(f_src[0, :, :K2])     # all_to_all of the filter VALUES [world * sub][K2]
+                        link(recv * world * sub * K2 * 4)
+                        thr_s = ops.row_topk(f_vals[:per], K)[0][:, K - 1].contiguous()   # thresholds of Q / W queries
+                        link(recv * world * sub * 4)                 # all_gather of the thresholds: 4 bytes per query
+                        thr = thr_s.repeat(world)[: world * sub].contiguous()
+                    else:
+                        f_dst[:, :, :K2].copy_(f_src[:, :, :K2])     # all_gather of the filter values [world][Qb + 1][K2]
+                        link(recv * world * world * sub * K2 * 4)
+                        thr = ops.row_topk(f_vals, K)[0][:, K - 1].contiguous()
                     if keep_frac:
                         lidx2 = torch.where(keep_mask, lidx, minus1)     # 1 / world of the members are this rank's
                     else:
                         lidx2 = lidx
                     ops.f16r_keep_members(lval, lidx2, K, thr, qb, ymax_all)
                     out = ops.f16r_rescore(qb, shard, lidx2, K)
-                    lists_dst.copy_(lists_src)          # all_gather of the exact lists
-                    ops.row_topk(vals, K, idx_in=idx)   # k-way merge
+                    exchange_lists(vals, idx)
                 continue
             with torch.cuda.stream(side):
-                lists_dst.copy_(lists_src)              # all_gather of this sub-block's lists (gathered size)
-                ops.row_topk(vals, K, idx_in=idx)       # k-way merge
+                exchange_lists(vals, idx)
         for cs in mains[1:]:
             main.wait_stream(cs)
         main.wait_stream(side)

@@ -241,6 +241,32 @@ def _worker(rank, world, port, G, ret):
                                                   merge_fn=_oracle_merge, f16r_stages=_CpuF16rStages,
                                                   prepare_fn=lambda x: x, rows_travel=True)
         ok_topk = ok_topk and bool(np.array_equal(i13.numpy(), wi) and np.allclose(v13.numpy(), wv))
+        # query-SLICED post-processing (round 6, the default: an all_to_all hands every rank the lists of ITS Q / W
+        # queries, it merges those and the merged slices are all-gathered) against the replicated merge of rounds 1-5
+        # (all_gather of every list, every rank merges all Q): the same lists, bit for bit — query counts that do and
+        # do not divide by the world size, an overflowing block, the f16r two-phase protocol
+        assert sharded.SLICED_POSTPROCESSING
+        same = True
+        try:
+            for qn in (q.shape[0], q.shape[0] - 3, 1):
+                pair = []
+                for sl in (False, True):
+                    sharded.SLICED_POSTPROCESSING = sl
+                    pair.append(sharded.sharded_topk(q[:qn], g[start:start + n_valid], 10, start,
+                                                     local_topk_fn=_oracle_local_topk, merge_fn=_oracle_merge))
+                same = same and torch.equal(pair[0][0], pair[1][0]) and torch.equal(pair[0][1], pair[1][1]) \
+                    and tuple(pair[0][0].shape) == (qn, 10)
+            sharded.SLICED_POSTPROCESSING = False
+            a = sharded.sharded_topk(q, g[start:start + n_valid], 10, start, "f16r", blocks=2, merge_fn=_oracle_merge,
+                                     f16r_stages=_CpuF16rStages)
+            _first_block_overflows.seen = []
+            o = sharded.sharded_topk(q, g[start:start + n_valid], 10, start, blocks=2, local_topk_fn=_first_block_overflows,
+                                     merge_fn=_oracle_merge)
+            same = same and bool(np.array_equal(a[1].numpy(), wi) and np.allclose(a[0].numpy(), wv)
+                                 and np.array_equal(o[1].numpy(), wi))
+        finally:
+            sharded.SLICED_POSTPROCESSING = True
+        ok_topk = ok_topk and same
         rec = evaluators.recalls_from_topk(idx.numpy(), gt)
         ok_rec = bool(np.array_equal(rec, om.evaluate_all(d, gt, pids)))
 
