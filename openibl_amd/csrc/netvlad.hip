@@ -501,13 +501,20 @@ static size_t nv_off_parts(int N, int P, int K, int C) {
 
 // the fused kernel's slabs: 160 pixels; it serves batches of 16 images and more (8 slabs of a 30 x 40 map: from 128
 // workgroups on; measured 97 against 112 us for five launches at batch 32, 86 against 79 at batch 8)
-constexpr int NVF_SLAB_PX = 160, NVF_MIN_N = 16;
-static int nvf_slabs(int P) { return (P + NVF_SLAB_PX - 1) / NVF_SLAB_PX; }
+// Round 6: the slab shrinks with the batch — a slab is a workgroup, and 8 slabs x N images fill the
+// chip only from N = 32 on: 96 pixels below 16 images, 64 below 8, 32 (one chunk) below 4 — so that the fused kernel
+// serves EVERY batch size (N = 1: 38 workgroups, one per chunk of the 30 x 40 map; the five launches it replaces read
+// the map three times).  The slab size is a function of N alone (a row's result must not depend on its batch mates
+// within a kernel selection: the per-N association of the slab sums is tested), hook 3 forces the fused kernel
+// everywhere, hook 2 the five launches.
+constexpr int NVF_MIN_N = 1;
+static int nvf_slab_px(int N) { return N >= 16 ? 160 : N >= 8 ? 96 : N >= 4 ? 64 : 32; }
+static int nvf_slabs(int N, int P) { return (P + nvf_slab_px(N) - 1) / nvf_slab_px(N); }
 
 size_t oibl_netvlad_workspace_bytes(int N, int P, int K, int C) {
   if (N <= 0 || P <= 0 || K <= 0 || C <= 0) return 0;
   int slabs = nv_pixel_slabs(N, P);
-  if (N >= NVF_MIN_N && nvf_slabs(P) > slabs) slabs = nvf_slabs(P);
+  if (nvf_slabs(N, P) > slabs) slabs = nvf_slabs(N, P);
   return nv_off_parts(N, P, K, C) + align_up((size_t)slabs * N * K * C * sizeof(float), 256);
 }
 
@@ -536,13 +543,14 @@ int oibl_netvlad_forward(const void* feat, int N, int P, int K, int C, int preci
   float* raw = vlad_raw ? vlad_raw : (float*)(wsb + nv_off_raw(N, P));
   void* w_t = wsb + nv_off_w(N, P, K, C);
   const long rows = (long)N * P;
-  if (precision == OIBL_F32 && g_nv_slabs == 1 && C == 512 && N >= NVF_MIN_N && (uintptr_t)assign_w % 16 == 0) {
+  if (precision == OIBL_F32 && ((g_nv_slabs == 1 && N >= NVF_MIN_N) || g_nv_slabs == 3) && C == 512 &&
+      (uintptr_t)assign_w % 16 == 0) {
     // the fused layer: the map read once (netvlad_fused_kernel), then the slab sum + the two normalising launches
-    const int ns = nvf_slabs(P);
+    const int ns = nvf_slabs(N, P);
     float* parts = ns > 1 ? (float*)(wsb + nv_off_parts(N, P, K, C)) : raw;   // (one slab: it IS the raw output)
     OIBL_SET_MAX_LDS(netvlad_fused_kernel, NVF_LDS);
     hipLaunchKernelGGL(netvlad_fused_kernel, dim3((unsigned)N, (unsigned)ns), dim3(256), NVF_LDS, st, (const float*)feat,
-                       assign_w, centroids, parts, P, NVF_SLAB_PX, normalize_input);
+                       assign_w, centroids, parts, P, nvf_slab_px(N), normalize_input);
     OIBL_LAUNCH_CHECK();
     float* stats = (float*)(wsb + nv_off_stats(N, P, K, C));
     const long vrows = (long)N * K;
@@ -614,7 +622,7 @@ int oibl_netvlad_forward(const void* feat, int N, int P, int K, int C, int preci
 
 #ifdef OIBL_DEBUG_HOOKS
 int oibl_debug_set_netvlad_slabs(int on) {
-  g_nv_slabs = on < 0 ? 0 : (on > 2 ? 2 : on);
+  g_nv_slabs = on < 0 ? 0 : (on > 3 ? 3 : on);
   return OIBL_OK;
 }
 #endif

@@ -31,7 +31,7 @@ def timed(fn, iters=50):
 
 
 g = torch.Generator(device=dev).manual_seed(3)
-for N in (32, 8, 1):
+for N in (32, 16, 12, 8, 4, 2, 1):
     feat = torch.randn((N, 30, 40, 512), generator=g, device=dev) * 3.0
     t_f = timed(lambda: ops.netvlad(feat, cw, cent, True, want_raw=False, want_norm=True))
     lib.debug_hooks().oibl_debug_set_netvlad_slabs(2)
