@@ -501,13 +501,16 @@ static size_t nv_off_parts(int N, int P, int K, int C) {
 
 // the fused kernel's slabs: 160 pixels; it serves batches of 16 images and more (8 slabs of a 30 x 40 map: from 128
 // workgroups on; measured 97 against 112 us for five launches at batch 32, 86 against 79 at batch 8)
-// Round 6: the slab shrinks with the batch — a slab is a workgroup, and 8 slabs x N images fill the
-// chip only from N = 32 on: 96 pixels below 16 images, 64 below 8, 32 (one chunk) below 4 — so that the fused kernel
-// serves EVERY batch size (N = 1: 38 workgroups, one per chunk of the 30 x 40 map; the five launches it replaces read
-// the map three times).  The slab size is a function of N alone (a row's result must not depend on its batch mates
-// within a kernel selection: the per-N association of the slab sums is tested), hook 3 forces the fused kernel
-// everywhere, hook 2 the five launches.
-constexpr int NVF_MIN_N = 1;
+// Round 6 ("fused NetVLAD for N < 16 with the pixel-slab split inside the kernel"): built — the slab
+// shrinks with the batch (96 pixels below 16 images, 64 below 8, 32 = one chunk below 4: N = 1 is 38 workgroups) — and
+// MEASURED (tests/gpu_head_bench.py, profiles/r06_h_head_bench.txt; fused | five launches, us): N = 32: 97 | 113,
+// 16: 87 | 84, 12: 79 | 79, 8: 78 | 78, 4: 80 | 54, 2: 110 | 52, 1: 100 | 51.  Every workgroup of the fused kernel
+// first loads its waves' 128 KB of assignment weights into registers and ends in a 128 KB partial: fixed costs a
+// 32-pixel slab does not amortise, while the five launches' pixel-split aggregation has none.  So the fused kernel
+// keeps serving batches of 16 images and more, the five launches everything below (hook 3 forces the fused kernel at
+// any N, hook 2 the five launches).  The slab size is a function of N alone (a row's result must not depend on its
+// batch mates within a kernel selection).
+constexpr int NVF_MIN_N = 16;
 static int nvf_slab_px(int N) { return N >= 16 ? 160 : N >= 8 ? 96 : N >= 4 ? 64 : 32; }
 static int nvf_slabs(int N, int P) { return (P + nvf_slab_px(N) - 1) / nvf_slab_px(N); }
 

@@ -197,3 +197,15 @@ def test_netvlad_fused_kernel_against_the_five_launch_path(dev, normalize_input)
         want = od.netvlad(f.double(), sd["net_vlad.conv.weight"].double(), sd["net_vlad.centroids"].double(), normalize_input)
         assert_rel_l2("fused raw vs the fp64 oracle", outs[20][0].cpu(), want, 5e-6)
         assert_rel_l2("fused normalised vs the fp64 oracle", outs[20][1].cpu(), od.normalize_vlad(want), 5e-6)
+        # round 6: the fused kernel at ANY batch size (hook 3: slabs of 32 / 64 / 96 pixels below 4 / 8 / 16 images —
+        # measured slower than the five launches there, so not the default): the same layer
+        lib.debug_hooks().oibl_debug_set_netvlad_slabs(3)
+        try:
+            small = {n: ops.netvlad(feat[:n].contiguous(), cw, cent, normalize_input, want_raw=True, want_norm=True)
+                     for n in (1, 3, 5, 9)}
+        finally:
+            lib.debug_hooks().oibl_debug_set_netvlad_slabs(1)
+        for n, (raw, nrm) in small.items():
+            assert_rel_l2(f"fused at N = {n}, raw vs the fp64 oracle", raw.cpu(), want[:n], 5e-6)
+            assert_rel_l2(f"fused at N = {n}, normalised", nrm.cpu(), od.normalize_vlad(want[:n]), 5e-6)
+        assert torch.equal(small[1][0], small[3][0][:1])                     # same slab size: rows independent of their mates
