@@ -2118,9 +2118,28 @@ constexpr bool S3_TAIL128 = true, S3_LANE_PERM = true;
 #else
 constexpr bool S3_TAIL128 = false, S3_LANE_PERM = false;
 #endif
+// ONE workgroup per tile for the f16mx stem (round 6): conv1_1 + the f16mx line packing of a tile's 340-pixel halo — the
+// vector-ALU work that bounds the kernel — is done ONCE instead of in both workgroups of the tile, and that workgroup
+// runs BOTH halves of conv1_2's output channels one after the other over the same two halo buffers:
+//   stage S1  consumers: channels 0-31,  input half 0 (halo buffer 0)   producers: conv1_1 half 1 of this tile -> buffer 1
+//   stage S2  consumers: channels 0-31,  input half 1 (buffer 1)         producers: convert the next tile's window, gather the one after
+//             consumers: pool / pack / store channels 0-31
+//   stage S3  consumers: channels 32-63, input half 0 (buffer 0)         producers: —
+//   stage S4  consumers: channels 32-63, input half 1 (buffer 1)         producers: conv1_1 half 0 of the NEXT tile -> buffer 0
+//             consumers: pool / pack / store channels 32-63
+// (buffer 0 is last read in S3, buffer 1 in S4: the producers keep their one-stage run-ahead).  conv1_2's weights no
+// longer fit as residents (2 x 72 KB): the 36 KB image of the NEXT stage (its output-channel half x input half: 9 taps x
+// 32 rows x 128 B) streams from L2 into the weight buffer the PREVIOUS stage used while the current one computes —
+// buffer_load ... lds issued by the consumers at the head of their pass, vmcnt(0) in front of the stage's barrier:
+// 147 KB per tile through the LDS-DMA path, the same 72 KB of LDS.  -DOIBL_STEM_SPLIT restores the two workgroups per tile.
+#ifdef OIBL_STEM_SPLIT
+constexpr bool S3_DUAL = false;
+#else
+constexpr bool S3_DUAL = true;
+#endif
 constexpr int S3_W_BYTES = 2 * 9 * 32 * 128;
 constexpr int S3_BIAS_OFF = S3_W_BYTES + 2 * ST_HALO_BYTES;   // conv1_1 bias: 64 floats; MX: + this half's 32 of conv1_2
-constexpr int S3_LDS_BYTES = S3_BIAS_OFF + 256 + 128;
+constexpr int S3_LDS_BYTES = S3_BIAS_OFF + 256 + 256;    // conv1_1's 64 biases + conv1_2's (32 of a half; all 64: S3_DUAL)
 
 // MX = true: the f16mx stem.  Same roles, tiles, passes and hand-overs; what changes is the arithmetic of
 // conv1_2 (2 f16 + 1 scaled-fp6 MFMA per 32 K instead of 6 bf16 ones) and therefore every format:
@@ -2156,8 +2175,9 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = lane >> 5, l31 = lane & 31;
+  constexpr bool DUAL = MX && S3_DUAL;   // one workgroup per tile, both output-channel halves in turn (above)
   const int first = blockIdx.x, stride = gridDim.x;
-  const int co0 = blockIdx.y * 32;       // this workgroup's conv1_2 output channels
+  const int co0 = DUAL ? 0 : blockIdx.y * 32;       // this workgroup's (first) conv1_2 output channels
   int niter = 0;
   if (first < p.ntiles) niter = (p.ntiles - first + stride - 1) / stride;
   const int nstages = 2 * niter;
@@ -2166,7 +2186,7 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
   // (f16mx: conv1_1's weights and both biases carry the activation scale — every activation of the kernel, the
   //  halo tile in LDS included, is stored scaled; vgg_forward_impl)
   if (threadIdx.x < 64) reinterpret_cast<float*>(smem + S3_BIAS_OFF)[threadIdx.x] = p.b1[threadIdx.x] * (MX ? p.act_scale : 1.f);
-  if (MX && threadIdx.x >= 64 && threadIdx.x < 96)
+  if (MX && threadIdx.x >= 64 && threadIdx.x < (DUAL ? 128 : 96))
     reinterpret_cast<float*>(smem + S3_BIAS_OFF)[threadIdx.x] = p.b2[co0 + threadIdx.x - 64] * (MX ? p.act_scale : 1.f);
   __syncthreads();
   // f16mx range guard (common.h): the largest group maximum this lane has packed, in a register; the flag —
@@ -2604,6 +2624,29 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if constexpr (DUAL) {
+      for (int it = 0; it < niter; ++it) {
+        // S1: the tile's second channel half into buffer 1 (last read in S4 of the previous tile)
+        unsigned long long t0 = prof ? __builtin_amdgcn_s_memtime() : 0;
+        produce(first + it * stride, H1{}, hb + ST_HALO_BYTES);
+        hand_over(t0, 0);
+        // S2: the tile's fragments are no longer needed — the window of tile it+1 (it has had a whole tile to
+        // arrive) is converted and the gathers of tile it+2 go out
+        t0 = prof ? __builtin_amdgcn_s_memtime() : 0;
+        if (it + 1 < niter) {
+          convert();
+          if (it + 2 < niter) issue_loads(first + (it + 2) * stride);
+        }
+        hand_over(t0);
+        // S3: nothing (buffer 0 is still read)
+        t0 = prof ? __builtin_amdgcn_s_memtime() : 0;
+        hand_over(t0);
+        // S4: the first channel half of the next tile into buffer 0 (last read in S3)
+        t0 = prof ? __builtin_amdgcn_s_memtime() : 0;
+        if (it + 1 < niter) produce(first + (it + 1) * stride, H0{}, hb);
+        hand_over(t0);
+      }
+    } else
     for (int it = 0; it < niter; ++it) {
       // while the consumers run pass 0 of tile it: its second channel half; then — its fragments
       // are no longer needed — the window of tile it+1 (it has had a whole tile to arrive) is
@@ -2643,10 +2686,28 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
       else if (cprio == 2) __builtin_amdgcn_s_setprio(2);
       else if (cprio == 3) __builtin_amdgcn_s_setprio(3);
     }
-    {
-      // conv1_2's weights: LDS row (h * 9 + tap) * 32 + m = the f16mx line of output channel co0 + chan(m),
-      // input group h; 16-byte slots swizzled by (m >> 1) & 7
-      const int piece = ((lane & 7) ^ (4 * (wave & 1) + (lane >> 4))) * 16;
+    // conv1_2's weights: LDS row (h * 9 + tap) * 32 + m = the f16mx line of output channel co0 + chan(m),
+    // input group h; 16-byte slots swizzled by (m >> 1) & 7
+    const int wpiece = ((lane & 7) ^ (4 * (wave & 1) + (lane >> 4))) * 16;
+    const __amdgpu_buffer_rsrc_t rs_w2 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w2), 0, 9 * 64 * 256, 0x00020000);
+    // DUAL: the 36 KB image (output-channel half c, input half h) into weight buffer `buf`: nine LDS-DMA
+    // instructions per consumer wave (buffer loads: the compiler counts them in vmcnt only — a global_load_lds it has
+    // not seen waited for turns every counted lgkmcnt of the pass into lgkmcnt(0))
+    auto stream_w = [&](int c, int h, int buf) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        const int q = j * 4 + wave;
+        const int r = q * 8 + (lane >> 3);
+        const int tap = r >> 5, m = r & 31;
+        const int ch = 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3);
+        buf_glds16(rs_w2, (unsigned)((tap * 64 + 32 * c + ch) * 256 + h * 128 + wpiece), 0u,
+                   wl + buf * (9 * 32 * 128) + q * 1024);
+      }
+    };
+    if constexpr (DUAL) {
+      stream_w(0, 0, 0);
+    } else {
 #pragma unroll
       for (int j = 0; j < 18; ++j) {
         const int q = j * 4 + wave;
@@ -2654,7 +2715,7 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
         const int h = r / 288, rem = r - 288 * h;
         const int tap = rem >> 5, m = rem & 31;
         const int ch = 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3);
-        glds16(p.w2 + ((long)(tap * 64 + co0 + ch) * 256 + h * 128) + piece, wl + q * 1024);
+        glds16(p.w2 + ((long)(tap * 64 + co0 + ch) * 256 + h * 128) + wpiece, wl + q * 1024);
       }
     }
     // Pixel (B) fragments: the bf16x3 consumers' addressing (below): lane (pixel l31 of block i, k-half hc)
@@ -2694,9 +2755,14 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
     f16x8_t w0, w1, b0[2], b1[2];
     u4 wma, bma[2];
     u4 wmt, bmt[2];
-    auto run_pass = [&](auto h_c) __attribute__((always_inline)) {
+    // DUAL: (nc, nh) = the stage after this one (nc < 0: none): its weight image streams into the buffer this pass
+    // does not read (the previous stage's, handed back behind that stage's barrier)
+    auto run_pass = [&](auto h_c, int nc = -1, int nh = 0) __attribute__((always_inline)) {
       constexpr int h = decltype(h_c)::value;
       const unsigned long long c0 = cprof ? __builtin_amdgcn_s_memtime() : 0;
+      if constexpr (DUAL) {
+        if (nc >= 0) stream_w(nc, nh, h ^ 1);
+      }
       const int pc = pxb + S3_W_BYTES + h * ST_HALO_BYTES;
       if (h == 0) {
 #pragma unroll
@@ -2807,8 +2873,10 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
         __builtin_amdgcn_sched_barrier(0);
         if (more) ld_bm(n, 1, a2, a3);
       }
-      // every fragment read of this halo buffer has been consumed: hand it back
+      // every fragment read of this halo buffer has been consumed: hand it back (DUAL: and the next stage's weight
+      // image has landed — it has had the whole pass)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if constexpr (DUAL) wait_vmcnt<0>();
       const unsigned long long c1 = cprof ? __builtin_amdgcn_s_memtime() : 0;
       __builtin_amdgcn_s_barrier();
       if (cprof) {
@@ -2821,15 +2889,25 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
     };
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
-    for (int it = 0; it < niter; ++it) {
-      run_pass(C0{});
-      run_pass(C1{});
+    constexpr int NCZ = DUAL ? 2 : 1;     // output-channel halves a workgroup runs per tile
+#pragma unroll 1
+    for (int itc = 0; itc < niter * NCZ; ++itc) {
+      const int it = DUAL ? (itc >> 1) : itc, cz = DUAL ? (itc & 1) : 0;
+      if constexpr (DUAL) {
+        // S1 / S3 stream the image of S2 / S4 (same output half, input half 1); S2 streams (half 1, input 0); S4 the
+        // next tile's (half 0, input 0)
+        run_pass(C0{}, cz, 1);
+        run_pass(C1{}, (cz == 0 || it + 1 < niter) ? (cz ^ 1) : -1, 0);
+      } else {
+        run_pass(C0{});
+        run_pass(C1{});
+      }
       const unsigned long long e0 = cprof ? __builtin_amdgcn_s_memtime() : 0;
       // 2x2 max-pool (the window = the lane quad: two DPP steps), bias, ReLU, pack, store.  Lane quad q of
       // block i is pooled pixel (wave, 8 i + q) of the tile's 4 x 16.
       const int lane_e = fresh_lane_id();
       const int half = lane_e >> 5, l31 = lane_e & 31;   // (shadow the kernel's: nothing lane-derived stays live across the passes)
-      const float* const bias2 = reinterpret_cast<const float*>(smem + S3_BIAS_OFF) + 64 + 16 * half;
+      const float* const bias2 = reinterpret_cast<const float*>(smem + S3_BIAS_OFF) + 64 + 32 * cz + 16 * half;
       const int tile = first + it * stride;
       const unsigned r2 = (unsigned)tile / (unsigned)p.tiles_x;
       const int tx = tile - (int)r2 * p.tiles_x;
@@ -2873,7 +2951,8 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
         mx_pack_half<false>(v, h16, h6, l6, bh, bl, range_seen);
         // lanes 0, 1 of a quad store: pooled pixel 8 (l31 & 1) + (l31 >> 2) of the tile row
         const unsigned off = (l31 & 2) ? 0x80000000u
-                                       : (unsigned)(tx * 16 + 8 * (l31 & 1) + (l31 >> 2)) * 256u + blockIdx.y * 128u;
+                                       : (unsigned)(tx * 16 + 8 * (l31 & 1) + (l31 >> 2)) * 256u +
+                                             (DUAL ? (unsigned)cz : blockIdx.y) * 128u;
         __builtin_amdgcn_raw_buffer_store_b128((u4){h16[0], h16[1], h16[2], h16[3]}, rs_o, (int)(off + 32 * half), 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128((u4){h16[4], h16[5], h16[6], h16[7]}, rs_o, (int)(off + 32 * half + 16), 0, 0);
         // e2m3 strings: this lane's dwords 3 half .. 3 half + 2; dwords 0-3 in slot 4 / 5, dwords 4, 5 in slot 6 / 7
@@ -3106,14 +3185,21 @@ static int launch_vgg_stem_x3(const void* x, int N, int H, int W, const float* w
   p.prod_prio = (mx && g_stem3_prio == 0) ? 14 : g_stem3_prio;
   int gx = 128;  // two workgroups (output-channel halves) per tile range: one persistent workgroup per CU
   if (gx > p.ntiles) gx = p.ntiles;
+  // f16mx, S3_DUAL: one workgroup per tile range and CU, both output-channel halves inside it
+  int gmx = 256, gmy = 1;
+  if (!S3_DUAL) {
+    gmx = gx;
+    gmy = 2;
+  }
+  if (gmx > p.ntiles) gmx = p.ntiles;
   if (mx && u8) {
     auto kern = vgg_stem_x3_kernel<true, true>;
     OIBL_SET_MAX_LDS(kern, S3_LDS_BYTES);
-    hipLaunchKernelGGL(kern, dim3(gx, 2), dim3(1024), S3_LDS_BYTES, st, p);
+    hipLaunchKernelGGL(kern, dim3(gmx, gmy), dim3(1024), S3_LDS_BYTES, st, p);
   } else if (mx) {
     auto kern = vgg_stem_x3_kernel<true>;
     OIBL_SET_MAX_LDS(kern, S3_LDS_BYTES);
-    hipLaunchKernelGGL(kern, dim3(gx, 2), dim3(1024), S3_LDS_BYTES, st, p);
+    hipLaunchKernelGGL(kern, dim3(gmx, gmy), dim3(1024), S3_LDS_BYTES, st, p);
   } else if (u8) {
     auto kern = vgg_stem_x3_kernel<false, true>;
     OIBL_SET_MAX_LDS(kern, S3_LDS_BYTES);
