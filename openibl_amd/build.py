@@ -46,7 +46,9 @@ CXXFLAGS = [
 # Round 6: ["-DOIBL_STEM_R6_LDS"] — the f16mx stem with MX tails as one ds_read_b128 and conflict-free producer line
 # writes (2612 -> 452 modelled bank-conflict cycles per tile, 2.0e8 -> 3.5e7 measured per launch): not faster (1.609
 # against 1.598 ms — the kernel is bound by VALU issue: profiles/r06_d_stem_lds_ab.txt); not adopted, off again.
-DBG_EXPERIMENT_FLAGS = []
+# ["-DOIBL_STEM_SPLIT"] — the f16mx stem of rounds 3-5 (two workgroups per tile, resident weights) as the debug library:
+# tests/gpu_stem_lds_ab.py times it against the product (one workgroup per tile): profiles/r06_j_stem_dual_ab.txt.
+DBG_EXPERIMENT_FLAGS = ["-DOIBL_STEM_SPLIT"]
 
 
 def _hipcc() -> str:

@@ -2113,7 +2113,10 @@ __device__ static inline int fresh_lane_id() {
 // SIMD can ISSUE on the vector ALU (1374 VALU wave-instructions per SIMD and tile = 5.5k of its 9.8k cycles at four
 // cycles each, three quarters of them the producers' conv1_1 + line packing, which BOTH workgroups of a tile run), and
 // the b128 operands cost 6 % more VALU instructions (register moves).  The product keeps the rounds 3-5 pattern.
-#ifdef OIBL_STEM_R6_LDS
+// ... for the two-workgroups-per-tile kernel (-DOIBL_STEM_SPLIT).  With ONE workgroup per tile (S3_DUAL below: the
+// producers' work per consumer pass is halved) the consumers' passes are what bounds the tile again, and the
+// conflict-free pattern is the default there.
+#if defined(OIBL_STEM_R6_LDS) || !defined(OIBL_STEM_SPLIT)
 constexpr bool S3_TAIL128 = true, S3_LANE_PERM = true;
 #else
 constexpr bool S3_TAIL128 = false, S3_LANE_PERM = false;

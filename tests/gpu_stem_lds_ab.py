@@ -11,7 +11,7 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from openibl_amd import build, lib, ops  # noqa: E402
 
-assert "-DOIBL_STEM_R6_LDS" in build.DBG_EXPERIMENT_FLAGS, "build the debug library with -DOIBL_STEM_R6_LDS first"
+assert build.DBG_EXPERIMENT_FLAGS, "build the debug library with an experiment flag first (openibl_amd/build.py)"
 dev = torch.device("cuda", 0)
 N, H, W = 32, 480, 640
 g = torch.Generator(device=dev).manual_seed(1)
@@ -37,7 +37,7 @@ def timed(iters=10):
     return a.elapsed_time(b) / iters, out
 
 
-ts, outs = {"product (b64 + b32 tails, lane = pixel)": [], "debug, OIBL_STEM_R6_LDS (b128 tails, lane permutation)": []}, {}
+ts, outs = {"product": [], "debug library, " + " ".join(build.DBG_EXPERIMENT_FLAGS): []}, {}
 for r in range(rounds):
     for name in ts:
         if name.startswith("product"):

@@ -17,8 +17,9 @@ w1 = torch.randn((64, 3, 3, 3), generator=g, device=dev) * 0.27
 b1 = torch.randn((64,), generator=g, device=dev) * 0.1
 w2 = torch.randn((64, 64, 3, 3), generator=g, device=dev) * 0.06
 b2 = torch.randn((64,), generator=g, device=dev) * 0.1
-tiles = N * ((H + 7) // 8) * ((W + 31) // 32) / 128
-modes = [int(a) for a in sys.argv[1:]] or [0]
+tiles = N * ((H + 7) // 8) * ((W + 31) // 32) / 128    # per workgroup, two workgroups per tile (bf16x3; f16mx with -DOIBL_STEM_SPLIT)
+tiles_mx = N * ((H + 7) // 8) * ((W + 31) // 32) / 256  # f16mx, one workgroup per tile (round 6): 256 tile streams
+modes = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [0]
 for name, fn, prec, mode in [("bf16x3", ops.vgg16_stem_x3, "bf16x3", 0)] + [("f16mx", ops.vgg16_stem_mx, "f16mx", m) for m in modes]:
     L.oibl_debug_set_stem3_prio(mode)   # producer priority | consumer priority << 2
     name = f"{name} prio {mode & 3}/{(mode >> 2) & 3}"
@@ -38,6 +39,7 @@ for name, fn, prec, mode in [("bf16x3", ops.vgg16_stem_x3, "bf16x3", 0)] + [("f1
     torch.cuda.synchronize()
     L.oibl_debug_set_prof_buffer(None)
     t = buf.cpu().tolist()
+    tiles = tiles_mx if ("f16mx" in name and "--split" not in sys.argv) else N * ((H + 7) // 8) * ((W + 31) // 32) / 128
     print(f"{name} stem: {a.elapsed_time(b) / 10:.3f} ms | per tile: consumer passes {t[0] / tiles:7.0f} waits {t[1] / tiles:6.0f} "
           f"epilogue {t[2] / tiles:6.0f} | producer work {t[4] / tiles:7.0f} waits {t[5] / tiles:6.0f}"
           + (f" || beside pass 0: consumers wait {t[3] / tiles:6.0f}, producers work {t[6] / tiles:6.0f} wait {t[7] / tiles:6.0f}"
