@@ -47,8 +47,9 @@ CXXFLAGS = [
 # writes (2612 -> 452 modelled bank-conflict cycles per tile, 2.0e8 -> 3.5e7 measured per launch): not faster (1.609
 # against 1.598 ms — the kernel is bound by VALU issue: profiles/r06_d_stem_lds_ab.txt); not adopted, off again.
 # ["-DOIBL_STEM_SPLIT"] — the f16mx stem of rounds 3-5 (two workgroups per tile, resident weights) as the debug library:
-# tests/gpu_stem_lds_ab.py times it against the product (one workgroup per tile): profiles/r06_j_stem_dual_ab.txt.
-DBG_EXPERIMENT_FLAGS = ["-DOIBL_STEM_SPLIT"]
+# tests/gpu_stem_lds_ab.py times it against the product (one workgroup per tile): 1.555 -> 1.384 ms, bit-identical,
+# profiles/r06_j_stem_dual_ab.txt — adopted; off again.  ["-DOIBL_HALO4_CONT"]: profiles/r06_e_halo4_cont.txt.
+DBG_EXPERIMENT_FLAGS = []
 
 
 def _hipcc() -> str:
