@@ -26,8 +26,14 @@
 //   select    one wave per query holds its candidate list in registers: k rounds of minimum extraction give T =
 //             the k-th smallest D_h, and a member of the true top-k has D_h <= T + max_{e < k} eps_e + eps(i, j)
 //             <= T + 2 eps_any (eps_any: the bound with the gallery-wide maxima of |y|, |ry|): the RESCORE SET,
-//             typically k + 2..5 entries, compacted by ballot.  More than K2 (32 for k <= 16) members, or a list
-//             beyond the register window: *overflow is raised and the caller repeats on the exact fp32 path.
+//             typically k + 2..5 entries, compacted by ballot.  k > 32 (round 6: the 120 ranks of spatial NMS, up
+//             to 496): T by BISECTION over the values' order-preserving image, one workgroup per query
+//             (f16r_select_bisect_kernel).  More than K2 (32 for k <= 16, 2k + 32 beyond) members, or a list beyond
+//             the register window: *overflow is raised and the caller repeats on the exact path.
+//   storage   (round 6) the rows may be STORED as fp32, IEEE half or bf16 (OIBL_ST_*): prepare widens them exactly,
+//             the rescoring reads the stored rows; an fp16-stored row is its own fp16 image (residual 0).  The exact
+//             path (small problems, the repeat after *overflow) takes its member set from fp32 distance tiles and
+//             ends in the SAME rescoring: values and tie order do not depend on the path.
 //   rescore   for the set only: x.y from the resident fp32 rows, accumulated in fp64 (one wave per pair, a 16 KB
 //             contiguous gather per gallery row), D = fl32((|x|^2 + |y|^2) - 2 x.y) with the fp32 norms every
 //             mode uses; the k smallest (D, index) leave, lowest index first on ties.
