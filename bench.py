@@ -263,9 +263,10 @@ def time_extraction(c, model, x, precision, steps, warmup, eager=False, pipeline
     if precision == "f16mx":
         # per 32x32x32 block: 2 x v_mfma_f32_32x32x16_f16 + 1 x v_mfma_scale_f32_32x32x64_f8f6f4 = 96 cycles
         # of the matrix pipe against 64 for bf16; conv1_1 (0.56 % of the FLOPs, K = 27 padded to 32) runs at 3x in
-        # bf16x3 inside the stem — in BOTH of a tile's workgroups (each serves half of conv1_2's output channels)
+        # bf16x3 inside the stem — ONCE per tile since round 6 (one workgroup serves both halves of conv1_2's output
+        # channels; rounds 3-5 ran it in both workgroups of a tile: a factor 2 on this term)
         c11 = conv11_flops_per_image() / (igemm_flops_per_image() + conv11_flops_per_image())
-        roof["matrix_pipe_time_per_product_vs_bf16"] = round((1.0 - c11) * 1.5 + c11 * 3.0 * 2.0 * 32.0 / 27.0, 3)
+        roof["matrix_pipe_time_per_product_vs_bf16"] = round((1.0 - c11) * 1.5 + c11 * 3.0 * 32.0 / 27.0, 3)
         roof["issued_frac"] = round(roof["matrix_pipe_time_per_product_vs_bf16"] * achieved / peak, 4)
     runs = {k_: v_ - runs0.get(k_, 0) for k_, v_ in bm.precision_runs.items() if v_ - runs0.get(k_, 0)}
     return {"value": round(value, 2), "ms_per_step": round(elapsed / steps * 1e3, 4),
