@@ -2179,10 +2179,21 @@ __global__ __launch_bounds__(1024) void vgg_stem_x3_kernel(StemParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = lane >> 5, l31 = lane & 31;
   constexpr bool DUAL = MX && S3_DUAL;   // one workgroup per tile, both output-channel halves in turn (above)
-  const int first = blockIdx.x, stride = gridDim.x;
+  // The tiles of a workgroup: tile `first + it * stride`, it < niter.  Workgroups are dealt to the 8 XCDs round-robin
+  // (id % 8), and every XCD has its own L2: with tile = blockIdx.x + it * gridDim.x (rounds 2-5) the four neighbours
+  // of a tile — whose 10 x 34-pixel halo windows overlap its own by a third — were gathered through four OTHER L2s
+  // and the kernel fetched 256 MB for a 118 MB input.  Round 6: XCD x owns the contiguous eighth [x T / 8, (x + 1) T / 8)
+  // of the tile sequence (whole tile rows of whole images) and deals it to its gridDim.x / 8 workgroups.
+  int first = blockIdx.x, stride = gridDim.x, tile_end = p.ntiles;
+  if ((gridDim.x & 7) == 0) {
+    const int x = blockIdx.x & 7;
+    stride = gridDim.x >> 3;
+    first = (int)((long)p.ntiles * x / 8) + (int)(blockIdx.x >> 3);
+    tile_end = (int)((long)p.ntiles * (x + 1) / 8);
+  }
   const int co0 = DUAL ? 0 : blockIdx.y * 32;       // this workgroup's (first) conv1_2 output channels
   int niter = 0;
-  if (first < p.ntiles) niter = (p.ntiles - first + stride - 1) / stride;
+  if (first < tile_end) niter = (tile_end - first + stride - 1) / stride;
   const int nstages = 2 * niter;
   const int Ho = p.H >> 1, Wo = p.W >> 1;
   // conv1_1's bias lives in LDS (the producers have no registers to spare for 2 x 16 values per lane)
