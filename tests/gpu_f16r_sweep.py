@@ -2,7 +2,7 @@
 rounded fp32 matrix — every index equal to fp64's except where fp64 itself calls a near-tie, every value within fp32
 rounding): random sizes, k, dimensions; unit rows, planted near-duplicates, rows of wildly different magnitude,
 duplicated gallery rows (exact ties: the lower index wins).
-    python tests/gpu_f16r_sweep.py [cases=60] [first seed=0]"""
+    python tests/gpu_f16r_sweep.py [cases=60] [first seed=0] [wide]      (wide: k in 33..496, fp32 / fp16 / bf16 storage)"""
 import sys
 import time
 from pathlib import Path
@@ -24,6 +24,11 @@ for seed in range(first, first + cases):
     m, n = r(1, 700), r(8192, 36000)
     d = [256, 512, 1024, 2048, 4096][r(0, 4)]
     k = [1, 5, 10, 20, 32][r(0, 4)]
+    store = torch.float32
+    if len(sys.argv) > 3 and sys.argv[3] == "wide":   # round 6: k beyond the register rounds (bisection selection) and
+        k = [33, 64, 120, 200, 496][r(0, 4)]         # descriptors STORED in 16 bits (rescored from the stored rows)
+        store = [torch.float32, torch.float16, torch.bfloat16][r(0, 2)]
+        n = max(n, 16 * 2048 if k > 120 else n)
     kind = ["unit", "hard", "scales", "dups"][seed % 4]
     if kind == "hard":
         q, gal, _, _ = synth.retrieval_problem(m, n, dim=d, seed=seed, hard_fraction=0.7)
@@ -38,11 +43,18 @@ for seed in range(first, first + cases):
             dst = torch.randint(0, n, (n // 8,), generator=g)
             gal[dst] = gal[src]
             q[: m // 2] = gal[torch.randint(0, n, (m // 2,), generator=g)] + 1e-3 * torch.randn((m // 2, d), generator=g)
-    v, i, flag = ops.sqdist_topk(q.to(dev), gal.to(dev), k, precision="f16r", defer_check=True)
+    if store != torch.float32:                   # the problem IS the stored values (widened exactly)
+        if kind == "scales" and store == torch.float16:
+            q, gal = q.clamp(-6e4, 6e4), gal.clamp(-6e4, 6e4)
+        qs, gs = q.to(store), gal.to(store)
+        q, gal = qs.float(), gs.float()
+    else:
+        qs, gs = q, gal
+    v, i, flag = ops.sqdist_topk(qs.to(dev), gs.to(dev), k, precision="f16r", defer_check=True)
     is_fused = bool(ops.f16r_fused(m, n, d, k))
     fused += int(is_fused)
     if int(flag.item()):                         # (overflow of a candidate list: the exact path answers)
-        v, i = ops.sqdist_topk(q.to(dev), gal.to(dev), k, precision="f16r")
+        v, i = ops.sqdist_topk(qs.to(dev), gs.to(dev), k, precision="f16r")
         is_fused = False
     q64, g64 = q.double().to(dev), gal.double().to(dev)
     d64 = (q64 ** 2).sum(1)[:, None] + (g64 ** 2).sum(1)[None] - 2.0 * q64 @ g64.t()
@@ -61,7 +73,8 @@ for seed in range(first, first + cases):
         same = v[:, 1:] == v[:, :-1]
         ok = bool((i[:, 1:][same] > i[:, :-1][same]).all())
     bad += int(not ok)
-    print(f"seed {seed:3d} {kind:6s} {m:3d} x {n:5d} x {d:4d} k={k:2d} {'fused' if is_fused else 'exact'} flag {int(flag.item())}: value err {verr:.1e}, "
+    sname = str(store).replace("torch.", "")
+    print(f"seed {seed:3d} {kind:6s} {m:3d} x {n:5d} x {d:4d} k={k:2d} {sname} {'fused' if is_fused else 'exact'} flag {int(flag.item())}: value err {verr:.1e}, "
           f"{int(diff.sum())} indices differ (fp64 gap {tie:.1e}) {'ok' if ok else 'FAILED'}", flush=True)
 print(f"{cases} cases, {fused} on the fused path, {bad} failed, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
