@@ -522,3 +522,37 @@ def test_pca_weight_holder_checks_its_argument_and_has_no_cpu_path():
         ops.pca(torch.zeros((3, 8192)), w, torch.zeros(256))
     with pytest.raises(ValueError):
         ops.PcaWeight(torch.zeros((256, 8192), dtype=torch.bfloat16)).packed()   # fp32 weights only
+
+
+def test_topk_precision_rule_host_side():
+    """ops.topk_precision is host logic: an f16mx model's descriptors are matched in f16r whatever their storage type
+    and for every ranked prefix the reference reads (k <= 496: Recall@1/5/10 and the 120 ranks of spatial NMS,
+    ibl/evaluators.py:152-153); the other precisions as asked (round 6)."""
+    from openibl_amd import ops
+    assert ops.topk_precision("f16mx") == ops.F16R
+    for dt in (torch.float32, torch.float16, torch.bfloat16):
+        for k in (1, 10, 120, 496):
+            assert ops.topk_precision("f16mx", dt, k) == ops.F16R
+    assert ops.topk_precision("f16mx", torch.float32, 497) == ops.F16MX
+    assert ops.topk_precision("f16mx", None, 10) == ops.F16MX          # query / gallery stored differently: as asked
+    for p in ("fp32", "bf16x3", "bf16"):
+        assert ops.topk_precision(p, torch.float16, 120) == ops.precision_code(p)
+    assert ops.F16R_MAX_FUSED_K == 496
+
+
+def test_tokyo_problem_is_what_it_says(tmp_path):
+    """synth.tokyo_problem: 12 views per place with one pid, one true place per query (all of its views are ground
+    truth), views of a place near-duplicates, deterministic whatever the thread count; on a small instance NMS changes
+    the oracle's Recall@5/10 — the property tests/test_gpu_tokyo.py relies on at the stated size."""
+    a = synth.tokyo_problem(24, 2400, dim=128, seed=9, views=12, distractors=6)
+    b = synth.tokyo_problem(24, 2400, dim=128, seed=9, views=12, distractors=6)
+    q, g, gt, pids = a
+    assert torch.equal(q, b[0]) and torch.equal(g, b[1]) and gt == b[2]
+    assert pids == [j // 12 for j in range(2400)] and all(len(t) == 12 and len({pids[j] for j in t}) == 1 for t in gt)
+    assert torch.allclose(g.norm(dim=1), torch.ones(2400), atol=1e-5)
+    place0 = g[:12]                                                    # an untouched place (if it is): views correlate
+    cos = (place0 @ place0.t()).min()
+    assert float(cos) > 0.5 or any(0 in t for t in gt)
+    d = om.pairwise_distance(q, g).numpy()
+    with_nms, without = om.evaluate_all(d, gt, pids, nms=True), om.evaluate_all(d, gt, pids, nms=False)
+    assert with_nms[0] == without[0] and with_nms[2] > without[2]
