@@ -118,6 +118,7 @@ class GraphedForward:
         # never aliases a caller's tensor; every slot starts with the example in place
         self.static_in = [example.clone(memory_format=torch.contiguous_format) for _ in range(self.depth)]
         self.done = [torch.cuda.Event() for _ in range(self.depth)]
+        self.stage_in = {}                    # (slot, half) -> (device staging buffer for host batches, its free event)
         self.g_backbone, self.g_head, self.out = [], [], []
         self._keep = []
         if range_guard is None and GUARD_REPLAYS:
@@ -206,6 +207,15 @@ class GraphedForward:
     def shape(self):
         return self.static_in[0].shape
 
+    def _stage_in(self, j: int, h: int):
+        """(device staging buffer, event of the device copy that last read it) for host batches of slot j."""
+        key = (j, h)
+        if key not in self.stage_in:
+            self.stage_in[key] = (torch.empty_like(self.static_in[j]), torch.cuda.Event())
+            # the block may have had an earlier life on the caller's stream
+            self.copy.wait_stream(torch.cuda.current_stream(self.device))
+        return self.stage_in[key]
+
     def __call__(self, x: Optional[torch.Tensor] = None, events=None,
                  dest: Optional[torch.Tensor] = None, stable_src: bool = False) -> torch.Tensor:
         """stable_src=False (default): `x` only has to stay unchanged until the lane has copied it (the
@@ -244,20 +254,36 @@ class GraphedForward:
                 self._settle((c, j, None, dest), True)
             return self.out[j]
         lane = self.lanes[j]
-        if x is not None:
+        if x is not None and x.is_cuda:
             # the slot's last backbone has read its input; whatever produced x on the caller's
             # stream has finished
             self.copy.wait_event(self.bb_done[j])
-            if x.is_cuda:
-                self.copy.wait_stream(main)
+            self.copy.wait_stream(main)
             with torch.cuda.stream(self.copy):
                 self.static_in[j].copy_(x, non_blocking=True)
                 self.in_ready[j].record(self.copy)
-            if x.is_cuda:
-                # the caller may drop x right after this call: its block must not be handed out again
-                # (on the caller's stream) before the copy stream has read it
-                x.record_stream(self.copy)
+            # the caller may drop x right after this call: its block must not be handed out again
+            # (on the caller's stream) before the copy stream has read it
+            x.record_stream(self.copy)
             lane.wait_event(self.in_ready[j])
+            self.last_stream = self.copy
+        elif x is not None:
+            # A host batch crosses PCIe into a STAGING buffer of the slot (two per slot, call c in buffer
+            # (c / depth) % 2) and moves into the graph's input with a device copy on the lane.  Copying straight
+            # into the slot's input had to wait for the slot's previous backbone (it reads that input), i.e. the
+            # transfer of batch c + 2 started when batch c was half done and the lane idled until it arrived: with
+            # 118 MB fp32 batches extract_features ran 10 % below the eager lanes, whose inputs are fresh tensors
+            # (profiles/r06_n_eager_lanes.txt).  Now the transfer waits only for the device copy that last read its
+            # staging buffer (four calls back) and runs as far ahead as the host does.
+            buf, free = self._stage_in(j, (c // self.depth) % 2)
+            self.copy.wait_event(free)
+            with torch.cuda.stream(self.copy):
+                buf.copy_(x, non_blocking=True)
+                self.in_ready[j].record(self.copy)
+            lane.wait_event(self.in_ready[j])
+            with torch.cuda.stream(lane):          # behind the slot's previous batch on the same lane
+                self.static_in[j].copy_(buf, non_blocking=True)
+                free.record(lane)
             self.last_stream = self.copy
         if dest is not None:
             lane.wait_stream(main)           # dest was allocated / last written on the caller's stream
