@@ -82,7 +82,9 @@ class GraphedForward:
     synchronisation), overwritten by the call `depth` calls later.  `dest=` hands the result off
     instead: the rows are copied into `dest` on the lane right behind the head, and the slot is free
     again without the caller synchronising.  A device tensor `x` must stay unchanged until the lane
-    has copied it (`wait()`); host tensors are read before the call returns unless pinned.
+    has copied it (`wait()`); host tensors are read before the call returns unless pinned.  A host batch
+    crosses PCIe into one of two device staging buffers of its slot (its transfer may run while the slot's
+    previous batch is still being computed) and reaches the graph's input with a device copy on the lane.
     `events`: optional (start, stop) torch.cuda.Event pair recorded on the launching lane right
     around the backbone graph (bench.py's matrix-core span: meaningful with ONE lane — with two the
     spans of consecutive batches overlap).

@@ -203,6 +203,37 @@ def test_two_lanes_in_flight_do_not_share_scratch(dev, precision):
         assert torch.equal(res[2 * r:2 * r + 2], wants[r % 2]), r
 
 
+@pytest.mark.parametrize("precision", ["bf16", "f16mx"])
+def test_host_batches_reach_the_replayed_forward_through_staging_buffers(dev, precision):
+    """Round 6: a host batch crosses PCIe into one of two staging buffers of its slot and moves into the graph's input
+    with a device copy on the lane (extract.GraphedForward.__call__).  Seven distinct batches, pinned / pageable /
+    device-resident in turn, many rounds with nothing waited for in between: every staging buffer is reused while
+    later transfers are queued, a slot sees host and device sources alternately, and every row of the result
+    matrix is its batch's eager descriptor, bit for bit."""
+    import hubconf
+    model = hubconf.vgg16_netvlad(pretrained=False)
+    model.load_state_dict(synth.embednetpca_state(0))
+    model = model.to(dev).eval().set_precision(precision)
+    N, H, W = 32, 112, 160                            # f16mx proper (not the small-batch bf16x3 route)
+    hosts = [synth.images(N, H, W, seed=70 + i) for i in range(7)]
+    wants = [model(h.to(dev)).clone() for h in hosts]
+    if precision == "f16mx":
+        assert model.base_model.effective_precision(hosts[0].to(dev)) == "f16mx"
+    srcs = []
+    for i, h in enumerate(hosts):
+        srcs.append(h.pin_memory() if i % 3 == 0 else (h if i % 3 == 1 else h.to(dev)))
+    pf = model.graphed(srcs[2], pipeline=True)
+    rounds = 35
+    res = torch.zeros((rounds * N, wants[0].shape[1]), device=dev)
+    for r in range(rounds):
+        pf(srcs[r % 7], dest=res[r * N:(r + 1) * N], stable_src=True)
+    pf.wait()
+    torch.cuda.synchronize()
+    assert len(pf.stage_in) == 4
+    for r in range(rounds):
+        assert torch.equal(res[r * N:(r + 1) * N], wants[r % 7]), r
+
+
 @pytest.mark.parametrize("precision", ["bf16", "fp32"])
 @pytest.mark.parametrize("N,H,W", [(2, 64, 96), (1, 70, 90), (1, 480, 640)])
 def test_uint8_input_equals_normalised_input(dev, N, H, W, precision):
