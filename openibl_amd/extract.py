@@ -52,6 +52,8 @@ def unwrap_model(model):
 
 
 _LANE_POOL = {}
+NUM_LANES = 2             # lanes of a pipelined replay.  Three are slower: f16mx 3570 / 3697 / 3665 images/s on
+                          # 1 / 2 / 3 lanes, bf16 6261 / 6812 / 6612 (tests/gpu_lanes_ab.py, profiles/r06_n_lanes_ab.txt)
 
 
 def _lane_streams(dev: torch.device):
@@ -63,7 +65,8 @@ def _lane_streams(dev: torch.device):
     of a device therefore share one pair of lanes (they are replayed one at a time anyway)."""
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     if key not in _LANE_POOL:
-        _LANE_POOL[key] = ([torch.cuda.Stream(device=dev) for _ in range(2)], torch.cuda.Stream(device=dev))
+        _LANE_POOL[key] = ([torch.cuda.Stream(device=dev) for _ in range(max(2, NUM_LANES))],
+                           torch.cuda.Stream(device=dev))
     return _LANE_POOL[key]
 
 
@@ -111,7 +114,7 @@ class GraphedForward:
         dev = example.device
         self.device = dev
         self.pipeline = bool(pipeline)
-        self.depth = 2 if self.pipeline else 1
+        self.depth = NUM_LANES if self.pipeline else 1
         self.calls = 0
         self.lanes, self.copy = _lane_streams(dev) if self.pipeline else ([None], None)
         self.in_ready = [torch.cuda.Event() for _ in range(self.depth)]
