@@ -85,6 +85,53 @@ __global__ __launch_bounds__(256) void pca_reduce_kernel(const float* __restrict
   if (threadIdx.x == 0) ss_part[(size_t)n * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// Reduction, bias, and the row's L2 normalisation in ONE launch for the packed stream (round 6; N <= 32 rows, d <= 4096):
+// a workgroup of 1024 threads owns a row, a thread four of its dimensions, all 4 x 16 partials of the thread in flight
+// at once (summed in a loop they were a chain of loads N workgroups cannot hide: 10 us slower than the two launches).
+constexpr int PRN_PER = 4;
+template <int SPLITS>
+__global__ __launch_bounds__(1024) void pca_reduce_norm_kernel(const float* __restrict__ part,
+                                                               const float* __restrict__ bias,
+                                                               float* __restrict__ out, int N, int d, int l2norm) {
+  __shared__ float red[16];
+  const int n = blockIdx.x;
+  float v[PRN_PER], ss = 0.f;
+  float p[PRN_PER][SPLITS];       // every partial of the thread in flight at once: N workgroups cannot hide a chain
+#pragma unroll
+  for (int i = 0; i < PRN_PER; ++i) {
+    const int j = min(threadIdx.x + 1024 * i, d - 1);
+#pragma unroll
+    for (int s = 0; s < SPLITS; ++s) p[i][s] = __builtin_nontemporal_load(part + ((size_t)s * N + n) * d + j);
+  }
+#pragma unroll
+  for (int i = 0; i < PRN_PER; ++i) {
+    const int j = threadIdx.x + 1024 * i;
+    v[i] = 0.f;
+    if (j < d) {
+      float t = 0.f;
+#pragma unroll
+      for (int s = 0; s < SPLITS; ++s) t += p[i][s];
+      v[i] = t + bias[j];
+      ss = fmaf(v[i], v[i], ss);
+    }
+  }
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  float inv = 1.f;
+  if (l2norm) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w];
+    inv = 1.0f / fmaxf(sqrtf(t), 1e-12f);
+  }
+#pragma unroll
+  for (int i = 0; i < PRN_PER; ++i) {
+    const int j = threadIdx.x + 1024 * i;
+    if (j < d) out[(size_t)n * d + j] = v[i] * inv;
+  }
+}
+
 __global__ __launch_bounds__(256) void pca_scale_kernel(float* __restrict__ out,
                                                         const float* __restrict__ ss_part, int d) {
   const int n = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
@@ -165,16 +212,23 @@ static bool pca_small_ok(int N, int D, int d, int precision) {
 // the scaling: 93 us for 3 rows (5.8 TB/s of W), 94 for 8, 102 for 16, 110 for 32 (4.9 TB/s; the row-major tile:
 // 137 us) — the growth with N is the partials (16.7 MB written and read at 32 rows).
 constexpr int PK_WAVES = 8, PK_SPLITS = 32, PK_CHUNK = 256, PK_TILES = PK_CHUNK / 8, PK_MAXN = 32;
-template <int PK_DEPTH, int OCC>
-__global__ __launch_bounds__(PK_WAVES * 64, OCC) void pca_stream_kernel(const float* __restrict__ v,
-                                                                      const float* __restrict__ wp,
-                                                                      float* __restrict__ part, int N, int D, int d,
-                                                                      int kper) {
+// KP = 2 (round 6, the default): a workgroup of 16 waves is TWO such workgroups over neighbouring K parts — waves 8-15
+// the second part, with their own input chunks in LDS — and the second part's sums reach the first through LDS at the
+// end: 16 partials per output instead of 32 (8.4 MB written and read at 32 rows instead of 16.7).  With the one-launch
+// reduction below: 98-99 us at 32 rows (5.4-5.5 TB/s; 109 before), 94.6 at 16 (102), 93 at 3-8 rows (unchanged).
+template <int PK_DEPTH, int OCC, int KP>
+__global__ __launch_bounds__(KP * PK_WAVES * 64, OCC) void pca_stream_kernel(const float* __restrict__ v,
+                                                                           const float* __restrict__ wp,
+                                                                           float* __restrict__ part, int N, int D,
+                                                                           int d, int kper) {
   typedef __attribute__((ext_vector_type(4))) float f4;
-  __shared__ __attribute__((aligned(16))) char smem[2 * PK_TILES * 1024];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  extern __shared__ __attribute__((aligned(16))) char pk_smem[];
+  const int lane = threadIdx.x & 63;
+  const int kp = KP == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 9));
+  const int wave = (threadIdx.x >> 6) & 7;
+  char* const smem = pk_smem + kp * (2 * PK_TILES * 1024);
   const int nb = blockIdx.x * PK_WAVES + wave;
-  const long k0 = (long)blockIdx.y * kper;
+  const long k0 = (long)(blockIdx.y * KP + kp) * kper;
   const int chunks = kper / PK_CHUNK;
   const f4* wt = reinterpret_cast<const f4*>(wp) + ((size_t)nb * (D / 8) + k0 / 8) * 64 + lane;   // tile t: wt[64 t]
   const int m = min(lane & 31, N - 1);
@@ -225,6 +279,19 @@ __global__ __launch_bounds__(PK_WAVES * 64, OCC) void pca_stream_kernel(const fl
   for (int c = 0; c + 1 < chunks; ++c) chunk(c, std::false_type{});
   chunk(chunks - 1, std::true_type{});
 
+  if constexpr (KP == 2) {
+    // the second K part hands its sums over through its own (now idle) chunk buffers: [wave][register][lane]
+    __syncthreads();
+    float* const xch = reinterpret_cast<float*>(pk_smem + 2 * PK_TILES * 1024) + (wave * 16) * 64 + lane;
+    if (kp == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xch[r * 64] = acc[r];
+    }
+    __syncthreads();
+    if (kp == 1) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += xch[r * 64];
+  }
   float* out = part + (size_t)blockIdx.y * N * d + nb * 32 + (lane & 31);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -380,18 +447,34 @@ int oibl_pca_forward_packed(const float* v, int N, int D, const float* w_packed,
   char* wsb = (char*)ws;
   float* part = (float*)(wsb + align_up((size_t)N * D * sizeof(float), 256));
   const dim3 grid((unsigned)(d / (32 * PK_WAVES)), PK_SPLITS);
+  constexpr int lds1 = 2 * PK_TILES * 1024;
+  int nparts = PK_SPLITS;
   // 8 loads in flight x 4 waves per SIMD (104 VGPRs) against 16 x 2 (173): 109.8 against 112.8 us at 32 rows, 92.7
   // against 95.5 at 3 (tests/gpu_pca_bench.py; all three launches)
-  if (g_pca_stream == 2)
-    hipLaunchKernelGGL((pca_stream_kernel<16, 2>), grid, dim3(PK_WAVES * 64), 0, st, v, w_packed, part, N, D, d,
+  if (g_pca_stream == 2) {
+    auto kern = pca_stream_kernel<16, 2, 1>;
+    OIBL_SET_MAX_LDS(kern, lds1);
+    hipLaunchKernelGGL(kern, grid, dim3(PK_WAVES * 64), lds1, st, v, w_packed, part, N, D, d, D / PK_SPLITS);
+  } else if (g_pca_stream == 3) {      // rounds 5's launch: 32 partials
+    auto kern = pca_stream_kernel<8, 4, 1>;
+    OIBL_SET_MAX_LDS(kern, lds1);
+    hipLaunchKernelGGL(kern, grid, dim3(PK_WAVES * 64), lds1, st, v, w_packed, part, N, D, d, D / PK_SPLITS);
+  } else {
+    auto kern = pca_stream_kernel<8, 1, 2>;
+    OIBL_SET_MAX_LDS(kern, 2 * lds1);
+    nparts = PK_SPLITS / 2;
+    hipLaunchKernelGGL(kern, dim3(grid.x, nparts), dim3(2 * PK_WAVES * 64), 2 * lds1, st, v, w_packed, part, N, D, d,
                        D / PK_SPLITS);
-  else
-    hipLaunchKernelGGL((pca_stream_kernel<8, 4>), grid, dim3(PK_WAVES * 64), 0, st, v, w_packed, part, N, D, d,
-                       D / PK_SPLITS);
+  }
   OIBL_LAUNCH_CHECK();
+  if (d <= 1024 * PRN_PER && g_pca_stream == 1) {
+    hipLaunchKernelGGL(pca_reduce_norm_kernel<PK_SPLITS / 2>, dim3((unsigned)N), dim3(1024), 0, st, part, b, out, N, d, l2norm);
+    OIBL_LAUNCH_CHECK();
+    return OIBL_OK;
+  }
   float* ss_part = (float*)((char*)part + align_up((size_t)PK_SPLITS * N * d * sizeof(float), 256));
   const dim3 rgrid((unsigned)((d + 255) / 256), (unsigned)N);
-  hipLaunchKernelGGL(pca_reduce_kernel, rgrid, dim3(256), 0, st, part, b, out, ss_part, N, d, PK_SPLITS);
+  hipLaunchKernelGGL(pca_reduce_kernel, rgrid, dim3(256), 0, st, part, b, out, ss_part, N, d, nparts);
   OIBL_LAUNCH_CHECK();
   if (l2norm) {
     hipLaunchKernelGGL(pca_scale_kernel, rgrid, dim3(256), 0, st, out, ss_part, d);

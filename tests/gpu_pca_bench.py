@@ -33,7 +33,7 @@ pw = ops.PcaWeight(w)
 for N in (1, 3, 8, 16, 32):
     v = torch.nn.functional.normalize(torch.randn((N, 32768), device=dev), dim=1)
     row = []
-    for variant in (1, 2):
+    for variant in (1, 3, 2, 1, 3):
         L.oibl_debug_set_pca_stream(variant)
         old = ops.PCA_STREAM_MIN_ROWS
         ops.PCA_STREAM_MIN_ROWS = 1
@@ -48,7 +48,8 @@ for N in (1, 3, 8, 16, 32):
         torch.cuda.synchronize()
         ops.PCA_STREAM_MIN_ROWS = old
         t = s.elapsed_time(e) / 50
-        row.append(f"packed stream, {'8 loads x 4 waves' if variant == 1 else '16 loads x 2 waves'} per SIMD "
-                   f"{t * 1e3:7.1f} us ({w.numel() * 4 / t / 1e9:5.2f} TB/s)")
+        name = {1: "16-wave workgroup, two K parts (16 partials)", 3: "8 loads x 4 waves per SIMD (32 partials)",
+                2: "16 loads x 2 waves per SIMD (32 partials)"}[variant]
+        row.append(f"{name} {t * 1e3:7.1f} us ({w.numel() * 4 / t / 1e9:5.2f} TB/s)")
     print(f"N={N:2d}: " + " | ".join(row))
 L.oibl_debug_set_pca_stream(1)

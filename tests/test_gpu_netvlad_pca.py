@@ -118,10 +118,16 @@ def test_pca_packed_weight_streaming_kernel(dev):
     assert torch.equal(ops.pca(v[:32].contiguous(), pw, b), outs[32])
     raw = ops.pca(v[:7].contiguous(), pw, b, l2norm=False)
     assert_rel_l2("packed, without normalize", torch.nn.functional.normalize(raw.cpu().double(), dim=1), want[:7], 5e-6)
-    # the second instantiation (16 loads in flight, 2 waves per SIMD): same sums in the same order
+    # the 8-wave instantiations (round 5's: 8 loads in flight x 4 waves per SIMD, and 16 x 2): 32 partials summed one
+    # by one where the default adds neighbouring K parts in LDS first — the same sums as each other, bit for bit, and
+    # the default's to rounding
     lib.debug_hooks().oibl_debug_set_pca_stream(2)
     try:
-        assert torch.equal(ops.pca(v[:32].contiguous(), pw, b), outs[32])
+        deep = ops.pca(v[:32].contiguous(), pw, b)
+        lib.debug_hooks().oibl_debug_set_pca_stream(3)
+        assert torch.equal(ops.pca(v[:32].contiguous(), pw, b), deep)
+        assert not torch.equal(deep, outs[32])
+        assert_rel_l2("32 partials vs 16", deep.cpu(), outs[32].cpu(), 1e-6)
         lib.debug_hooks().oibl_debug_set_pca_stream(0)
         assert torch.equal(ops.pca(v[:7].contiguous(), pw, b), tile[7])    # hook 0: the packed form is not offered
     finally:
